@@ -1,0 +1,453 @@
+// Per-lane articulated-body dynamics of the T1 legs (one LEG per wavefront lane,
+// two neighbouring lanes = one environment).
+//
+// Replaces `gym.simulate` (reference envs/t1.py:451, PhysX inside Isaac Gym) for the
+// 13-body / 12-DoF collapsed T1 (resources/T1/T1_locomotion.xml:36-139).  Algorithm:
+// floating-base articulated-body algorithm (Featherstone, RBDA Table 9.4) in body
+// coordinates, specialised to this robot's structure:
+//   * two identical 6-link serial chains hanging off the trunk -> each lane owns one
+//     chain; the only exchange is the chain's articulated inertia / bias force at the
+//     trunk (27 floats, one DPP lane swap per value)
+//   * every joint is revolute about a coordinate axis of its own frame and no body
+//     frame is rotated against its parent at q=0 -> joint transforms are a 2-D rotation
+//     (compile-time axis) plus a translation
+//   * spatial inertias are kept as 3x3 blocks [A H; H^T M] with A, M symmetric
+// Contact and joint limits are linearly-implicit penalty forces folded into the
+// articulated inertia; the oracle in oracle/dyn_ref.c states the
+// same model with dense 6x6 algebra in double precision.
+#pragma once
+#include "bg_math.h"
+
+namespace bg {
+
+constexpr int LEG_LINKS = 6;
+// Hip_Pitch y, Hip_Roll x, Hip_Yaw z, Knee_Pitch y, Ankle_Pitch y, Ankle_Roll x  (T1_locomotion.xml:56-79)
+constexpr int LEG_AXIS[LEG_LINKS] = {2, 1, 3, 2, 2, 1};
+
+struct LinkConst {   // one rigid body, per-env randomisation already applied
+    V3 pos;          // origin in the parent frame
+    float m;         // mass
+    V3 mc;           // mass * centre of mass
+    S3 Io;           // rotational inertia about the body origin
+};
+
+struct Phys {
+    float dt;
+    V3 g;
+    float contact_ramp, friction_visc, limit_k, limit_d;
+    int clamp_qd;
+};
+
+struct TerrainDev {
+    int type;  // 0 plane, 1 heightfield
+    int rows, cols, border_px;
+    float inv_hscale, vscale;
+    const int16_t* hf;
+};
+
+struct LegParams {
+    LinkConst lk[LEG_LINKS];
+    float q_lo[LEG_LINKS], q_hi[LEG_LINKS], qd_max[LEG_LINKS];
+    V3 corner[4];
+    float mu, kn, dn;  // combined friction, normal stiffness, normal damping of this foot
+};
+
+struct LegState { float q[LEG_LINKS], qd[LEG_LINKS]; };
+
+struct BaseState {
+    V3 pos;
+    float quat[4];  // xyzw
+    V3 vlin, vang;  // world frame (Isaac Gym root-state layout, t1.py:221-222)
+};
+
+struct LegWork {  // what the inward sweep leaves behind for the outward sweep
+    float c[LEG_LINKS], s[LEG_LINKS];
+    SV cb[LEG_LINKS];  // velocity-product accelerations
+    SV U[LEG_LINKS];
+    float dinv[LEG_LINKS], u[LEG_LINKS];
+    M3 Rfoot;          // foot -> world
+    SI Bc;             // contact impedance on the foot
+    SV f0c;            // contact wrench at the current state (foot coords)
+    bool contact;
+};
+
+struct BaseContribution { SI I; SV p; };  // articulated inertia / bias force seen at the trunk
+
+BG_HD SI rigid_inertia(const LinkConst& k) {
+    SI I;
+    I.A = k.Io;
+    I.H = skew(k.mc);
+    I.M = s3_zero();
+    I.M.e[0] = I.M.e[1] = I.M.e[2] = k.m;
+    return I;
+}
+BG_HD SV mul(const SI& I, SV v) {
+    SV f;
+    f.a = mul(I.A, v.a) + mul(I.H, v.l);
+    f.l = mulT(I.H, v.a) + mul(I.M, v.l);
+    return f;
+}
+// rigid-body shortcut of  I v  (H = skew(mc), M = m 1)
+BG_HD SV mul_rigid(const LinkConst& k, SV v) {
+    SV f;
+    f.a = mul(k.Io, v.a) + cross(k.mc, v.l);
+    f.l = k.m * v.l - cross(k.mc, v.a);
+    return f;
+}
+// v x* f  (spatial force cross product, RBDA eq. 2.32)
+BG_HD SV crf(SV v, SV f) {
+    SV o;
+    o.a = cross(v.a, f.a) + cross(v.l, f.l);
+    o.l = cross(v.a, f.l);
+    return o;
+}
+
+// bilinear terrain height and surface normal (reference utils/terrain.py:101-121; indices clamped)
+BG_HD void terrain_query(const TerrainDev& t, float x, float y, float* h, V3* n) {
+    if (t.type == 0) { *h = 0.f; *n = v3(0.f, 0.f, 1.f); return; }
+    float px = (float)t.border_px + x * t.inv_hscale, py = (float)t.border_px + y * t.inv_hscale;
+    int x1 = (int)floorf(px), y1 = (int)floorf(py);
+    x1 = x1 < 0 ? 0 : (x1 > t.rows - 2 ? t.rows - 2 : x1);
+    y1 = y1 < 0 ? 0 : (y1 > t.cols - 2 ? t.cols - 2 : y1);
+    float fx = px - (float)x1, fy = py - (float)y1;
+    const int16_t* p = t.hf + (size_t)x1 * t.cols + y1;
+    float h00 = (float)p[0], h01 = (float)p[1], h10 = (float)p[t.cols], h11 = (float)p[t.cols + 1];
+    *h = ((1.f - fx) * (1.f - fy) * h00 + fx * (1.f - fy) * h10 + (1.f - fx) * fy * h01 + fx * fy * h11) * t.vscale;
+    float hx = ((1.f - fy) * (h10 - h00) + fy * (h11 - h01)) * t.vscale * t.inv_hscale;
+    float hy = ((1.f - fx) * (h01 - h00) + fx * (h11 - h10)) * t.vscale * t.inv_hscale;
+    float inv = bg_rsqrt(hx * hx + hy * hy + 1.0f);
+    *n = v3(-hx * inv, -hy * inv, inv);
+}
+BG_HD float terrain_height(const TerrainDev& t, float x, float y) {
+    float h; V3 n;
+    terrain_query(t, x, y, &h, &n);
+    return h;
+}
+
+// ---------------------------------------------------------------- outward sweep, link I
+template <int I>
+BG_HD void leg_outward(const LegParams& lp, const LegState& ls, LegWork& w, SV vpar, M3 Rpar, V3 ppar, SV* vout, V3* pfoot) {
+    constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    float s, c;
+    bg_sincos(ls.q[I], &s, &c);
+    w.c[I] = c; w.s[I] = s;
+    // v_i = X v_parent + S qd :  w' = E w ; v' = E (v + w x r)
+    SV v;
+    v.a = rotT<AX>(c, s, vpar.a);
+    v.l = rotT<AX>(c, s, vpar.l + cross(vpar.a, lp.lk[I].pos));
+    // c_i = v_i x (S qd)   (S = unit angular axis A)
+    V3 sq = v3(0.f, 0.f, 0.f); sq.e[A] = ls.qd[I];
+    w.cb[I].a = cross(v.a, sq);
+    w.cb[I].l = cross(v.l, sq);
+    v.a.e[A] += ls.qd[I];
+    vout[I] = v;
+    // world pose of the link (needed for the foot only, carried down the chain)
+    V3 p = ppar + mul(Rpar, lp.lk[I].pos);
+    M3 R;  // R_world_child = R_world_parent * R(axis,q): rotate the columns J,K
+    {
+        constexpr int J = Plane<AX>::J, K = Plane<AX>::K;
+        R = Rpar;
+        for (int r = 0; r < 3; r++) {
+            R.e[r][J] = c * Rpar.e[r][J] + s * Rpar.e[r][K];
+            R.e[r][K] = -s * Rpar.e[r][J] + c * Rpar.e[r][K];
+        }
+    }
+    if constexpr (I + 1 < LEG_LINKS) {
+        leg_outward<I + 1>(lp, ls, w, v, R, p, vout, pfoot);
+    } else {
+        w.Rfoot = R;
+        *pfoot = p;
+    }
+}
+
+// ---------------------------------------------------------------- foot contact (4 sole corners)
+BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& lp, LegWork& w, SV vfoot, V3 pfoot, V3* force_w0) {
+    SI B; B.A = s3_zero(); B.H = m3_zero(); B.M = s3_zero();
+    SV f0 = sv_zero();
+    V3 fw_sum = v3(0.f, 0.f, 0.f);
+    bool any = false;
+    for (int k = 0; k < 4; k++) {
+        V3 r = lp.corner[k];
+        V3 xw = pfoot + mul(w.Rfoot, r);
+        V3 vb = vfoot.l + cross(vfoot.a, r);
+        V3 vw = mul(w.Rfoot, vb);
+        float h; V3 n;
+        terrain_query(tr, xw.e[0], xw.e[1], &h, &n);
+        float pen = (h - xw.e[2]) * n.e[2];
+        float vn = dot(vw, n);
+        float ramp = pen < ph.contact_ramp ? pen / ph.contact_ramp : 1.0f;
+        float d_eff = lp.dn * ramp;
+        float fn0 = lp.kn * pen - d_eff * vn;
+        if (pen > 0.f && fn0 > 0.f) {
+            any = true;
+            V3 vt = vw - vn * n;
+            float vtn = sqrtf(dot(vt, vt));
+            float c_t = fminf(ph.friction_visc, lp.mu * fn0 / (vtn + 1e-6f));
+            V3 fw = fn0 * n - c_t * vt;
+            fw_sum = fw_sum + fw;
+            V3 nb = mulT(w.Rfoot, n), fb = mulT(w.Rfoot, fw);
+            float cn = ph.dt * (d_eff + ph.dt * lp.kn), ctt = ph.dt * c_t;
+            M3 C = outer((cn - ctt) * nb, nb);
+            C.e[0][0] += ctt; C.e[1][1] += ctt; C.e[2][2] += ctt;
+            // wrench J^T f = (r x f, f);  B = J^T C J = [-rx C rx, rx C; -C rx, C]
+            f0.a = f0.a + cross(r, fb);
+            f0.l = f0.l + fb;
+            M3 rC = cross_cols(r, C);          // rx C
+            M3 rCr = mul_skew(rC, r);           // rx C rx
+            B.M = B.M + upper(C);
+            B.H = B.H + rC;
+            S3 a = upper(rCr);
+            for (int i = 0; i < 6; i++) B.A.e[i] -= a.e[i];
+        }
+    }
+    w.Bc = B; w.f0c = f0; w.contact = any;
+    *force_w0 = fw_sum;
+}
+
+// ---------------------------------------------------------------- inward sweep, link I (child -> parent)
+template <int I>
+BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, const float* tau, LegWork& w, const SV* v, SI IA, SV pA,
+                      BaseContribution* out) {
+    constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    // joint limit spring/damper, implicit in the joint velocity: tau_lim = t0 - bl * qdd
+    float viol = ls.q[I] < lp.q_lo[I] ? ls.q[I] - lp.q_lo[I] : (ls.q[I] > lp.q_hi[I] ? ls.q[I] - lp.q_hi[I] : 0.f);
+    float t0 = 0.f, bl = 0.f;
+    if (viol != 0.f) { t0 = -ph.limit_k * viol - ph.limit_d * ls.qd[I]; bl = ph.dt * (ph.limit_d + ph.dt * ph.limit_k); }
+    // U = IA S ; d = S.U + bl ; u = tau - S.pA
+    M3 Af = full(IA.A), Mf = full(IA.M);
+    SV U;
+    U.a = v3(Af.e[0][A], Af.e[1][A], Af.e[2][A]);
+    U.l = v3(IA.H.e[A][0], IA.H.e[A][1], IA.H.e[A][2]);
+    float d = U.a.e[A] + bl;
+    float dinv = 1.0f / d;
+    float u = tau[I] + t0 - pA.a.e[A];
+    w.U[I] = U; w.dinv[I] = dinv; w.u[I] = u;
+    // Ia = IA - U U^T / d ;  pa = pA + Ia c + U u / d
+    V3 Uad = dinv * U.a, Uld = dinv * U.l;
+    M3 A1 = Af - outer(Uad, U.a), H1 = IA.H - outer(Uad, U.l), M1 = Mf - outer(Uld, U.l);
+    SV cb = w.cb[I];
+    SV pa;
+    pa.a = pA.a + mul(A1, cb.a) + mul(H1, cb.l) + u * Uad;
+    pa.l = pA.l + mulT(H1, cb.a) + mul(M1, cb.l) + u * Uld;
+    // to parent coordinates: rotate by R(axis,q) then shift the origin by r = pos
+    float c = w.c[I], s = w.s[I];
+    A1 = rot_conj<AX>(c, s, A1); H1 = rot_conj<AX>(c, s, H1); M1 = rot_conj<AX>(c, s, M1);
+    V3 r = lp.lk[I].pos;
+    M3 H2 = H1 + cross_cols(r, M1);
+    M3 A2 = A1 + cross_cols(r, transpose(H1)) - mul_skew(H2, r);
+    SV pp;
+    pp.l = rot<AX>(c, s, pa.l);
+    pp.a = rot<AX>(c, s, pa.a) + cross(r, pp.l);
+    if constexpr (I > 0) {
+        // parent's own rigid inertia and velocity-dependent bias
+        const LinkConst& pk = lp.lk[I - 1];
+        SI IP = rigid_inertia(pk);
+        SV vp = v[I - 1];
+        SV pP = crf(vp, mul_rigid(pk, vp));
+        IP.A = IP.A + upper(A2); IP.H = IP.H + H2; IP.M = IP.M + upper(M1);
+        leg_inward<I - 1>(ph, lp, ls, tau, w, v, IP, pP + pp, out);
+    } else {
+        out->I.A = upper(A2); out->I.H = H2; out->I.M = upper(M1);
+        out->p = pp;
+    }
+}
+
+// Everything a lane does before the pair exchange: kinematics, contact, inward sweep.
+// gb = gravity in base coordinates.  Returns this leg's contribution at the trunk.
+BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
+                                  const BaseState& bs, M3 R0, SV v0, LegWork& w, V3* foot_force_w0) {
+    SV v[LEG_LINKS];
+    V3 pfoot;
+    leg_outward<0>(lp, ls, w, v0, R0, bs.pos, v, &pfoot);
+    foot_contact(ph, tr, lp, w, v[LEG_LINKS - 1], pfoot, foot_force_w0);
+    const LinkConst& fk = lp.lk[LEG_LINKS - 1];
+    SI IA = rigid_inertia(fk);
+    SV pA = crf(v[LEG_LINKS - 1], mul_rigid(fk, v[LEG_LINKS - 1]));
+    if (w.contact) {
+        // f_ext = f0 - B a_true = (f0 - B ag) - B a'   with a' = a_true - ag  (gravity field in foot coords)
+        SV ag; ag.a = v3(0.f, 0.f, 0.f); ag.l = mulT(w.Rfoot, ph.g);
+        SV Bag = mul(w.Bc, ag);
+        IA.A = IA.A + w.Bc.A; IA.H = IA.H + w.Bc.H; IA.M = IA.M + w.Bc.M;
+        pA = pA - (w.f0c - Bag);
+    }
+    BaseContribution out;
+    leg_inward<LEG_LINKS - 1>(ph, lp, ls, tau, w, v, IA, pA, &out);
+    return out;
+}
+
+// Trunk: solve  IA0 a0' = -pA0  by block elimination on the 3x3 blocks.
+BG_HD SV base_solve(const SI& I, SV p) {
+    S3 Minv = inv_sym(I.M);
+    // (A - H Minv H^T) alpha = -n + H Minv f
+    M3 HMi = mul(I.H, full(Minv));
+    M3 Sch = full(I.A) - mul(HMi, transpose(I.H));
+    V3 rhs = mul(HMi, p.l) - p.a;
+    SV a;
+    a.a = mul(inv_sym(upper(Sch)), rhs);
+    a.l = -1.0f * mul(Minv, p.l + mulT(I.H, a.a));
+    return a;
+}
+
+// ---------------------------------------------------------------- outward acceleration sweep + joint integration
+template <int I>
+BG_HD void leg_accel(const Phys& ph, const LegParams& lp, LegState& ls, const LegWork& w, SV apar, float* qdd, SV* afoot) {
+    constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    float c = w.c[I], s = w.s[I];
+    SV a;
+    a.a = rotT<AX>(c, s, apar.a);
+    a.l = rotT<AX>(c, s, apar.l + cross(apar.a, lp.lk[I].pos));
+    a = a + w.cb[I];
+    float qa = (w.u[I] - dot(w.U[I], a)) * w.dinv[I];
+    a.a.e[A] += qa;
+    qdd[I] = qa;
+    if constexpr (I + 1 < LEG_LINKS) leg_accel<I + 1>(ph, lp, ls, w, a, qdd, afoot);
+    else *afoot = a;
+}
+
+BG_HD void integrate_leg(const Phys& ph, const LegParams& lp, LegState& ls, const float* qdd) {
+    for (int i = 0; i < LEG_LINKS; i++) {
+        float qd = ls.qd[i] + ph.dt * qdd[i];
+        if (ph.clamp_qd) qd = fminf(fmaxf(qd, -lp.qd_max[i]), lp.qd_max[i]);
+        ls.qd[i] = qd;
+        ls.q[i] += ph.dt * qd;
+    }
+}
+
+// true base acceleration -> d/dt of the Isaac-style world velocities
+BG_HD void base_world_rates(M3 R0, SV v0, SV a0p, V3 g, V3* lin_w, V3* ang_w) {
+    V3 gb = mulT(R0, g);
+    V3 lin_b = a0p.l + gb + cross(v0.a, v0.l);  // classical acceleration of the origin
+    *lin_w = mul(R0, lin_b);
+    *ang_w = mul(R0, a0p.a);
+}
+
+BG_HD void integrate_base(const Phys& ph, BaseState& bs, V3 lin_w, V3 ang_w) {
+    bs.vlin = bs.vlin + ph.dt * lin_w;
+    bs.vang = bs.vang + ph.dt * ang_w;
+    bs.pos = bs.pos + ph.dt * bs.vlin;
+    // q+ = exp(dt w_world) * q
+    V3 wv = bs.vang;
+    float w2 = dot(wv, wv);
+    float dqx = 0.f, dqy = 0.f, dqz = 0.f, dqw = 1.f;
+    if (w2 > 1e-24f) {
+        float wn = sqrtf(w2);
+        float sh, ch;
+        bg_sincos(0.5f * wn * ph.dt, &sh, &ch);
+        float k = sh / wn;
+        dqx = wv.e[0] * k; dqy = wv.e[1] * k; dqz = wv.e[2] * k; dqw = ch;
+    }
+    float x = bs.quat[0], y = bs.quat[1], z = bs.quat[2], w = bs.quat[3];
+    float nw = dqw * w - dqx * x - dqy * y - dqz * z;
+    float nx = dqw * x + dqx * w + dqy * z - dqz * y;
+    float ny = dqw * y - dqx * z + dqy * w + dqz * x;
+    float nz = dqw * z + dqx * y - dqy * x + dqz * w;
+    float inv = bg_rsqrt(nx * nx + ny * ny + nz * nz + nw * nw);
+    bs.quat[0] = nx * inv; bs.quat[1] = ny * inv; bs.quat[2] = nz * inv; bs.quat[3] = nw * inv;
+}
+
+// PD actuator with joint friction and torque clipping (reference envs/t1.py:446-448)
+BG_HD float pd_torque(float kp, float kd, float fric, float limit, float target, float q, float qd) {
+    float t = kp * (target - q) - kd * qd;
+    float fr = fminf(fric, fabsf(t));
+    t -= t > 0.f ? fr : (t < 0.f ? -fr : 0.f);
+    return fminf(fmaxf(t, -limit), limit);
+}
+
+// Body-coordinate trunk velocity from the world-frame root state
+BG_HD SV base_body_velocity(M3 R0, const BaseState& bs) {
+    SV v;
+    v.a = mulT(R0, bs.vang);
+    v.l = mulT(R0, bs.vlin);
+    return v;
+}
+
+// Trunk's own articulated terms (rigid inertia, velocity bias, applied wrench in base coords)
+BG_HD BaseContribution base_own(const LinkConst& bk, SV v0, SV wrench /* a = torque, l = force */) {
+    BaseContribution b;
+    b.I = rigid_inertia(bk);
+    b.p = crf(v0, mul_rigid(bk, v0)) - wrench;
+    return b;
+}
+
+// ---------------------------------------------------------------- model constants and per-env parameters
+struct ModelDev {  // nominal (un-randomised) model, shared by all envs; filled by bg_model_create
+    float pos[13][3];
+    float mass[13];
+    float com[13][3];
+    float inertia[13][6];  // about the centre of mass: xx yy zz xy xz yz
+    float q_lo[12], q_hi[12], qd_max[12], tau_lim[12];
+    float corner[4][3];
+};
+
+// nominal body + per-env randomisation (mass scale, com offset; inertia scales with the mass as
+// Isaac Gym's recomputeInertia=True does, reference t1.py:129-131) -> constants about the body origin
+BG_HD LinkConst make_link(const ModelDev& m, int b, float mass_scale, V3 com_off) {
+    LinkConst k;
+    k.pos = v3(m.pos[b][0], m.pos[b][1], m.pos[b][2]);
+    k.m = m.mass[b] * mass_scale;
+    V3 c = v3(m.com[b][0], m.com[b][1], m.com[b][2]) + com_off;
+    k.mc = k.m * c;
+    float cc = dot(c, c);
+    k.Io.e[0] = m.inertia[b][0] * mass_scale + k.m * (cc - c.e[0] * c.e[0]);
+    k.Io.e[1] = m.inertia[b][1] * mass_scale + k.m * (cc - c.e[1] * c.e[1]);
+    k.Io.e[2] = m.inertia[b][2] * mass_scale + k.m * (cc - c.e[2] * c.e[2]);
+    k.Io.e[3] = m.inertia[b][3] * mass_scale - k.m * c.e[0] * c.e[1];
+    k.Io.e[4] = m.inertia[b][4] * mass_scale - k.m * c.e[0] * c.e[2];
+    k.Io.e[5] = m.inertia[b][5] * mass_scale - k.m * c.e[1] * c.e[2];
+    return k;
+}
+
+struct ContactCfg { float k, d, terrain_mu, terrain_restitution; };
+
+// per-env parameter arrays are SoA: value(field f, env e) = p[f * n + e]
+BG_HD void load_leg_params(const ModelDev& m, const ContactCfg& cc, int leg, int e, int n, const float* mass_scale /*[13][n]*/,
+                           const float* com_off /*[39][n]*/, const float* foot_mat /*[6][n]*/, LegParams& lp) {
+    for (int i = 0; i < LEG_LINKS; i++) {
+        int b = 1 + leg * LEG_LINKS + i, j = leg * LEG_LINKS + i;
+        lp.lk[i] = make_link(m, b, mass_scale[(size_t)b * n + e],
+                             v3(com_off[(size_t)(3 * b) * n + e], com_off[(size_t)(3 * b + 1) * n + e], com_off[(size_t)(3 * b + 2) * n + e]));
+        lp.q_lo[i] = m.q_lo[j]; lp.q_hi[i] = m.q_hi[j]; lp.qd_max[i] = m.qd_max[j];
+    }
+    for (int k = 0; k < 4; k++) lp.corner[k] = v3(m.corner[k][0], m.corner[k][1], m.corner[k][2]);
+    float mu_f = foot_mat[(size_t)(3 * leg) * n + e], compl_f = foot_mat[(size_t)(3 * leg + 1) * n + e], rest_f = foot_mat[(size_t)(3 * leg + 2) * n + e];
+    lp.mu = 0.5f * (mu_f + cc.terrain_mu);  // PhysX default material combine: average
+    lp.kn = cc.k / compl_f;
+    lp.dn = cc.d * (1.0f - 0.5f * (rest_f + cc.terrain_restitution));
+}
+BG_HD LinkConst load_base_link(const ModelDev& m, int e, int n, const float* mass_scale, const float* com_off) {
+    return make_link(m, 0, mass_scale[e], v3(com_off[e], com_off[(size_t)n + e], com_off[(size_t)2 * n + e]));
+}
+
+// ---------------------------------------------------------------- one substep, split around the lane-pair exchange
+struct SubstepCtx { M3 R0; SV v0; LegWork w; };
+
+BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
+                                   const BaseState& bs, SubstepCtx& cx) {
+    cx.R0 = quat_to_mat(bs.quat);
+    cx.v0 = base_body_velocity(cx.R0, bs);
+    V3 unused;
+    return leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused);
+}
+// `both` = this leg's contribution + the partner leg's.  Returns accelerations; does not integrate.
+BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& lp, LegState& ls, const SubstepCtx& cx, const BaseContribution& both,
+                         SV wrench, float* qdd, V3* lin_w, V3* ang_w, V3* foot_force_w) {
+    BaseContribution own = base_own(bk, cx.v0, wrench);
+    SI I; I.A = own.I.A + both.I.A; I.H = own.I.H + both.I.H; I.M = own.I.M + both.I.M;
+    SV a0p = base_solve(I, own.p + both.p);
+    SV afoot;
+    leg_accel<0>(ph, lp, ls, cx.w, a0p, qdd, &afoot);
+    base_world_rates(cx.R0, cx.v0, a0p, ph.g, lin_w, ang_w);
+    V3 fw = v3(0.f, 0.f, 0.f);
+    if (cx.w.contact) {  // force that acts over the step: f0 - B a_true
+        SV at = afoot; at.l = at.l + mulT(cx.w.Rfoot, ph.g);
+        V3 fb = cx.w.f0c.l - (mulT(cx.w.Bc.H, at.a) + mul(cx.w.Bc.M, at.l));
+        fw = mul(cx.w.Rfoot, fb);
+    }
+    *foot_force_w = fw;
+}
+BG_HD void substep_integrate(const Phys& ph, const LegParams& lp, LegState& ls, BaseState& bs, const float* qdd, V3 lin_w, V3 ang_w) {
+    integrate_leg(ph, lp, ls, qdd);
+    integrate_base(ph, bs, lin_w, ang_w);
+}
+
+}  // namespace bg

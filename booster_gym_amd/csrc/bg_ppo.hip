@@ -1,0 +1,325 @@
+// HIP kernels + C ABI for the PPO half of the hot path (gfx950 only):
+//   bg_gae            reference utils/utils.py:33-44 (discount_values) + utils/runner.py:135,144 fused into one backward scan
+//   bg_ppo_loss       reference utils/runner.py:145-174 + utils/utils.py:47-52: forward AND analytic backward in one pass
+//   bg_gaussian_logp  reference utils/runner.py:123-125
+//   bg_actor_sample   reference utils/model.py:29-32 + dist.sample() (runner.py:109-111) as one launch
+//   bg_adam_step      reference utils/runner.py:162-165 (clip_grad_norm_ + torch.optim.Adam.step) on a flat buffer
+//   bg_adapt_lr       reference utils/runner.py:174-180 without the host sync
+// All of these are HBM/latency-bound elementwise or scan work; none is reshaped into a GEMM.
+#include <hip/hip_runtime.h>
+#include <string>
+
+#include "../../include/booster_gym_amd.h"
+#include "bg_rng.h"
+
+extern int bg_set_error(int code, const char* msg);
+#define HIP_OK(expr)                                                                        \
+    do {                                                                                    \
+        hipError_t _e = (expr);                                                             \
+        if (_e != hipSuccess) return bg_set_error(-2, hipGetErrorString(_e));               \
+    } while (0)
+
+// ------------------------------------------------------------------ block reduction helper (wave64)
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+template <int NV>
+__device__ __forceinline__ void block_atomic_add(double (&v)[NV], double* dst, double* smem /*[NV * waves]*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+    for (int k = 0; k < NV; k++) {
+        double s = wave_sum(v[k]);
+        if (lane == 0) smem[k * waves + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < NV) {
+        double s = 0;
+        for (int w = 0; w < waves; w++) s += smem[threadIdx.x * waves + w];
+        atomicAdd(&dst[threadIdx.x], s);
+    }
+}
+
+// ------------------------------------------------------------------ GAE: one lane per env, backward scan over T
+__global__ __launch_bounds__(256) void gae_kernel(int T, int N, float* __restrict__ rewards, const uint8_t* __restrict__ dones,
+                                                  const uint8_t* __restrict__ touts, const float* __restrict__ values,
+                                                  const float* __restrict__ last_values, float gamma, float lam, float* __restrict__ adv,
+                                                  float* __restrict__ ret, double* __restrict__ sums) {
+    __shared__ double sm[3 * 4];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (e < N) {
+        float next_v = last_values[e], last_adv = 0.f;
+        for (int t = T - 1; t >= 0; t--) {
+            const size_t k = (size_t)t * N + e;
+            const float v = values[k];
+            const bool to = touts[k] != 0;
+            float r = rewards[k];
+            if (to) { r = v; rewards[k] = v; }  // runner.py:135 (in place, repeated every mini-epoch with the current critic)
+            const float nn = (dones[k] != 0 || to) ? 0.f : 1.f;
+            const float delta = r + gamma * nn * next_v - v;
+            last_adv = delta + gamma * lam * nn * last_adv;
+            adv[k] = last_adv;
+            ret[k] = v + last_adv;
+            acc[0] += (double)last_adv; acc[1] += (double)last_adv * (double)last_adv; acc[2] += 1.0;
+            next_v = v;
+        }
+    }
+    block_atomic_add<3>(acc, sums, sm);
+}
+
+// ------------------------------------------------------------------ PPO loss forward + backward, one lane per sample
+constexpr float kHalfLog2Pi = 0.9189385332046727f;
+
+template <int A>
+__global__ __launch_bounds__(256) void ppo_loss_kernel(int B, const float* __restrict__ mu, const float* __restrict__ logstd,
+                                                       const float* __restrict__ actions, const float* __restrict__ old_mu,
+                                                       const float* __restrict__ old_logstd, const float* __restrict__ old_logp,
+                                                       const float* __restrict__ adv, const double* __restrict__ adv_stats,
+                                                       const float* __restrict__ values, const float* __restrict__ returns, float e_clip,
+                                                       float bound_coef, float entropy_coef, float* __restrict__ grad_mu,
+                                                       float* __restrict__ grad_values, double* __restrict__ grad_logstd,
+                                                       double* __restrict__ stats) {
+    __shared__ double sm[(A + 5) * 4];
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    // advantage normalisation: (adv - mean) / (std + 1e-8), torch.std is the unbiased estimator (runner.py:145)
+    const double cnt = adv_stats[2], mean_d = adv_stats[0] / cnt;
+    double var_d = (adv_stats[1] - cnt * mean_d * mean_d) / (cnt - 1.0);
+    if (var_d < 0.0) var_d = 0.0;
+    const float mean = (float)mean_d, inv_std = 1.0f / ((float)sqrt(var_d) + 1e-8f);
+    const float invB = 1.0f / (float)B;
+    float sig[A], isig2[A], osig[A];
+    float ent = 0.f;
+    for (int a = 0; a < A; a++) {
+        sig[a] = expf(logstd[a]); isig2[a] = 1.0f / (sig[a] * sig[a]); osig[a] = expf(old_logstd[a]);
+        ent += 0.5f + kHalfLog2Pi + logstd[a];
+    }
+    double acc[A + 5];
+    for (int k = 0; k < A + 5; k++) acc[k] = 0.0;
+    if (b < B) {
+        float m[A], d[A];
+        float logp = 0.f, kl = 0.f, bound = 0.f;
+        for (int a = 0; a < A; a++) {
+            m[a] = mu[(size_t)b * A + a];
+            d[a] = actions[(size_t)b * A + a] - m[a];
+            logp += -0.5f * d[a] * d[a] * isig2[a] - logstd[a] - kHalfLog2Pi;
+            const float dm = m[a] - old_mu[(size_t)b * A + a];
+            kl += logstd[a] - old_logstd[a] + 0.5f * (osig[a] * osig[a] + dm * dm) * isig2[a] - 0.5f;
+            const float hi = fmaxf(m[a] - 1.0f, 0.f), lo = fminf(m[a] + 1.0f, 0.f);
+            bound += hi * hi + lo * lo;
+        }
+        const float An = (adv[b] - mean) * inv_std;
+        const float ratio = expf(logp - old_logp[b]);
+        const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
+        const float s1 = -An * ratio, s2 = -An * rc;
+        const float actor = fmaxf(s1, s2);
+        // d max(s1,s2)/d logp: through s1 when it wins or ties, through the clamp only inside the clip range
+        const bool inside = ratio >= 1.0f - e_clip && ratio <= 1.0f + e_clip;
+        const float dlogp = (inside || s1 > s2) ? -An * ratio * invB : 0.f;
+        const float v = values[b], rt = returns[b];
+        const float verr = v - rt;
+        grad_values[b] = 2.0f * verr * invB;
+        const float bscale = bound_coef * 2.0f * invB / (float)A;
+        for (int a = 0; a < A; a++) {
+            const float hi = fmaxf(m[a] - 1.0f, 0.f), lo = fminf(m[a] + 1.0f, 0.f);
+            grad_mu[(size_t)b * A + a] = dlogp * d[a] * isig2[a] + bscale * (hi + lo);
+            acc[a] = (double)(dlogp * (d[a] * d[a] * isig2[a] - 1.0f));
+        }
+        acc[A + 0] = (double)(verr * verr);
+        acc[A + 1] = (double)actor;
+        acc[A + 2] = (double)bound;
+        acc[A + 3] = (double)ent;
+        acc[A + 4] = (double)kl;
+    }
+    // reduce: grad_logstd[A] and stats[5]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;
+    for (int k = 0; k < A + 5; k++) {
+        double s = wave_sum(acc[k]);
+        if (lane == 0) sm[k * waves + wave] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < A + 5) {
+        double s = 0;
+        for (int w = 0; w < waves; w++) s += sm[threadIdx.x * waves + w];
+        if (threadIdx.x < A) atomicAdd(&grad_logstd[threadIdx.x], s);
+        else atomicAdd(&stats[threadIdx.x - A], s);
+    }
+    if (blockIdx.x == 0 && threadIdx.x < A) atomicAdd(&grad_logstd[threadIdx.x], (double)entropy_coef);  // d(entropy.mean())/dlogstd = 1
+}
+
+template <int A>
+__global__ void gaussian_logp_kernel(int B, const float* __restrict__ mu, const float* __restrict__ logstd, const float* __restrict__ actions,
+                                     float* __restrict__ logp) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    float s = 0.f;
+    for (int a = 0; a < A; a++) {
+        const float d = actions[(size_t)b * A + a] - mu[(size_t)b * A + a];
+        const float sg = expf(logstd[a]);
+        s += -0.5f * d * d / (sg * sg) - logstd[a] - kHalfLog2Pi;
+    }
+    logp[b] = s;
+}
+
+// ------------------------------------------------------------------ fused actor MLP + Gaussian sample (rollout inference)
+// One workgroup = ROWS observation rows.  Activations live in LDS; every thread owns output neurons and
+// streams its weight rows (L2-resident: 253 KB for the whole actor) with 16-byte loads.
+constexpr int AROWS = 8;
+__device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
+
+template <int K, int OUT, bool ACT>
+__device__ __forceinline__ void dense_layer(const float* __restrict__ W, const float* __restrict__ bias, const float (*in)[260], float (*out)[260]) {
+    for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
+        float acc[AROWS];
+        const float bv = bias[o];
+        for (int r = 0; r < AROWS; r++) acc[r] = bv;
+        const float* w = W + (size_t)o * K;
+        if constexpr (K % 4 == 0) {
+            for (int k = 0; k < K; k += 4) {
+                const float4 wv = *reinterpret_cast<const float4*>(w + k);
+                for (int r = 0; r < AROWS; r++) {
+                    acc[r] = fmaf(wv.x, in[r][k], acc[r]); acc[r] = fmaf(wv.y, in[r][k + 1], acc[r]);
+                    acc[r] = fmaf(wv.z, in[r][k + 2], acc[r]); acc[r] = fmaf(wv.w, in[r][k + 3], acc[r]);
+                }
+            }
+        } else {
+            for (int k = 0; k < K; k++) {
+                const float wv = w[k];
+                for (int r = 0; r < AROWS; r++) acc[r] = fmaf(wv, in[r][k], acc[r]);
+            }
+        }
+        for (int r = 0; r < AROWS; r++) out[r][o] = ACT ? elu(acc[r]) : acc[r];
+    }
+}
+
+__global__ __launch_bounds__(128) void actor_sample_kernel(int N, const float* __restrict__ obs, const float* __restrict__ w0,
+                                                           const float* __restrict__ b0, const float* __restrict__ w1,
+                                                           const float* __restrict__ b1, const float* __restrict__ w2,
+                                                           const float* __restrict__ b2, const float* __restrict__ w3,
+                                                           const float* __restrict__ b3, const float* __restrict__ logstd, uint64_t seed,
+                                                           uint32_t counter, float* __restrict__ mu_out, float* __restrict__ act_out) {
+    __shared__ float bufA[AROWS][260];
+    __shared__ float bufB[AROWS][260];
+    const int r0 = blockIdx.x * AROWS;
+    for (int k = threadIdx.x; k < AROWS * BG_NUM_OBS; k += blockDim.x) {
+        const int r = k / BG_NUM_OBS, c = k % BG_NUM_OBS;
+        bufA[r][c] = (r0 + r < N) ? obs[(size_t)(r0 + r) * BG_NUM_OBS + c] : 0.f;
+    }
+    __syncthreads();
+    dense_layer<BG_NUM_OBS, 256, true>(w0, b0, bufA, bufB);
+    __syncthreads();
+    dense_layer<256, 128, true>(w1, b1, bufB, bufA);
+    __syncthreads();
+    dense_layer<128, 128, true>(w2, b2, bufA, bufB);
+    __syncthreads();
+    dense_layer<128, BG_NUM_DOFS, false>(w3, b3, bufB, bufA);
+    __syncthreads();
+    // sample: one thread per (row, group of 4 actions)
+    if (threadIdx.x < AROWS * 3) {
+        const int r = threadIdx.x / 3, g = threadIdx.x % 3, row = r0 + r;
+        if (row < N) {
+            bg::Rand4 rn = bg::rand4(seed, (uint32_t)row, counter, bg::RS_ACTOR + g);
+            for (int k = 0; k < 4; k++) {
+                const int a = g * 4 + k;
+                const float m = bufA[r][a];
+                if (mu_out) mu_out[(size_t)row * BG_NUM_DOFS + a] = m;
+                act_out[(size_t)row * BG_NUM_DOFS + a] = m + expf(logstd[a]) * rn.n[k];
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------ clip_grad_norm_ + Adam on a flat buffer
+__global__ __launch_bounds__(256) void sqnorm_kernel(int n, const float* __restrict__ g, double* __restrict__ out) {
+    __shared__ double sm[4];
+    double acc[1] = {0.0};
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) acc[0] += (double)g[i] * (double)g[i];
+    block_atomic_add<1>(acc, out, sm);
+}
+__global__ __launch_bounds__(256) void adam_kernel(int n, float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, const float* __restrict__ lr_dev, float bc1, float bc2_sqrt, float beta1,
+                                                   float beta2, float eps, float max_norm, const double* __restrict__ sqnorm) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float total = (float)sqrt(*sqnorm);
+    const float coef = max_norm > 0.f ? fminf(max_norm / (total + 1e-6f), 1.0f) : 1.0f;  // torch.nn.utils.clip_grad_norm_
+    const float gi = g[i] * coef;
+    const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
+    const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
+    m[i] = mi; v[i] = vi;
+    const float step_size = *lr_dev / bc1;
+    p[i] -= step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+}
+__global__ void adapt_lr_kernel(const double* __restrict__ kl_sum, float count, float desired, float lr_min, float lr_max, float* __restrict__ lr) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const float kl = (float)(kl_sum[0] / (double)count);
+    float l = *lr;
+    if (kl > desired * 2.0f) l = fmaxf(lr_min, l / 1.5f);
+    else if (kl < desired / 2.0f) l = fminf(lr_max, l * 1.5f);
+    *lr = l;
+}
+
+// ------------------------------------------------------------------ ABI
+extern "C" int bg_gae(int32_t T, int32_t N, float* rewards, const uint8_t* dones, const uint8_t* time_outs, const float* values,
+                      const float* last_values, float gamma, float lam, float* advantages, float* returns, double* sums, void* stream) {
+    if (T <= 0 || N <= 0 || !rewards || !dones || !time_outs || !values || !last_values || !advantages || !returns || !sums)
+        return bg_set_error(-1, "bg_gae: bad argument");
+    hipLaunchKernelGGL(gae_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, T, N, rewards, dones, time_outs, values, last_values,
+                       gamma, lam, advantages, returns, sums);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_ppo_loss(int32_t B, int32_t A, const float* mu, const float* logstd, const float* actions, const float* old_mu,
+                           const float* old_logstd, const float* old_logp, const float* adv, const double* adv_stats, const float* values,
+                           const float* returns, float e_clip, float bound_coef, float entropy_coef, float* grad_mu, float* grad_values,
+                           double* grad_logstd, double* stats, void* stream) {
+    if (B <= 0 || !mu || !logstd || !actions || !old_mu || !old_logstd || !old_logp || !adv || !adv_stats || !values || !returns || !grad_mu ||
+        !grad_values || !grad_logstd || !stats)
+        return bg_set_error(-1, "bg_ppo_loss: bad argument");
+    if (A != BG_NUM_DOFS) return bg_set_error(-1, "bg_ppo_loss: this build is compiled for 12 actions");
+    hipLaunchKernelGGL(ppo_loss_kernel<BG_NUM_DOFS>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, mu, logstd, actions, old_mu,
+                       old_logstd, old_logp, adv, adv_stats, values, returns, e_clip, bound_coef, entropy_coef, grad_mu, grad_values, grad_logstd,
+                       stats);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_gaussian_logp(int32_t B, int32_t A, const float* mu, const float* logstd, const float* actions, float* logp, void* stream) {
+    if (B <= 0 || !mu || !logstd || !actions || !logp) return bg_set_error(-1, "bg_gaussian_logp: bad argument");
+    if (A != BG_NUM_DOFS) return bg_set_error(-1, "bg_gaussian_logp: this build is compiled for 12 actions");
+    hipLaunchKernelGGL(gaussian_logp_kernel<BG_NUM_DOFS>, dim3((B + 255) / 256), dim3(256), 0, (hipStream_t)stream, B, mu, logstd, actions, logp);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_actor_sample(int32_t N, const float* obs, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                               const float* b2, const float* w3, const float* b3, const float* logstd, uint64_t seed, uint64_t counter, float* mu,
+                               float* actions, void* stream) {
+    if (N <= 0 || !obs || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !logstd || !actions)
+        return bg_set_error(-1, "bg_actor_sample: bad argument");
+    hipLaunchKernelGGL(actor_sample_kernel, dim3((N + AROWS - 1) / AROWS), dim3(128), 0, (hipStream_t)stream, N, obs, w0, b0, w1, b1, w2, b2, w3, b3,
+                       logstd, seed, (uint32_t)counter, mu, actions);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_adam_step(int32_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr_device, int32_t step,
+                            float beta1, float beta2, float eps, float max_grad_norm, double* gnorm_scratch, void* stream) {
+    if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr_device || !gnorm_scratch || step < 1)
+        return bg_set_error(-1, "bg_adam_step: bad argument");
+    HIP_OK(hipMemsetAsync(gnorm_scratch, 0, sizeof(double), (hipStream_t)stream));
+    int blocks = (n + 255) / 256;
+    hipLaunchKernelGGL(sqnorm_kernel, dim3(blocks < 256 ? blocks : 256), dim3(256), 0, (hipStream_t)stream, n, grads, gnorm_scratch);
+    const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
+    hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq, lr_device, bc1, bc2s,
+                       beta1, beta2, eps, max_grad_norm, gnorm_scratch);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_min, float lr_max, float* lr_device, void* stream) {
+    if (!kl_sum || !lr_device || !(count > 0.f)) return bg_set_error(-1, "bg_adapt_lr: bad argument");
+    hipLaunchKernelGGL(adapt_lr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_sum, count, desired_kl, lr_min, lr_max, lr_device);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

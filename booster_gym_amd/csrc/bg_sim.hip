@@ -1,0 +1,400 @@
+// HIP kernels + C ABI of the simulator/task half of libbooster_gym_amd.so (gfx950 only).
+// Lane mapping: 64-thread workgroups = one wavefront = 32 environments, one leg per lane.
+// At 4096 envs that is 128 single-wave workgroups, i.e. one wave per CU on 128 of the 256 CUs:
+// the kernel is latency-bound per wave, so each wave gets a whole CU (LDS, scalar unit, I-cache).
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "bg_env.h"
+
+using namespace bg;
+
+// ------------------------------------------------------------------ error plumbing
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) { g_err = msg; return code; }
+#define HIP_OK(expr)                                                                                 \
+    do {                                                                                             \
+        hipError_t _e = (expr);                                                                      \
+        if (_e != hipSuccess) return fail(-2, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+    } while (0)
+
+int bg_set_error(int code, const char* msg) { return fail(code, msg ? msg : "error"); }
+extern "C" const char* bg_last_error(void) { return g_err.c_str(); }
+extern "C" const char* bg_version(void) { return "booster_gym_amd 0.1 (gfx950)"; }
+
+struct bg_model { bg_model_desc desc; };
+
+struct bg_env {
+    bg_env_cfg cfg;
+    bg_model_desc model;
+    int n;
+    float* f = nullptr;
+    int32_t* i = nullptr;
+    float* stats = nullptr;
+    ModelDev* model_dev = nullptr;
+    int16_t* hf = nullptr;
+    TerrainDev terrain;
+    StepOut bound;
+    int64_t step_count = 0;
+};
+
+// ------------------------------------------------------------------ lane-pair exchange: DPP quad_perm [1,0,3,2]
+struct DppSwap {
+    __device__ __forceinline__ float swap(float v) {
+        int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true);
+        return __int_as_float(r);
+    }
+};
+
+struct LdsSink {
+    float* obs; float* priv; int el;
+    __device__ __forceinline__ void put_obs(int k, float v) { obs[el * BG_NUM_OBS + k] = v; }
+    __device__ __forceinline__ void put_priv(int k, float v) { priv[el * BG_NUM_PRIV + k] = v; }
+};
+
+constexpr int ENVS_PER_BLOCK = 32;
+
+__global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __restrict__ act, uint32_t step, int mode, StepOut out) {
+    __shared__ float s_obs[ENVS_PER_BLOCK * BG_NUM_OBS];
+    __shared__ float s_priv[ENVS_PER_BLOCK * BG_NUM_PRIV];
+    const int lane = threadIdx.x;
+    const int e0 = blockIdx.x * ENVS_PER_BLOCK;
+    int e = e0 + (lane >> 1);
+    const bool valid = e < E.n;
+    if (!valid) e = E.n - 1;
+    DppSwap x;
+    LdsSink sink{s_obs, s_priv, lane >> 1};
+    env_step_lane(E, x, sink, e, lane & 1, valid, act, step, mode, out);
+    __syncthreads();
+    // coalesced copy-out of the block's 32 observation rows (contiguous in the [N][47] / [N][14] outputs)
+    const int rows = min(ENVS_PER_BLOCK, E.n - e0);
+    float* go = out.obs + (size_t)e0 * BG_NUM_OBS;
+    for (int k = lane; k < rows * BG_NUM_OBS; k += 64) go[k] = s_obs[k];
+    float* gp = out.priv + (size_t)e0 * BG_NUM_PRIV;
+    for (int k = lane; k < rows * BG_NUM_PRIV; k += 64) gp[k] = s_priv[k];
+}
+
+// ------------------------------------------------------------------ dynamics only: qacc for N independent states
+__global__ __launch_bounds__(64) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
+                                                              const float* __restrict__ qd, const float* __restrict__ tau,
+                                                              const float* __restrict__ wrench, float* __restrict__ qacc) {
+    const int lane = threadIdx.x, leg = lane & 1;
+    int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
+    const bool valid = e < E.n;
+    if (!valid) e = E.n - 1;
+    const int n = E.n;
+    Phys ph = make_phys(E.cfg);
+    ContactCfg cc = make_contact_cfg(E.cfg);
+    BaseState bs;
+    const float* r = root + (size_t)e * 13;
+    bs.pos = v3(r[0], r[1], r[2]);
+    for (int a = 0; a < 4; a++) bs.quat[a] = r[3 + a];
+    bs.vlin = v3(r[7], r[8], r[9]); bs.vang = v3(r[10], r[11], r[12]);
+    LegState ls;
+    float t6[LEG_LINKS];
+    for (int i = 0; i < LEG_LINKS; i++) {
+        ls.q[i] = q[(size_t)e * 12 + leg * 6 + i]; ls.qd[i] = qd[(size_t)e * 12 + leg * 6 + i]; t6[i] = tau[(size_t)e * 12 + leg * 6 + i];
+    }
+    LegParams lp;
+    load_leg_params(*E.model, cc, leg, e, n, E.f + (size_t)F_MASS_SCALE * n, E.f + (size_t)F_COM_OFF * n, E.f + (size_t)F_FOOT_MAT * n, lp);
+    LinkConst bk = load_base_link(*E.model, e, n, E.f + (size_t)F_MASS_SCALE * n, E.f + (size_t)F_COM_OFF * n);
+    SV wr = sv_zero();
+    if (wrench) { const float* w = wrench + (size_t)e * 6; wr.l = v3(w[0], w[1], w[2]); wr.a = v3(w[3], w[4], w[5]); }
+    DppSwap x;
+    SubstepCtx cx;
+    BaseContribution mine = substep_pre(ph, E.terrain, lp, ls, t6, bs, cx), both;
+    for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
+    for (int k = 0; k < 3; k++) { both.p.a.e[k] = mine.p.a.e[k] + x.swap(mine.p.a.e[k]); both.p.l.e[k] = mine.p.l.e[k] + x.swap(mine.p.l.e[k]); }
+    float qdd[LEG_LINKS];
+    V3 lin_w, ang_w, fw;
+    substep_solve(ph, bk, lp, ls, cx, both, wr, qdd, &lin_w, &ang_w, &fw);
+    if (!valid) return;
+    float* o = qacc + (size_t)e * 18;
+    if (leg == 0) for (int a = 0; a < 3; a++) { o[a] = lin_w.e[a]; o[3 + a] = ang_w.e[a]; }
+    for (int i = 0; i < LEG_LINKS; i++) o[6 + leg * 6 + i] = qdd[i];
+    for (int a = 0; a < 3; a++) E.f[(size_t)(F_CONTACT + 3 * leg + a) * n + e] = fw.e[a];
+}
+
+// ------------------------------------------------------------------ layout conversion helpers
+__global__ void soa_to_aos_kernel(const float* __restrict__ soa, float* __restrict__ aos, int n, int comps) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * comps) return;
+    int e = idx / comps, c = idx % comps;
+    aos[idx] = soa[(size_t)c * n + e];
+}
+__global__ void aos_to_soa_kernel(const float* __restrict__ aos, float* __restrict__ soa, int n, int comps) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n * comps) return;
+    int e = idx / comps, c = idx % comps;
+    soa[(size_t)c * n + e] = aos[idx];
+}
+__global__ void get_state_kernel(EnvDev E, float* root, float* dof, float* contact) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E.n) return;
+    const int n = E.n;
+    if (root) for (int c = 0; c < 13; c++) root[(size_t)e * 13 + c] = E.f[(size_t)(F_ROOT + c) * n + e];
+    if (dof) for (int j = 0; j < 12; j++) {
+        dof[((size_t)e * 12 + j) * 2] = E.f[(size_t)(F_Q + j) * n + e];
+        dof[((size_t)e * 12 + j) * 2 + 1] = E.f[(size_t)(F_QD + j) * n + e];
+    }
+    if (contact) {
+        for (int c = 0; c < 39; c++) contact[(size_t)e * 39 + c] = 0.f;
+        for (int a = 0; a < 3; a++) {
+            contact[(size_t)e * 39 + 6 * 3 + a] = E.f[(size_t)(F_CONTACT + a) * n + e];
+            contact[(size_t)e * 39 + 12 * 3 + a] = E.f[(size_t)(F_CONTACT + 3 + a) * n + e];
+        }
+    }
+}
+__global__ void set_state_kernel(EnvDev E, const float* root, const float* dof) {
+    int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= E.n) return;
+    const int n = E.n;
+    if (root) for (int c = 0; c < 13; c++) E.f[(size_t)(F_ROOT + c) * n + e] = root[(size_t)e * 13 + c];
+    if (dof) for (int j = 0; j < 12; j++) {
+        E.f[(size_t)(F_Q + j) * n + e] = dof[((size_t)e * 12 + j) * 2];
+        E.f[(size_t)(F_QD + j) * n + e] = dof[((size_t)e * 12 + j) * 2 + 1];
+    }
+}
+
+// ------------------------------------------------------------------ ABI: model
+static const int kLegAxis[6] = {2, 1, 3, 2, 2, 1};
+
+extern "C" int bg_model_create(const bg_model_desc* d, bg_model** out) {
+    if (!d || !out) return fail(-1, "bg_model_create: null argument");
+    if (d->num_bodies != BG_NUM_BODIES || d->num_dofs != BG_NUM_DOFS)
+        return fail(-1, "bg_model_create: this build supports the 13-body / 12-DoF collapsed T1 topology only");
+    for (int leg = 0; leg < 2; leg++)
+        for (int i = 0; i < 6; i++) {
+            int b = 1 + leg * 6 + i;
+            int want_parent = i == 0 ? 0 : b - 1;
+            if (d->parent[b] != want_parent || d->joint_axis[b] != kLegAxis[i])
+                return fail(-1, "bg_model_create: body " + std::to_string(b) + " does not match the T1 leg chain (parent/axis)");
+        }
+    if (d->parent[0] != -1 || d->joint_axis[0] != 0) return fail(-1, "bg_model_create: body 0 must be the floating base");
+    for (int b = 0; b < BG_NUM_BODIES; b++)
+        if (!(d->mass[b] > 0.f)) return fail(-1, "bg_model_create: non-positive mass on body " + std::to_string(b));
+    bg_model* m = new bg_model;
+    m->desc = *d;
+    *out = m;
+    return 0;
+}
+extern "C" int bg_model_get(const bg_model* m, bg_model_desc* out) {
+    if (!m || !out) return fail(-1, "bg_model_get: null argument");
+    *out = m->desc;
+    return 0;
+}
+extern "C" void bg_model_destroy(bg_model* m) { delete m; }
+
+// ------------------------------------------------------------------ ABI: env
+static EnvDev env_dev(const bg_env* e) {
+    EnvDev E;
+    E.f = e->f; E.i = e->i; E.stats = e->stats; E.model = e->model_dev; E.terrain = e->terrain; E.cfg = e->cfg; E.n = e->n;
+    return E;
+}
+
+extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_env** out) {
+    if (!cfg || !model || !out) return fail(-1, "bg_env_create: null argument");
+    if (cfg->num_envs <= 0) return fail(-1, "bg_env_create: num_envs must be positive");
+    if (cfg->decimation <= 0 || !(cfg->sim_dt > 0.f)) return fail(-1, "bg_env_create: bad sim dt / decimation");
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(-3, "bg_env_create: no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "bg_env_create: device ordinal out of range");
+    HIP_OK(hipSetDevice(cfg->device));
+    bg_env* e = new bg_env;
+    e->cfg = *cfg; e->model = model->desc; e->n = cfg->num_envs;
+    const size_t n = (size_t)e->n;
+    HIP_OK(hipMalloc(&e->f, sizeof(float) * n * F_COUNT));
+    HIP_OK(hipMalloc(&e->i, sizeof(int32_t) * n * I_COUNT));
+    HIP_OK(hipMalloc(&e->stats, sizeof(float) * STATS_COUNT));
+    HIP_OK(hipMalloc(&e->model_dev, sizeof(ModelDev)));
+    HIP_OK(hipMemset(e->f, 0, sizeof(float) * n * F_COUNT));
+    HIP_OK(hipMemset(e->i, 0, sizeof(int32_t) * n * I_COUNT));
+    HIP_OK(hipMemset(e->stats, 0, sizeof(float) * STATS_COUNT));
+    ModelDev md;
+    memset(&md, 0, sizeof(md));
+    for (int b = 0; b < BG_NUM_BODIES; b++) {
+        md.mass[b] = model->desc.mass[b];
+        for (int a = 0; a < 3; a++) { md.pos[b][a] = model->desc.body_pos[b][a]; md.com[b][a] = model->desc.com[b][a]; }
+        for (int a = 0; a < 6; a++) md.inertia[b][a] = model->desc.inertia[b][a];
+    }
+    for (int j = 0; j < BG_NUM_DOFS; j++) {
+        md.q_lo[j] = model->desc.dof_lower[j]; md.q_hi[j] = model->desc.dof_upper[j];
+        md.qd_max[j] = model->desc.dof_velocity[j]; md.tau_lim[j] = model->desc.dof_effort[j];
+    }
+    for (int k = 0; k < 4; k++) for (int a = 0; a < 3; a++) md.corner[k][a] = model->desc.feet_edge_pos[k][a];
+    HIP_OK(hipMemcpy(e->model_dev, &md, sizeof(md), hipMemcpyHostToDevice));
+    e->terrain.type = 0; e->terrain.rows = e->terrain.cols = e->terrain.border_px = 0; e->terrain.inv_hscale = 1.f; e->terrain.vscale = 0.f; e->terrain.hf = nullptr;
+    memset(&e->bound, 0, sizeof(e->bound));
+    // defaults: unit mass scale / compliance, identity orientation, nominal friction
+    std::vector<float> host(n * F_COUNT, 0.f);
+    for (size_t k = 0; k < n; k++) {
+        host[(size_t)(F_ROOT + 6) * n + k] = 1.f;
+        for (int b = 0; b < 13; b++) host[(size_t)(F_MASS_SCALE + b) * n + k] = 1.f;
+        for (int f = 0; f < 2; f++) { host[(size_t)(F_FOOT_MAT + 3 * f) * n + k] = 1.f; host[(size_t)(F_FOOT_MAT + 3 * f + 1) * n + k] = 1.f; }
+    }
+    HIP_OK(hipMemcpy(e->f, host.data(), sizeof(float) * n * F_COUNT, hipMemcpyHostToDevice));
+    *out = e;
+    return 0;
+}
+
+extern "C" void bg_env_destroy(bg_env* e) {
+    if (!e) return;
+    (void)hipFree(e->f); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf);
+    delete e;
+}
+
+extern "C" int bg_env_set_heightfield(bg_env* e, const int16_t* hf, int32_t rows, int32_t cols, int32_t border_px, float hscale, float vscale) {
+    if (!e || !hf) return fail(-1, "bg_env_set_heightfield: null argument");
+    if (rows < 2 || cols < 2 || !(hscale > 0.f)) return fail(-1, "bg_env_set_heightfield: bad dimensions");
+    if (e->hf) { HIP_OK(hipFree(e->hf)); e->hf = nullptr; }
+    HIP_OK(hipMalloc(&e->hf, sizeof(int16_t) * (size_t)rows * cols));
+    HIP_OK(hipMemcpy(e->hf, hf, sizeof(int16_t) * (size_t)rows * cols, hipMemcpyHostToDevice));
+    e->terrain.type = 1; e->terrain.rows = rows; e->terrain.cols = cols; e->terrain.border_px = border_px;
+    e->terrain.inv_hscale = 1.0f / hscale; e->terrain.vscale = vscale; e->terrain.hf = e->hf;
+    return 0;
+}
+
+static int upload_field(bg_env* e, int field, int comps, const float* src_env_major) {
+    if (!src_env_major) return 0;
+    const size_t n = (size_t)e->n;
+    std::vector<float> t(n * comps);
+    for (size_t k = 0; k < n; k++) for (int c = 0; c < comps; c++) t[(size_t)c * n + k] = src_env_major[k * comps + c];
+    hipError_t r = hipMemcpy(e->f + (size_t)field * n, t.data(), sizeof(float) * n * comps, hipMemcpyHostToDevice);
+    if (r != hipSuccess) return fail(-2, std::string("upload_field: ") + hipGetErrorString(r));
+    return 0;
+}
+
+extern "C" int bg_env_set_params(bg_env* e, const float* kp, const float* kd, const float* friction, const float* mass_scale,
+                                 const float* com_offset, const float* foot_material, const float* base_mass_scaled, const float* env_origins) {
+    if (!e) return fail(-1, "bg_env_set_params: null env");
+    int r = 0;
+    if ((r = upload_field(e, F_KP, 12, kp))) return r;
+    if ((r = upload_field(e, F_KD, 12, kd))) return r;
+    if ((r = upload_field(e, F_FRIC, 12, friction))) return r;
+    if ((r = upload_field(e, F_MASS_SCALE, 13, mass_scale))) return r;
+    if ((r = upload_field(e, F_COM_OFF, 39, com_offset))) return r;
+    if ((r = upload_field(e, F_FOOT_MAT, 6, foot_material))) return r;
+    if ((r = upload_field(e, F_BMS, 4, base_mass_scaled))) return r;
+    if ((r = upload_field(e, F_ORIGIN, 3, env_origins))) return r;
+    return 0;
+}
+
+extern "C" int bg_env_bind_outputs(bg_env* e, float* obs, float* priv, float* rew, uint8_t* done, uint8_t* tout, float* terms) {
+    if (!e || !obs || !priv || !rew || !done || !tout) return fail(-1, "bg_env_bind_outputs: null argument");
+    e->bound.obs = obs; e->bound.priv = priv; e->bound.rew = rew; e->bound.done = done; e->bound.tout = tout; e->bound.terms = terms;
+    return 0;
+}
+
+static int launch_step(bg_env* e, const float* actions, int mode, const StepOut& out, void* stream) {
+    if (!out.obs || !out.priv || !out.rew || !out.done || !out.tout) return fail(-1, "bg_env_step: outputs are not bound");
+    dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
+    hipLaunchKernelGGL(env_step_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), actions, (uint32_t)e->step_count, mode, out);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_env_reset(bg_env* e, void* stream) {
+    if (!e) return fail(-1, "bg_env_reset: null env");
+    return launch_step(e, nullptr, 1, e->bound, stream);
+}
+extern "C" int bg_env_step(bg_env* e, const float* actions, void* stream) {
+    if (!e || !actions) return fail(-1, "bg_env_step: null argument");
+    int r = launch_step(e, actions, 0, e->bound, stream);
+    if (r == 0) e->step_count++;
+    return r;
+}
+extern "C" int bg_env_step_to(bg_env* e, const float* actions, float* obs, float* priv, float* rew, uint8_t* done, uint8_t* tout, void* stream) {
+    if (!e || !actions) return fail(-1, "bg_env_step_to: null argument");
+    StepOut o = e->bound;
+    o.obs = obs; o.priv = priv; o.rew = rew; o.done = done; o.tout = tout;
+    int r = launch_step(e, actions, 0, o, stream);
+    if (r == 0) e->step_count++;
+    return r;
+}
+
+extern "C" int bg_env_get_state(bg_env* e, float* root, float* dof, float* contact, void* stream) {
+    if (!e) return fail(-1, "bg_env_get_state: null env");
+    hipLaunchKernelGGL(get_state_kernel, dim3((e->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_dev(e), root, dof, contact);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+extern "C" int bg_env_set_state(bg_env* e, const float* root, const float* dof, void* stream) {
+    if (!e) return fail(-1, "bg_env_set_state: null env");
+    hipLaunchKernelGGL(set_state_kernel, dim3((e->n + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_dev(e), root, dof);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+struct FieldInfo { const char* name; int off; int comps; int is_int; };
+static const FieldInfo kFields[] = {
+    {"root_states", F_ROOT, 13, 0}, {"dof_pos", F_Q, 12, 0}, {"dof_vel", F_QD, 12, 0}, {"last_dof_targets", F_LAST_TGT, 12, 0},
+    {"actions", F_ACT, 12, 0}, {"last_actions", F_LAST_ACT, 12, 0}, {"last_dof_vel", F_LAST_QD, 12, 0}, {"last_root_vel", F_LAST_ROOTVEL, 6, 0},
+    {"commands", F_CMD, 3, 0}, {"gait_frequency", F_GAIT_F, 1, 0}, {"gait_process", F_GAIT_P, 1, 0}, {"filtered_lin_vel", F_FILT_LIN, 3, 0},
+    {"filtered_ang_vel", F_FILT_ANG, 3, 0}, {"last_feet_pos", F_LAST_FEET, 6, 0}, {"pushing", F_PUSH, 6, 0}, {"feet_contact_forces", F_CONTACT, 6, 0},
+    {"dof_stiffness", F_KP, 12, 0}, {"dof_damping", F_KD, 12, 0}, {"dof_friction", F_FRIC, 12, 0}, {"mass_scale", F_MASS_SCALE, 13, 0},
+    {"com_offset", F_COM_OFF, 39, 0}, {"foot_material", F_FOOT_MAT, 6, 0}, {"base_mass_scaled", F_BMS, 4, 0}, {"env_origins", F_ORIGIN, 3, 0},
+    {"feet_pos", F_FEET_POS, 6, 0}, {"feet_roll", F_FEET_ROLL, 2, 0}, {"feet_yaw", F_FEET_YAW, 2, 0}, {"feet_contact", F_FEET_CONTACT, 2, 0},
+    {"torques", F_TORQUES, 12, 0}, {"base_lin_vel", F_BASE_LIN, 3, 0}, {"base_ang_vel", F_BASE_ANG, 3, 0}, {"projected_gravity", F_PROJ_G, 3, 0},
+    {"episode_sums", F_EP_SUMS, 27, 0},
+    {"episode_length_buf", I_EP_LEN, 1, 1}, {"cmd_resample_time", I_CMD_TIME, 1, 1}, {"delay_steps", I_DELAY, 1, 1}, {"episode_steps", I_EP_STEPS, 1, 1},
+};
+static const FieldInfo* find_field(const char* name) {
+    for (const auto& f : kFields) if (strcmp(f.name, name) == 0) return &f;
+    return nullptr;
+}
+extern "C" int bg_env_field_info(bg_env* e, const char* name, int32_t* comps, int32_t* is_int) {
+    (void)e;
+    const FieldInfo* f = name ? find_field(name) : nullptr;
+    if (!f) return fail(-1, std::string("unknown field: ") + (name ? name : "(null)"));
+    if (comps) *comps = f->comps;
+    if (is_int) *is_int = f->is_int;
+    return 0;
+}
+extern "C" int bg_env_get_field(bg_env* e, const char* name, void* dst, void* stream) {
+    if (!e || !dst) return fail(-1, "bg_env_get_field: null argument");
+    if (name && strcmp(name, "episode_stats") == 0) {  // global accumulator, STATS_COUNT floats
+        HIP_OK(hipMemcpyAsync(dst, e->stats, sizeof(float) * STATS_COUNT, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return 0;
+    }
+    const FieldInfo* f = name ? find_field(name) : nullptr;
+    if (!f) return fail(-1, std::string("unknown field: ") + (name ? name : "(null)"));
+    const float* src = f->is_int ? (const float*)(e->i + (size_t)f->off * e->n) : e->f + (size_t)f->off * e->n;
+    int total = e->n * f->comps;
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, e->n, f->comps);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+extern "C" int bg_env_set_field(bg_env* e, const char* name, const void* src, void* stream) {
+    if (!e || !src) return fail(-1, "bg_env_set_field: null argument");
+    if (name && strcmp(name, "episode_stats") == 0) {
+        HIP_OK(hipMemcpyAsync(e->stats, src, sizeof(float) * STATS_COUNT, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        return 0;
+    }
+    const FieldInfo* f = name ? find_field(name) : nullptr;
+    if (!f) return fail(-1, std::string("unknown field: ") + (name ? name : "(null)"));
+    float* dst = f->is_int ? (float*)(e->i + (size_t)f->off * e->n) : e->f + (size_t)f->off * e->n;
+    int total = e->n * f->comps;
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, e->n, f->comps);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+extern "C" int64_t bg_env_step_count(const bg_env* e) { return e ? e->step_count : -1; }
+extern "C" int bg_env_set_step_count(bg_env* e, int64_t c) {
+    if (!e) return fail(-1, "bg_env_set_step_count: null env");
+    e->step_count = c;
+    return 0;
+}
+
+extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float* q, const float* qd, const float* tau, const float* wrench,
+                                       float* qacc, void* stream) {
+    if (!e || !root || !q || !qd || !tau || !qacc) return fail(-1, "bg_env_forward_dynamics: null argument");
+    dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
+    hipLaunchKernelGGL(forward_dynamics_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,180 @@
+/*
+ * booster_gym_amd.h -- C ABI of libbooster_gym_amd.so (MI355X / gfx950, HIP).
+ *
+ * Drop-in boundary for the hot path of Nyro-Robotics/booster_gym: the Isaac Gym
+ * tensor API the reference's task code calls plus the
+ * GAE / PPO-loss loop of utils/runner.py.  Every entry point is extern "C",
+ * takes plain pointers and sizes (device pointers are raw `void*` from
+ * `torch.Tensor.data_ptr()`), returns 0 on success and a negative code on error
+ * (`bg_last_error()` returns a thread-local message).  No function synchronises
+ * the device or allocates after create; all work is enqueued on the caller's
+ * `stream` (a hipStream_t passed as void*, NULL = default stream).
+ *
+ * Citations `file:line` refer to the reference tree.
+ */
+#ifndef BOOSTER_GYM_AMD_H
+#define BOOSTER_GYM_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BG_NUM_BODIES 13
+#define BG_NUM_DOFS 12
+#define BG_NUM_OBS 47
+#define BG_NUM_PRIV 14
+#define BG_NUM_REWARD_TERMS 26
+
+typedef struct bg_model bg_model;
+typedef struct bg_env bg_env;
+
+/* Flat articulated-body model (what Isaac Gym's load_asset + asset queries return:
+ * envs/t1.py:54-67, 85-108).  Bodies depth-first: trunk, left leg 1..6, right leg 7..12. */
+typedef struct {
+    int32_t num_bodies, num_dofs;
+    int32_t parent[BG_NUM_BODIES];
+    int32_t joint_axis[BG_NUM_BODIES]; /* 0 floating base, 1/2/3 revolute about x/y/z */
+    float body_pos[BG_NUM_BODIES][3];
+    float mass[BG_NUM_BODIES];
+    float com[BG_NUM_BODIES][3];
+    float inertia[BG_NUM_BODIES][6]; /* about com: xx yy zz xy xz yz */
+    float dof_lower[BG_NUM_DOFS], dof_upper[BG_NUM_DOFS], dof_velocity[BG_NUM_DOFS], dof_effort[BG_NUM_DOFS];
+    float feet_edge_pos[4][3]; /* cfg asset.feet_edge_pos, envs/T1.yaml:79-82 */
+} bg_model_desc;
+
+/* randomisation / noise entry (utils/utils.py:5-30): mode 0 none, 1 gaussian additive,
+ * 2 gaussian scaling, 3 uniform additive, 4 uniform scaling; (a,b) = the yaml `range`. */
+typedef struct { int32_t mode; float a, b; } bg_rand;
+
+/* order of reward terms = order of envs/T1.yaml:252-278; scale 0 drops the term (t1.py:280-285) */
+enum {
+    BG_REW_SURVIVAL = 0, BG_REW_TRACKING_LIN_VEL_X, BG_REW_TRACKING_LIN_VEL_Y, BG_REW_TRACKING_ANG_VEL, BG_REW_BASE_HEIGHT,
+    BG_REW_ORIENTATION, BG_REW_TORQUES, BG_REW_TORQUE_TIREDNESS, BG_REW_POWER, BG_REW_LIN_VEL_Z, BG_REW_ANG_VEL_XY, BG_REW_DOF_VEL,
+    BG_REW_DOF_ACC, BG_REW_ROOT_ACC, BG_REW_ACTION_RATE, BG_REW_DOF_POS_LIMITS, BG_REW_DOF_VEL_LIMITS, BG_REW_TORQUE_LIMITS,
+    BG_REW_COLLISION, BG_REW_FEET_SLIP, BG_REW_FEET_VEL_Z, BG_REW_FEET_YAW_DIFF, BG_REW_FEET_YAW_MEAN, BG_REW_FEET_ROLL,
+    BG_REW_FEET_DISTANCE, BG_REW_FEET_SWING
+};
+
+/* Everything numeric the env needs from envs/T1.yaml (sections sim, control, normalization,
+ * noise, randomization, commands, rewards, init_state, terrain) plus this build's contact model. */
+typedef struct {
+    int32_t num_envs;
+    int32_t device;     /* HIP device ordinal; there is no CPU path in this library */
+    uint64_t seed;
+    /* sim (T1.yaml:39-44) + contact model of this build */
+    float sim_dt;
+    int32_t decimation; /* control.decimation, T1.yaml:95 */
+    float gravity[3];
+    float contact_k, contact_d, contact_ramp, friction_visc, limit_k, limit_d;
+    float terrain_mu, terrain_restitution; /* T1.yaml:99-101 */
+    int32_t clamp_qd;
+    /* control / normalization (T1.yaml:91-95, 135-145) */
+    float action_scale, clip_actions;
+    float norm_gravity, norm_lin_vel, norm_ang_vel, norm_dof_pos, norm_dof_vel, filter_weight, norm_push_force, norm_push_torque;
+    float default_dof_pos[BG_NUM_DOFS]; /* t1.py:264-272 */
+    float base_init_state[13];          /* t1.py:109-112 */
+    /* noise (T1.yaml:147-171) */
+    bg_rand noise_gravity, noise_lin_vel, noise_ang_vel, noise_dof_pos, noise_dof_vel, noise_height;
+    /* run-time randomisation (T1.yaml:173-206) */
+    bg_rand init_dof_pos, init_base_pos_xy, init_base_lin_vel_xy, kick_lin_vel, kick_ang_vel, push_force, push_torque;
+    int32_t kick_interval, push_interval, push_duration; /* in env steps: ceil(seconds / dt), t1.py:501,508,517 */
+    int32_t shared_reset_noise; /* 1 = reference quirk Q1 (t1.py:320): one noise vector per reset call */
+    /* commands (T1.yaml:115-133) */
+    float cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2], cmd_gait_frequency[2];
+    float still_proportion;
+    int32_t resample_steps[2]; /* int(seconds / dt), t1.py:384-385 */
+    /* rewards (T1.yaml:251-291) */
+    float reward_scale[BG_NUM_REWARD_TERMS]; /* yaml value * dt; 0 = dropped */
+    int32_t only_positive_rewards;
+    float tracking_sigma, base_height_target, soft_dof_pos_limit, soft_dof_vel_limit, soft_torque_limit, swing_period, feet_distance_ref;
+    int32_t max_episode_length; /* ceil(episode_length_s / dt), t1.py:556 */
+    float terminate_height, terminate_vel;
+    /* terrain extents for the teleport wrap (t1.py:343-360); plane => teleport off */
+    int32_t terrain_type; /* 0 plane, 1 heightfield ("trimesh" in the yaml) */
+    float terrain_env_width, terrain_env_length, terrain_border;
+} bg_env_cfg;
+
+/* ---- model (replaces gym.load_asset and the asset queries, t1.py:54-108) */
+int bg_model_create(const bg_model_desc* desc, bg_model** out);
+int bg_model_get(const bg_model* m, bg_model_desc* out);
+void bg_model_destroy(bg_model* m);
+
+/* ---- env = simulator + T1 task logic (replaces create_sim/create_env/create_actor/prepare_sim,
+ *      base_task.py:20-79, t1.py:33-137, and owns the per-env state of t1.py:187-272) */
+int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_env** out);
+void bg_env_destroy(bg_env* env);
+/* height field for terrain.type "trimesh" (utils/terrain.py:30-99): host int16 [rows][cols], copied to the device */
+int bg_env_set_heightfield(bg_env* env, const int16_t* hf_host, int32_t rows, int32_t cols, int32_t border_px, float hscale, float vscale);
+/* per-env build-time randomisation (t1.py:69-83, 122-167), host float arrays, env-major:
+ * kp/kd/friction [N][12], mass_scale [N][13], com_offset [N][13][3], foot_material [N][2][3] = (friction, compliance,
+ * restitution), base_mass_scaled [N][4] (raw draws shown to the critic, t1.py:141-152), env_origins [N][3] (t1.py:169-185) */
+int bg_env_set_params(bg_env* env, const float* kp, const float* kd, const float* friction, const float* mass_scale, const float* com_offset,
+                      const float* foot_material, const float* base_mass_scaled, const float* env_origins);
+/* outputs of reset/step, device pointers owned by the caller (torch tensors): obs [N][47], privileged [N][14],
+ * rew [N], done uint8 [N], time_outs uint8 [N], rew_terms [26][N] (rows of dropped terms stay 0) */
+int bg_env_bind_outputs(bg_env* env, float* obs, float* privileged_obs, float* rew, uint8_t* done, uint8_t* time_outs, float* rew_terms);
+/* T1.reset(): t1.py:294-299 */
+int bg_env_reset(bg_env* env, void* stream);
+/* T1.step(actions): t1.py:437-497.  actions: device float [N][12] */
+int bg_env_step(bg_env* env, const float* actions, void* stream);
+/* Same, writing obs/privileged/rew/done/time_outs of this step to the given device pointers instead of
+ * the bound ones (lets the rollout loop write straight into rows of the experience buffer, runner.py:107-118) */
+int bg_env_step_to(bg_env* env, const float* actions, float* obs, float* privileged_obs, float* rew, uint8_t* done, uint8_t* time_outs,
+                   void* stream);
+/* Isaac-Gym-layout views of the simulator state for inspection / tests (device pointers, may be NULL):
+ * root [N][13] (pos, quat xyzw, lin vel, ang vel: t1.py:215), dof [N][12][2] (pos, vel: t1.py:216-218),
+ * contact [N][13][3] net contact force per body, world frame (t1.py:219) */
+int bg_env_get_state(bg_env* env, float* root, float* dof, float* contact, void* stream);
+int bg_env_set_state(bg_env* env, const float* root, const float* dof, void* stream);
+/* named per-env arrays (task state of t1.py:187-272), float or int32 depending on the field; see bg_env_field_info */
+int bg_env_get_field(bg_env* env, const char* name, void* dst_device, void* stream);
+int bg_env_set_field(bg_env* env, const char* name, const void* src_device, void* stream);
+int bg_env_field_info(bg_env* env, const char* name, int32_t* components, int32_t* is_int);
+int64_t bg_env_step_count(const bg_env* env);
+int bg_env_set_step_count(bg_env* env, int64_t count);
+
+/* ---- dynamics only (what north_star calls "per-step joint accelerations"): forward dynamics of N
+ * independent states.  Device float arrays, env-major: root [N][13], dof_pos/dof_vel/tau [N][12],
+ * base_wrench [N][6] (force, torque in base coords) or NULL; qacc out [N][18] = d/dt(lin vel world,
+ * ang vel world, dof vel).  Uses the env's model, per-env parameters and terrain. */
+int bg_env_forward_dynamics(bg_env* env, const float* root, const float* dof_pos, const float* dof_vel, const float* tau,
+                            const float* base_wrench, float* qacc, void* stream);
+
+/* ---- PPO math (utils/utils.py:33-52, utils/runner.py:123-180), all pointers device float unless noted */
+/* GAE + returns + advantage moments.  rewards [T][N] is modified in place where time_outs is set (runner.py:135).
+ * sums out [3] = (sum adv, sum adv^2, count) as float64, accumulated with atomics; caller zeroes it. */
+int bg_gae(int32_t T, int32_t N, float* rewards, const uint8_t* dones, const uint8_t* time_outs, const float* values,
+           const float* last_values, float gamma, float lam, float* advantages, float* returns, double* sums, void* stream);
+/* Fused PPO loss forward+backward over B samples with A actions (runner.py:144-174):
+ * in:  mu [B][A], logstd [A], actions [B][A], old_mu [B][A], old_logstd [A], old_logp [B], adv [B] (un-normalised),
+ *      adv_stats [3] (sum, sumsq, count), values [B], returns [B]
+ * out: grad_mu [B][A], grad_values [B], grad_logstd [A] float64 (atomic, caller zeroes), stats [5] float64 (atomic,
+ *      caller zeroes) = sums over samples of (value error^2, surrogate, bound penalty, entropy, kl).
+ * adv_stats [3] float64 = bg_gae's sums (all-reduced across ranks in data-parallel runs). */
+int bg_ppo_loss(int32_t B, int32_t A, const float* mu, const float* logstd, const float* actions, const float* old_mu,
+                const float* old_logstd, const float* old_logp, const float* adv, const double* adv_stats, const float* values,
+                const float* returns, float e_clip, float bound_coef, float entropy_coef, float* grad_mu, float* grad_values,
+                double* grad_logstd, double* stats, void* stream);
+/* log-prob of actions under N(mu, exp(logstd)) summed over A (runner.py:123-125) */
+int bg_gaussian_logp(int32_t B, int32_t A, const float* mu, const float* logstd, const float* actions, float* logp, void* stream);
+/* Fused actor inference for the rollout (utils/model.py:29-32 + dist.sample(), runner.py:109-111):
+ * 47->256->128->128->12 ELU MLP + Gaussian sample.  weights: w0[256][47] b0[256] w1[128][256] b1 w2[128][128] b2 w3[12][128] b3,
+ * logstd[12]; obs [N][47]; out: mu [N][12] (may be NULL), actions [N][12].  Noise from Philox(seed, counter). */
+int bg_actor_sample(int32_t N, const float* obs, const float* w0, const float* b0, const float* w1, const float* b1, const float* w2,
+                    const float* b2, const float* w3, const float* b3, const float* logstd, uint64_t seed, uint64_t counter,
+                    float* mu, float* actions, void* stream);
+/* Fused global-norm clip + Adam over one flat parameter buffer (runner.py:162-165); lr is read from device memory
+ * so the KL-adaptive schedule (runner.py:174-180) needs no host sync.  gnorm_scratch [1] device float64. */
+int bg_adam_step(int32_t n, float* params, const float* grads, float* exp_avg, float* exp_avg_sq, const float* lr_device, int32_t step,
+                 float beta1, float beta2, float eps, float max_grad_norm, double* gnorm_scratch, void* stream);
+/* KL-adaptive learning rate on the device (runner.py:174-180): kl_sum [1] float64 (= stats[4] of bg_ppo_loss), count = samples -> lr_device [1] updated in place */
+int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_min, float lr_max, float* lr_device, void* stream);
+
+const char* bg_last_error(void);
+const char* bg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

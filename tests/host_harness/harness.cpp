@@ -1,0 +1,59 @@
+// TEST TOOL: compiles the product's per-lane dynamics header (booster_gym_amd/csrc/bg_dyn.h) with g++
+// so that its arithmetic can be compared with the double-precision oracle on a machine
+// without a GPU.  Not part of the shipped library; never loaded by the product path.
+#include "../../booster_gym_amd/csrc/bg_dyn.h"
+#include <string.h>
+using namespace bg;
+
+extern "C" {
+
+struct hh_cfg { float dt, g[3], contact_k, contact_d, contact_ramp, friction_visc, limit_k, limit_d, terrain_mu, terrain_restitution; int clamp_qd; };
+
+static void setup(const hh_cfg* c, Phys& ph, ContactCfg& cc) {
+    ph.dt = c->dt; ph.g = v3(c->g[0], c->g[1], c->g[2]); ph.contact_ramp = c->contact_ramp; ph.friction_visc = c->friction_visc;
+    ph.limit_k = c->limit_k; ph.limit_d = c->limit_d; ph.clamp_qd = c->clamp_qd;
+    cc.k = c->contact_k; cc.d = c->contact_d; cc.terrain_mu = c->terrain_mu; cc.terrain_restitution = c->terrain_restitution;
+}
+
+// one env; arrays are in the SoA layout with n = 1.  root: pos3 quat4 lin3 ang3.  step != 0 integrates in place.
+int hh_forward(const ModelDev* m, const hh_cfg* c, const TerrainDev* tr, const float* mass_scale, const float* com_off, const float* foot_mat,
+               float* root, float* q, float* qd, const float* tau, const float* wrench /*force3 torque3*/, float* qacc, float* cf /*2x3*/,
+               int step) {
+    Phys ph; ContactCfg cc; setup(c, ph, cc);
+    BaseState bs;
+    bs.pos = v3(root[0], root[1], root[2]);
+    for (int i = 0; i < 4; i++) bs.quat[i] = root[3 + i];
+    bs.vlin = v3(root[7], root[8], root[9]); bs.vang = v3(root[10], root[11], root[12]);
+    LinkConst bk = load_base_link(*m, 0, 1, mass_scale, com_off);
+    LegParams lp[2]; LegState ls[2]; SubstepCtx cx[2]; BaseContribution bc[2];
+    for (int l = 0; l < 2; l++) {
+        load_leg_params(*m, cc, l, 0, 1, mass_scale, com_off, foot_mat, lp[l]);
+        for (int i = 0; i < 6; i++) { ls[l].q[i] = q[6 * l + i]; ls[l].qd[i] = qd[6 * l + i]; }
+        bc[l] = substep_pre(ph, *tr, lp[l], ls[l], tau + 6 * l, bs, cx[l]);
+    }
+    BaseContribution both;
+    both.I.A = bc[0].I.A + bc[1].I.A; both.I.H = bc[0].I.H + bc[1].I.H; both.I.M = bc[0].I.M + bc[1].I.M; both.p = bc[0].p + bc[1].p;
+    SV wr; wr.l = v3(wrench[0], wrench[1], wrench[2]); wr.a = v3(wrench[3], wrench[4], wrench[5]);
+    V3 lin_w, ang_w;
+    float qdd[2][6];
+    for (int l = 0; l < 2; l++) {
+        V3 fw;
+        substep_solve(ph, bk, lp[l], ls[l], cx[l], both, wr, qdd[l], &lin_w, &ang_w, &fw);
+        for (int a = 0; a < 3; a++) cf[3 * l + a] = fw.e[a];
+        for (int i = 0; i < 6; i++) qacc[6 + 6 * l + i] = qdd[l][i];
+    }
+    for (int a = 0; a < 3; a++) { qacc[a] = lin_w.e[a]; qacc[3 + a] = ang_w.e[a]; }
+    if (step) {
+        BaseState b0 = bs;
+        for (int l = 0; l < 2; l++) {
+            BaseState b = b0;
+            substep_integrate(ph, lp[l], ls[l], b, qdd[l], lin_w, ang_w);
+            bs = b;
+            for (int i = 0; i < 6; i++) { q[6 * l + i] = ls[l].q[i]; qd[6 * l + i] = ls[l].qd[i]; }
+        }
+        for (int a = 0; a < 3; a++) { root[a] = bs.pos.e[a]; root[7 + a] = bs.vlin.e[a]; root[10 + a] = bs.vang.e[a]; }
+        for (int i = 0; i < 4; i++) root[3 + i] = bs.quat[i];
+    }
+    return 0;
+}
+}

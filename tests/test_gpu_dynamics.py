@@ -1,0 +1,67 @@
+"""K1 parity on the GPU: HIP forward dynamics (through the C ABI) vs the double-precision oracle.
+
+Stated tolerance: relative 1e-4 on the accelerations for contact-free states with joints
+inside or outside their limits; 5e-4 when stiff sole contacts are active (fp32 conditioning of k = 4e4 N/m).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _states(rng, m, n, contact):
+    root = np.zeros((n, 13))
+    root[:, 2] = rng.uniform(0.55, 0.72, n) if contact else 5.0
+    root[:, :2] = rng.uniform(-1, 1, (n, 2))
+    ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = rng.uniform(0, 0.3 if contact else 1.0, n)
+    root[:, 3:6] = ax * np.sin(ang / 2)[:, None]; root[:, 6] = np.cos(ang / 2)
+    root[:, 7:13] = rng.normal(size=(n, 6)) * (0.3 if contact else 1.0)
+    if contact:
+        q = np.tile(np.array([-0.2, 0, 0, 0.4, -0.25, 0] * 2), (n, 1)) + rng.normal(size=(n, 12)) * 0.1
+    else:
+        q = rng.uniform(m.dof_lower - 0.05, m.dof_upper + 0.05, (n, 12))
+    qd = rng.normal(size=(n, 12))
+    tau = rng.uniform(-m.dof_effort, m.dof_effort, (n, 12))
+    w = rng.normal(size=(n, 6)) * 10
+    return root, q, qd, tau, w
+
+
+@pytest.mark.parametrize("terrain,contact,tol", [("plane", False, 1e-4), ("plane", True, 5e-4), ("trimesh", True, 5e-4)])
+def test_forward_dynamics_matches_oracle(flat_model, terrain, contact, tol):
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+    from oracle.dyn_ref import DynRef
+
+    n = 256
+    cfg = load_cfg("T1", {"env.num_envs": n, "terrain.type": terrain})
+    env = T1(cfg)
+    tdict = None
+    if terrain != "plane":
+        t = env.terrain
+        tdict = dict(height_field_raw=t.height_field_raw, hscale=t.horizontal_scale, vscale=t.vertical_scale, border_px=t.border_pixels)
+    ref = DynRef(flat_model, feet_edge_pos=cfg["asset"]["feet_edge_pos"], terrain=tdict)
+    rng = np.random.default_rng(3)
+    root, q, qd, tau, w = _states(rng, flat_model, n, contact)
+    if terrain != "plane":
+        root[:, 0] += 20.0; root[:, 1] += 5.0  # inside the rough strips
+        root[:, 2] += np.array([ref.terrain_height(x, y) for x, y in root[:, :2]])
+    dev = env.device
+    f = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    qacc = env.forward_dynamics(f(root), f(q), f(qd), f(tau), f(w)).cpu().numpy().astype(np.float64)
+    cf = env.get_field("feet_contact_forces").cpu().numpy().reshape(n, 2, 3)
+    worst, ncontact = 0.0, 0
+    for e in range(n):
+        r32 = root[e].astype(np.float32).astype(np.float64)  # oracle sees the same rounded inputs
+        qa, cfr = ref.forward(r32, q[e].astype(np.float32), qd[e].astype(np.float32), tau[e].astype(np.float32), base_wrench=w[e].astype(np.float32),
+                              mass_scale=env._mass_scale[e].astype(np.float32), com_off=env._com_off[e].astype(np.float32),
+                              foot_mat=env._foot_mat[e].astype(np.float32).reshape(6))
+        worst = max(worst, np.abs(qacc[e] - qa).max() / max(1.0, np.abs(qa).max()))
+        if np.abs(cfr).max() > 0:
+            ncontact += 1
+            assert np.abs(cf[e] - cfr[[6, 12]]).max() <= 2e-3 * max(1.0, np.abs(cfr).max())
+    assert np.isfinite(qacc).all()
+    assert worst < tol, f"worst relative qacc error {worst}"
+    if contact:
+        assert ncontact > n // 4
