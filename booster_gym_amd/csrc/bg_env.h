@@ -51,8 +51,8 @@ enum {
     F_COUNT = 281
 };
 enum { I_EP_LEN = 0, I_CMD_TIME = 1, I_DELAY = 2, I_EP_STEPS = 3, I_COUNT = 4 };
-// global statistics accumulator: [0] finished episodes, [1] sum of their lengths, [2] sum reward, [3..28] sum of terms
-constexpr int STATS_COUNT = 3 + BG_NUM_REWARD_TERMS;
+// global statistics accumulator: [0] finished episodes, [1] sum of their lengths, [2] sum reward, [3..28] sum of terms, [29] non-finite resets
+constexpr int STATS_COUNT = 4 + BG_NUM_REWARD_TERMS;  // last entry: resets caused by a non-finite state
 
 struct EnvDev {
     float* f;
@@ -203,6 +203,18 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
         for (int i = 0; i < LEG_LINKS; i++) tmean[i] *= 1.0f / (float)C.decimation;
     }
 
+    // ------------------------------------------------------------ non-finite guard (PhysX clamps internally; here a blown-up
+    // state is treated as a termination so that one diverged env cannot poison its lane pair forever)
+    float chk = dot(bs.pos, bs.pos) + dot(bs.vlin, bs.vlin) + dot(bs.vang, bs.vang);
+    for (int i = 0; i < LEG_LINKS; i++) chk += ls.q[i] * ls.q[i] + ls.qd[i] * ls.qd[i];
+    float bad = (chk < 1.0e12f) ? 0.f : 1.f;  // false for NaN and Inf
+    bad = fmaxf(bad, x.swap(bad));
+    if (bad != 0.f) {
+        bs.pos = v3(0.f, 0.f, 1.f); bs.quat[0] = bs.quat[1] = bs.quat[2] = 0.f; bs.quat[3] = 1.f;
+        bs.vlin = v3(0.f, 0.f, 0.f); bs.vang = v3(0.f, 0.f, 0.f);
+        for (int i = 0; i < LEG_LINKS; i++) { ls.q[i] = 0.f; ls.qd[i] = 0.f; tmean[i] = 0.f; }
+        foot_force = v3(0.f, 0.f, 0.f);
+    }
     // ------------------------------------------------------------ post-physics derived state (t1.py:460-474)
     M3 R0 = quat_to_mat(bs.quat);
     V3 base_lin = mulT(R0, bs.vlin), base_ang = mulT(R0, bs.vang);
@@ -289,6 +301,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
         bool to = ep_len > C.max_episode_length;
         bool rs = (v2 > C.terminate_vel) || (bs.pos.e[2] - h_base < C.terminate_height) || to;
         to = to || (ep_len == cmd_time);
+        if (bad != 0.f) rs = true;
         reset_flag = rs ? 1 : 0; tout_flag = to ? 1 : 0;
         // ------------------------------------------------------------ rewards (t1.py:560-572, 606-730)
         float base_yaw = quat_yaw(bs.quat);
@@ -336,6 +349,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
             rew_total += term[k];
         }
         if (C.only_positive_rewards) rew_total = fmaxf(rew_total, 0.f);
+        if (bad != 0.f) { rew_total = 0.f; for (int k = 0; k < BG_NUM_REWARD_TERMS; k++) term[k] = 0.f; }
     } else {
         reset_flag = 1;
     }
@@ -457,6 +471,13 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
             // episode statistics (recorder.py:36-53): running sums, flushed to the global accumulator when the episode ends
             int eps = II[(size_t)I_EP_STEPS * n + e] + 1;
             float es = FLD(F_EP_SUMS, 0) + rew_total;
+            if (bad != 0.f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+                atomicAdd(&E.stats[3 + BG_NUM_REWARD_TERMS], 1.0f);
+#else
+                E.stats[3 + BG_NUM_REWARD_TERMS] += 1.0f;
+#endif
+            }
             if (reset_flag) {
 #if defined(__HIP_DEVICE_COMPILE__)
                 atomicAdd(&E.stats[0], 1.0f); atomicAdd(&E.stats[1], (float)eps); atomicAdd(&E.stats[2], es);

@@ -194,12 +194,12 @@ class T1(BaseTask):
         for a in range(3):
             c.gravity[a] = cfg["sim"]["gravity"][a]
         ct = cfg.get("contact", {}) or {}
-        c.contact_k = ct.get("stiffness", 4.0e4)
-        c.contact_d = ct.get("damping", 600.0)
-        c.contact_ramp = ct.get("damping_ramp", 1.0e-3)
-        c.friction_visc = ct.get("friction_viscosity", 1.0e4)
-        c.limit_k = ct.get("joint_limit_stiffness", 2000.0)
-        c.limit_d = ct.get("joint_limit_damping", 20.0)
+        c.contact_k = float(ct.get("stiffness", 4.0e4))
+        c.contact_d = float(ct.get("damping", 600.0))
+        c.contact_ramp = float(ct.get("damping_ramp", 1.0e-3))
+        c.friction_visc = float(ct.get("friction_viscosity", 1.0e4))
+        c.limit_k = float(ct.get("joint_limit_stiffness", 2000.0))
+        c.limit_d = float(ct.get("joint_limit_damping", 20.0))
         c.clamp_qd = int(bool(ct.get("clamp_dof_velocity", True)))
         c.terrain_mu = 0.5 * (cfg["terrain"]["static_friction"] + cfg["terrain"]["dynamic_friction"])
         c.terrain_restitution = cfg["terrain"]["restitution"]
@@ -352,8 +352,9 @@ class T1(BaseTask):
         torch.cuda.current_stream().synchronize()  # `v` may be a temporary
 
     def episode_stats(self, reset=True):
-        """Device-side replacement of recorder.py:36-53: (finished episodes, mean length, mean reward, {term: mean})."""
-        s = torch.empty(3 + _lib.NUM_REWARD_TERMS, dtype=torch.float32, device=self.device)
+        """Device-side replacement of recorder.py:36-53: float[30] = (finished episodes, sum of lengths, sum of reward,
+        26 per-term sums, resets caused by a non-finite state)."""
+        s = torch.empty(4 + _lib.NUM_REWARD_TERMS, dtype=torch.float32, device=self.device)
         _lib.check(self._lib.bg_env_get_field(self._env, b"episode_stats", _lib.ptr(s), _lib.current_stream_ptr()), "bg_env_get_field")
         if reset:
             z = torch.zeros_like(s)

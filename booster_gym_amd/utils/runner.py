@@ -1,0 +1,329 @@
+"""PPO driver (reference utils/runner.py:19-245, class `Runner`).
+
+Same surface: `Runner(test=False)` parses the reference's 8 CLI flags (runner.py:44-54), merges them over
+`envs/<task>.yaml` (:57-68), seeds (:70-80), builds env / model / Adam / buffers (:27-42), `_load` (:82-97),
+`train()` (:99-215) and `play()` (:217-241).  What changed is how an iteration executes:
+
+  rollout   per env-step: ONE fused actor+sample launch (bg_actor_sample) and ONE env launch (bg_env_step_to) that
+            writes obs / privileged obs / reward / done / time-out directly into rows of the experience buffer;
+            no `.to(device)` copies, no per-done-env `.item()` (runner.py:112-121).
+  update    per mini-epoch: critic + actor GEMMs through PyTorch-ROCm (fp32 MFMA), GAE as one backward scan (bg_gae),
+            the whole loss forward+backward as one pass (bg_ppo_loss) feeding autograd for the two MLPs, global-norm clip +
+            Adam on one flat buffer (bg_adam_step) and the KL-adaptive learning rate on the device (bg_adapt_lr): no host
+            sync inside the 20 mini-epochs (reference: 4 per mini-epoch, runner.py:175,182-184).
+  multi-GPU one process per GPU (torchrun), environments sharded, three all-reduces per mini-epoch on RCCL: advantage
+            moments (3 doubles), the flat gradient (177,945 floats), loss/KL sums (5 doubles) -- SURVEY section 8e.
+
+Reference quirks kept on purpose: GAE recomputed from the current critic every mini-epoch (Q5), the
+time-out reward overwrite repeated in place (Q4), KL measured with the pre-step distribution (Q6), entropy_coef < 0 (Q7).
+"""
+import argparse
+import glob
+import os
+import random
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .. import _lib
+from ..envs import TASKS
+from .buffer import ExperienceBuffer
+from .config import load_cfg
+from .model import ActorCritic
+from .recorder import Recorder
+from .utils import gae, gaussian_logp, ppo_loss_fused
+
+
+class FlatAdam:
+    """Adam state on one flat fp32 buffer, stepped by bg_adam_step.  Exposes a torch.optim.Adam-compatible state_dict."""
+
+    def __init__(self, params, lr, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0):
+        self.params = list(params)
+        dev = self.params[0].device
+        self.sizes = [p.numel() for p in self.params]
+        n = sum(self.sizes)
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.exp_avg = torch.zeros_like(self.flat)
+        self.exp_avg_sq = torch.zeros_like(self.flat)
+        off = 0
+        for p, k in zip(self.params, self.sizes):
+            self.flat[off : off + k].copy_(p.data.reshape(-1))
+            p.data = self.flat[off : off + k].view_as(p)
+            p.grad = self.grad[off : off + k].view_as(p)
+            off += k
+        self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
+        self.betas, self.eps, self.max_grad_norm = betas, eps, max_grad_norm
+        self.step_count = 0
+        self._gnorm = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    def zero_grad(self):
+        self.grad.zero_()
+
+    def step(self):
+        self.step_count += 1
+        _lib.check(_lib.load().bg_adam_step(self.flat.numel(), _lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg),
+                                            _lib.ptr(self.exp_avg_sq), _lib.ptr(self.lr), self.step_count, self.betas[0], self.betas[1], self.eps,
+                                            self.max_grad_norm, _lib.ptr(self._gnorm), _lib.current_stream_ptr()), "bg_adam_step")
+
+    def adapt_lr(self, kl_sum, count, desired_kl, lr_min=1e-5, lr_max=1e-2):
+        _lib.check(_lib.load().bg_adapt_lr(_lib.ptr(kl_sum), float(count), desired_kl, lr_min, lr_max, _lib.ptr(self.lr), _lib.current_stream_ptr()),
+                   "bg_adapt_lr")
+
+    def state_dict(self):
+        state, off = {}, 0
+        for i, k in enumerate(self.sizes):
+            state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off : off + k].view_as(self.params[i]).clone(),
+                        "exp_avg_sq": self.exp_avg_sq[off : off + k].view_as(self.params[i]).clone()}
+            off += k
+        group = {"lr": float(self.lr.item()), "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
+                 "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(self.sizes)))}
+        return {"state": state, "param_groups": [group]}
+
+    def load_state_dict(self, sd):
+        off = 0
+        for i, k in enumerate(self.sizes):
+            st = sd["state"].get(i)
+            if st is not None:
+                self.exp_avg[off : off + k].copy_(st["exp_avg"].reshape(-1))
+                self.exp_avg_sq[off : off + k].copy_(st["exp_avg_sq"].reshape(-1))
+                self.step_count = int(float(st["step"]))
+            off += k
+        self.lr.fill_(float(sd["param_groups"][0]["lr"]))
+
+
+class Runner:
+    def __init__(self, test=False, args=None, cfg=None):
+        self.test = test
+        self._init_distributed()
+        if cfg is None:
+            self._get_args(args)
+            self._update_cfg_from_args()
+        else:
+            self.cfg = cfg
+            self.cfg["basic"].setdefault("task", "T1")
+        self.cfg["basic"]["rank"] = self.rank
+        if self.world_size > 1:  # one process per GPU: each rank simulates and learns on its own device
+            self.cfg["basic"]["sim_device"] = self.cfg["basic"]["rl_device"] = f"cuda:{self.local_rank}"
+        self._set_seed()
+        task = self.cfg["basic"]["task"]
+        if task not in TASKS:
+            raise NameError(f"name {task!r} is not defined")  # reference: eval(task) (runner.py:27)
+        self.env = TASKS[task](self.cfg)
+
+        self.device = self.cfg["basic"]["rl_device"]
+        if torch.device(self.device) != torch.device(self.env.device):
+            raise ValueError("rl_device must equal sim_device: the rollout writes simulator outputs straight into the PPO buffers")
+        self.learning_rate = self.cfg["algorithm"]["learning_rate"]
+        self.model = ActorCritic(self.env.num_actions, self.env.num_obs, self.env.num_privileged_obs).to(self.device)
+        if self.world_size > 1:  # identical initial weights on every rank
+            for p in self.model.parameters():
+                dist.broadcast(p.data, src=0)
+        self.optimizer = FlatAdam(self.model.parameters(), lr=self.learning_rate)
+        self._load()
+
+        T, N = self.cfg["runner"]["horizon_length"], self.env.num_envs
+        self.buffer = ExperienceBuffer(T, N, self.device)
+        self.buffer.add_buffer("actions", (self.env.num_actions,))
+        self.buffer.add_buffer("obses", (self.env.num_obs,), extra_rows=1)
+        self.buffer.add_buffer("privileged_obses", (self.env.num_privileged_obs,), extra_rows=1)
+        self.buffer.add_buffer("rewards", ())
+        self.buffer.add_buffer("dones", (), dtype=torch.bool)
+        self.buffer.add_buffer("time_outs", (), dtype=torch.bool)
+        B, A = T * N, self.env.num_actions
+        dev = self.device
+        self._critic_in = torch.zeros(T + 1, N, self.env.num_obs + self.env.num_privileged_obs, device=dev)
+        self._adv = torch.zeros(T, N, device=dev)
+        self._ret = torch.zeros(T, N, device=dev)
+        self._adv_sums = torch.zeros(3, dtype=torch.float64, device=dev)
+        self._grad_mu = torch.zeros(B, A, device=dev)
+        self._grad_val = torch.zeros(B, device=dev)
+        self._grad_logstd = torch.zeros(A, dtype=torch.float64, device=dev)
+        self._stats = torch.zeros(5, dtype=torch.float64, device=dev)
+        self._stats_acc = torch.zeros(5, dtype=torch.float64, device=dev)
+        self._old_logp = torch.zeros(B, device=dev)
+        self._logstd_grad_view = self.model.logstd.grad.view(-1)
+        self._act_counter = 0
+        self.timers = {"rollout": 0.0, "update": 0.0}
+
+    # ------------------------------------------------------------------ distributed
+    def _init_distributed(self):
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world_size > 1 and not dist.is_initialized():
+            torch.cuda.set_device(self.local_rank)
+            dist.init_process_group(backend="nccl")  # "nccl" is RCCL on ROCm
+
+    def _all_reduce(self, t):
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+    # ------------------------------------------------------------------ config / seed / checkpoint (runner.py:44-97)
+    def _get_args(self, args=None):
+        parser = argparse.ArgumentParser()
+        parser.add_argument("--task", required=True, type=str, help="Name of the task to run.")
+        parser.add_argument("--checkpoint", type=str, help="Path of the model checkpoint to load. Overrides config file if provided.")
+        parser.add_argument("--num_envs", type=int, help="Number of environments to create. Overrides config file if provided.")
+        parser.add_argument("--headless", type=bool, help="Run headless. Overrides config file if provided.")
+        parser.add_argument("--sim_device", type=str, help="Device for physics simulation. Overrides config file if provided.")
+        parser.add_argument("--rl_device", type=str, help="Device for the RL algorithm. Overrides config file if provided.")
+        parser.add_argument("--seed", type=int, help="Random seed. Overrides config file if provided.")
+        parser.add_argument("--max_iterations", type=int, help="Maximum number of training iterations. Overrides config file if provided.")
+        self.args = parser.parse_args(args)
+
+    def _update_cfg_from_args(self):
+        self.cfg = load_cfg(self.args.task)
+        for arg, val in vars(self.args).items():
+            if val is not None:
+                if arg == "num_envs":
+                    self.cfg["env"][arg] = val
+                else:
+                    self.cfg["basic"][arg] = val
+        if not self.test:
+            self.cfg["viewer"]["record_video"] = False
+
+    def _set_seed(self):
+        if self.cfg["basic"]["seed"] == -1:
+            self.cfg["basic"]["seed"] = np.random.randint(0, 10000)
+        seed = self.cfg["basic"]["seed"]
+        if self.rank == 0:
+            print("Setting seed: {}".format(seed))
+        random.seed(seed)
+        np.random.seed(seed)
+        torch.manual_seed(seed)
+        os.environ["PYTHONHASHSEED"] = str(seed)
+        torch.cuda.manual_seed_all(seed)
+
+    def _load(self):
+        ck = self.cfg["basic"].get("checkpoint")
+        if not ck:
+            return
+        if ck == "-1" or ck == -1:
+            ck = sorted(glob.glob(os.path.join("logs", "**/*.pth"), recursive=True), key=os.path.getmtime)[-1]
+            self.cfg["basic"]["checkpoint"] = ck
+        print("Loading model from {}".format(ck))
+        model_dict = torch.load(ck, map_location=self.device, weights_only=True)
+        self.model.load_state_dict(model_dict["model"], strict=False)
+        try:
+            self.env.curriculum_prob = model_dict["curriculum"]
+        except Exception as e:
+            print(f"Failed to load curriculum: {e}")
+        try:
+            self.optimizer.load_state_dict(model_dict["optimizer"])
+        except Exception as e:
+            print(f"Failed to load optimizer: {e}")
+
+    def checkpoint_dict(self):
+        return {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "curriculum": self.env.curriculum_prob}
+
+    # ------------------------------------------------------------------ one PPO iteration
+    def rollout(self):
+        """runner.py:106-121: horizon_length env steps with sampled actions, outputs written in place."""
+        buf, T = self.buffer, self.cfg["runner"]["horizon_length"]
+        obses, priv = buf["obses"], buf["privileged_obses"]
+        seed = int(self.cfg["basic"]["seed"]) + 1000003 * (self.rank + 1)
+        with torch.no_grad():
+            for n in range(T):
+                self.model.sample_actions(obses[n], buf["actions"][n], seed, self._act_counter)
+                self._act_counter += 1
+                self.env.step_to(buf["actions"][n], obses[n + 1], priv[n + 1], buf["rewards"][n], buf["dones"][n], buf["time_outs"][n])
+
+    def update(self):
+        """runner.py:123-189: old log-probs, then mini_epochs full-batch optimiser steps."""
+        cfg, buf = self.cfg, self.buffer
+        T, N = cfg["runner"]["horizon_length"], self.env.num_envs
+        B, A = T * N, self.env.num_actions
+        alg = cfg["algorithm"]
+        obs_flat = buf["obses"][:T].reshape(B, -1)
+        act_flat = buf["actions"].reshape(B, A)
+        torch.cat((buf["obses"], buf["privileged_obses"]), dim=-1, out=self._critic_in)
+        critic_in = self._critic_in[:T].reshape(B, -1)
+        critic_last = self._critic_in[T]
+        with torch.no_grad():
+            old_mu = self.model.actor(obs_flat)
+            old_logstd = self.model.logstd.detach().reshape(-1).clone()
+            gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
+        self._stats_acc.zero_()
+        for _ in range(cfg["runner"]["mini_epochs"]):
+            values = self.model.critic(critic_in).squeeze(-1)
+            with torch.no_grad():
+                last_values = self.model.critic(critic_last).squeeze(-1)
+                gae(buf["rewards"], buf["dones"], buf["time_outs"], values.detach().view(T, N), last_values, alg["gamma"], alg["lam"],
+                    advantages=self._adv, returns=self._ret, sums=self._adv_sums)
+                self._all_reduce(self._adv_sums)
+            mu = self.model.actor(obs_flat)
+            with torch.no_grad():
+                ppo_loss_fused(mu.detach(), self.model.logstd.detach().reshape(-1), act_flat, old_mu, old_logstd, self._old_logp,
+                               self._adv.view(B), self._adv_sums, values.detach(), self._ret.view(B), 0.2, alg["bound_coef"],
+                               alg["entropy_coef"], self._grad_mu, self._grad_val, self._grad_logstd, self._stats)
+            self.optimizer.zero_grad()
+            torch.autograd.backward([mu, values], [self._grad_mu, self._grad_val])
+            self._logstd_grad_view.copy_(self._grad_logstd)
+            if self.world_size > 1:
+                self._all_reduce(self.optimizer.grad)
+                self.optimizer.grad.mul_(1.0 / self.world_size)
+                self._all_reduce(self._stats)
+            self.optimizer.step()
+            self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
+            self._stats_acc += self._stats
+        return self._stats_acc
+
+    def iteration(self):
+        buf, T = self.buffer, self.cfg["runner"]["horizon_length"]
+        self.rollout()
+        stats = self.update()
+        # carry the last observation into row 0 of the next rollout
+        buf["obses"][0].copy_(buf["obses"][T])
+        buf["privileged_obses"][0].copy_(buf["privileged_obses"][T])
+        return stats
+
+    def _summarize(self, stats_acc):
+        """Host-side means of the loss terms over the mini-epochs (runner.py:182-204); one device->host read."""
+        T, N = self.cfg["runner"]["horizon_length"], self.env.num_envs
+        B, A, E = T * N * self.world_size, self.env.num_actions, self.cfg["runner"]["mini_epochs"]
+        s = torch.cat((stats_acc, self._stats, self.optimizer.lr.double())).cpu().tolist()
+        self.learning_rate = s[10]
+        return {"value_loss": s[0] / (B * E), "actor_loss": s[1] / (B * E), "bound_loss": s[2] / (B * A * E), "entropy": s[3] / (B * E),
+                "kl_mean": s[9] / B, "lr": s[10]}
+
+    # ------------------------------------------------------------------ entry points
+    def train(self):
+        self.recorder = Recorder(self.cfg, rank=self.rank)
+        obs, infos = self.env.reset()
+        self.buffer["obses"][0].copy_(obs)
+        self.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+        max_it = self.cfg["basic"]["max_iterations"]
+        for it in range(max_it):
+            stats = self.iteration()
+            summary = self._summarize(stats)
+            self.recorder.record_episode_statistics(self.env, self.env.reward_names, it)
+            summary.update({"curriculum/mean_lin_vel_level": self.env.mean_lin_vel_level, "curriculum/mean_ang_vel_level": self.env.mean_ang_vel_level,
+                            "curriculum/max_lin_vel_level": self.env.max_lin_vel_level, "curriculum/max_ang_vel_level": self.env.max_ang_vel_level})
+            self.recorder.record_statistics(summary, it)
+            if (it + 1) % self.cfg["runner"]["save_interval"] == 0:
+                self.recorder.save(self.checkpoint_dict(), it + 1)
+            if self.rank == 0:
+                print("epoch: {}/{}".format(it + 1, max_it))
+
+    def play(self, max_steps=None, record_path=None):
+        """Deterministic rollout with `dist.loc` (runner.py:217-229).  The reference's camera video (runner.py:230-241) is replaced
+        by an optional .npz trajectory dump; `max_steps=None` runs until interrupted like the reference."""
+        obs, infos = self.env.reset()
+        traj, step = [], 0
+        try:
+            while max_steps is None or step < max_steps:
+                with torch.no_grad():
+                    act = self.model.actor(obs)
+                    obs, rew, done, infos = self.env.step(act)
+                if record_path is not None:
+                    traj.append({"root": self.env.root_states[0].cpu().numpy(), "dof_pos": self.env.dof_pos[0].cpu().numpy(), "rew": float(rew[0])})
+                step += 1
+        except KeyboardInterrupt:
+            pass
+        if record_path is not None and traj:
+            np.savez(record_path, root=np.stack([t["root"] for t in traj]), dof_pos=np.stack([t["dof_pos"] for t in traj]),
+                     rew=np.array([t["rew"] for t in traj]))
+        return step
