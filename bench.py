@@ -46,48 +46,14 @@ def gemm_flops_per_iteration(n_envs, horizon, mini_epochs):
     return train + nograd
 
 
-def cpu_baseline(cfg, n_sample=128, horizon=24, mini_epochs=20):
-    """CPU restatement baseline ("port"): oracle physics (C, OpenMP over envs) for a 24-step rollout of `n_sample` envs with
-    the actor evaluated in torch-CPU, plus the 20 mini-epoch PPO update in torch-CPU on that batch.  NOT PhysX."""
-    import numpy as np
+def cpu_baseline(n_sample=2048):
+    """CPU restatement baseline ("port"), timed in a child process that never touches the GPU (oracle/cpu_baseline.py)."""
+    import subprocess
 
-    from booster_gym_amd.utils.model import ActorCritic
-    from booster_gym_amd.utils.urdf import load_model
-    from oracle.dyn_ref import DynRef
-    from oracle.ppo_ref import ppo_update_reference
-
-    cores = os.cpu_count() or 1
-    torch.set_num_threads(cores)
-    m = load_model(cfg["asset"]["file"])
-    ref = DynRef(m, feet_edge_pos=cfg["asset"]["feet_edge_pos"])
-    rng = np.random.default_rng(0)
-    n = n_sample
-    model = ActorCritic(12, 47, 14)
-    root = np.zeros((n, 13)); root[:, 2] = 0.72; root[:, 6] = 1.0
-    default = np.array([-0.2, 0, 0, 0.4, -0.25, 0] * 2)
-    q = np.tile(default, (n, 1)); qd = np.zeros((n, 12)); last_t = q.copy()
-    kp = np.tile(np.array([200, 200, 200, 200, 50, 50] * 2, dtype=float), (n, 1)); kd = np.tile(np.array([5, 5, 5, 5, 1, 1] * 2, dtype=float), (n, 1))
-    fric = np.zeros((n, 12)); ms = np.ones((n, 13)); co = np.zeros((n, 39)); fm = np.tile(np.array([1.0, 1.0, 0.0] * 2), (n, 1))
-    delay = np.zeros(n, dtype=np.int32); wrench = np.zeros((n, 6))
-    obs = torch.zeros(horizon, n, 47); priv = torch.zeros(horizon, n, 14); acts = torch.zeros(horizon, n, 12)
-    t0 = time.perf_counter()
-    for t in range(horizon):
-        o = torch.zeros(n, 47)
-        o[:, 11:23] = torch.tensor(q - default, dtype=torch.float32); o[:, 23:35] = torch.tensor(qd * 0.1, dtype=torch.float32)
-        with torch.no_grad():
-            a = torch.distributions.Normal(model.actor(o), torch.exp(model.logstd)).sample().clamp(-1, 1)
-        obs[t], acts[t] = o, a
-        ref.substeps_batch(10, ms, co, fm, kp, kd, fric, m.dof_effort, root, q, qd, default + a.numpy().astype(np.float64), last_t, delay, wrench)
-    t_roll = time.perf_counter() - t0
-    rew = torch.rand(horizon, n); dones = torch.zeros(horizon, n, dtype=torch.bool); touts = torch.zeros(horizon, n, dtype=torch.bool)
-    t0 = time.perf_counter()
-    ppo_update_reference(model, torch.optim.Adam(model.parameters(), lr=1e-5), obs, priv, acts, rew, dones, touts, obs[-1], priv[-1],
-                         mini_epochs=mini_epochs)
-    t_upd = time.perf_counter() - t0
-    total = t_roll + t_upd
-    return {"value": n * horizon / total, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n} envs x {horizon} env-steps: oracle/dyn_ref.c physics (OpenMP) + torch-CPU actor, then {mini_epochs} torch-CPU PPO "
-                      f"mini-epochs on that batch; rollout {t_roll:.2f}s update {t_upd:.2f}s; obs/reward task logic not included"}
+    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(n_sample)], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    if r.returncode != 0:
+        raise RuntimeError(r.stderr[-400:])
+    return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def main():
@@ -100,6 +66,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
+    t_start = time.perf_counter()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
@@ -125,8 +92,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def log(msg):
+        if rank == 0:
+            print(f"[bench +{time.perf_counter() - t_start:.1f}s] {msg}", file=sys.stderr, flush=True)
+
+    log("env + runner built")
+    for w in range(args.warmup):
         runner.iteration()
+        torch.cuda.synchronize()
+        log(f"warmup iteration {w} done")
     # instrument: HIP events around every env-step launch and around the update phase (torch's current stream is the launch stream)
     step_events, phase_events = [], []
     orig_step_to = runner.env.step_to
@@ -151,6 +125,7 @@ def main():
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
     wall = float(tw.item())
 
+    log(f"timed region done: {wall:.3f}s for {args.steps} iterations")
     if rank == 0:
         step_ms = sum(a.elapsed_time(b) for a, b in step_events) / max(len(step_events), 1)
         roll_ms = sum(a.elapsed_time(b) for a, b, _ in phase_events) / len(phase_events)
@@ -178,7 +153,9 @@ def main():
         out["roofline_update"]["frac"] = out["roofline_update"]["achieved"] / MFMA_F32_PEAK_TF
         if not args.no_cpu_baseline and world == 1:
             try:
-                out["cpu_baseline"] = cpu_baseline(cfg)
+                log("cpu baseline ...")
+                out["cpu_baseline"] = cpu_baseline()
+                log("cpu baseline done")
             except Exception as ex:  # the bench line must still print
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))
