@@ -394,3 +394,7 @@ class T1(BaseTask):
     @property
     def common_step_counter(self):
         return int(self._lib.bg_env_step_count(self._env))
+
+    @common_step_counter.setter
+    def common_step_counter(self, value):
+        _lib.check(self._lib.bg_env_set_step_count(self._env, int(value)), "bg_env_set_step_count")

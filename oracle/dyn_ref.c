@@ -491,6 +491,19 @@ int ref_inverse(const ref_model_t *m, const ref_phys_t *p, const double *mass_sc
     return 0;
 }
 
+/* world pose of every body: pos [NB][3], rot [NB][9] (row-major body->world); used by the task oracle for the feet */
+void ref_body_poses(const ref_model_t *m, const double *root, const double *q, double *pos, double *rot) {
+    ref_phys_t p;
+    memset(&p, 0, sizeof(p));
+    double qd[ND] = {0};
+    kin_t k;
+    kinematics(m, &p, 0, 0, root, q, qd, &k);
+    for (int i = 0; i < m->nb; i++) {
+        for (int a = 0; a < 3; a++) pos[3 * i + a] = k.pw[i][a];
+        for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) rot[9 * i + 3 * a + b] = k.Rw[i][a][b];
+    }
+}
+
 /* ------------------------------------------------------------------ one substep: semi-implicit Euler */
 static void quat_mul(const double a[4], const double b[4], double o[4]) { /* xyzw */
     o[3] = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];

@@ -171,6 +171,12 @@ class DynRef:
         lib().ref_inverse(C.byref(self.model), C.byref(self.phys), _p(mass_scale), _p(com_off), _p(root), _p(q), _p(qd), _p(qacc), _p(res))
         return res
 
+    def body_poses(self, root, q):
+        root, q = _f64(root), _f64(q)
+        pos, rot = np.zeros((NB, 3)), np.zeros((NB, 3, 3))
+        lib().ref_body_poses(C.byref(self.model), _p(root), _p(q), _p(pos), _p(rot))
+        return pos, rot
+
     def step(self, root, q, qd, tau, base_wrench=None, mass_scale=None, com_off=None, foot_mat=None):
         """One substep, in place on float64 arrays root[13], q[12], qd[12]. Returns contact forces [13,3]."""
         assert root.dtype == np.float64 and q.dtype == np.float64 and qd.dtype == np.float64
