@@ -159,8 +159,7 @@ def main():
             except Exception as ex:  # the bench line must still print
                 out["cpu_baseline"] = {"error": repr(ex)}
         print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    runner.dp.shutdown()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,64 @@
+"""Data-parallel plumbing: one process per GPU, environments sharded across ranks.
+
+The reference is single-process (no torch.distributed anywhere).  Environments are independent, so the only exchange is per
+optimiser step: (1) [sum adv, sum adv^2, count] so that every rank normalises advantages with the global moments
+(runner.py:145), (2) one flat fp32 gradient bucket (177,945 floats = 712 kB, latency-bound on xGMI: one collective, no
+per-parameter hooks), averaged, (3) the loss / KL sums so that every rank takes the same learning-rate branch
+(runner.py:174-180).  With equal shards this is algebraically the reference update on the union of all shards.
+
+Backend: "nccl" (= RCCL on ROCm) on GPUs; `BG_DIST_BACKEND=gloo` lets the CPU tests run the same code path.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+class DataParallel:
+    def __init__(self, backend=None):
+        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        self.backend = os.environ.get("BG_DIST_BACKEND", backend or "nccl")
+        self.owns_group = False
+        if self.world_size > 1 and not dist.is_initialized():
+            if self.backend == "nccl":
+                torch.cuda.set_device(self.local_rank)
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size)
+            self.owns_group = True
+
+    @property
+    def active(self):
+        return self.world_size > 1
+
+    def sum_(self, t):
+        """In-place SUM all-reduce (no-op for a single process)."""
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def average_(self, t):
+        """In-place mean over ranks: the flat gradient bucket."""
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            t.mul_(1.0 / self.world_size)
+        return t
+
+    def max_(self, t):
+        if self.active:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return t
+
+    def broadcast_parameters(self, module, src=0):
+        if self.active:
+            for p in module.parameters():
+                dist.broadcast(p.data, src=src)
+
+    def barrier(self):
+        if self.active:
+            dist.barrier()
+
+    def shutdown(self):
+        if self.active and self.owns_group and dist.is_initialized():
+            dist.destroy_process_group()

@@ -25,13 +25,13 @@ import time
 
 import numpy as np
 import torch
-import torch.distributed as dist
 
 from .. import _lib
 from ..envs import TASKS
 from .buffer import ExperienceBuffer
 from .config import load_cfg
 from .model import ActorCritic
+from .parallel import DataParallel
 from .recorder import Recorder
 from .utils import gae, gaussian_logp, ppo_loss_fused
 
@@ -97,7 +97,8 @@ class FlatAdam:
 class Runner:
     def __init__(self, test=False, args=None, cfg=None):
         self.test = test
-        self._init_distributed()
+        self.dp = DataParallel()
+        self.world_size, self.rank, self.local_rank = self.dp.world_size, self.dp.rank, self.dp.local_rank
         if cfg is None:
             self._get_args(args)
             self._update_cfg_from_args()
@@ -118,9 +119,7 @@ class Runner:
             raise ValueError("rl_device must equal sim_device: the rollout writes simulator outputs straight into the PPO buffers")
         self.learning_rate = self.cfg["algorithm"]["learning_rate"]
         self.model = ActorCritic(self.env.num_actions, self.env.num_obs, self.env.num_privileged_obs).to(self.device)
-        if self.world_size > 1:  # identical initial weights on every rank
-            for p in self.model.parameters():
-                dist.broadcast(p.data, src=0)
+        self.dp.broadcast_parameters(self.model)  # identical initial weights on every rank
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.learning_rate)
         self._load()
 
@@ -147,19 +146,6 @@ class Runner:
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
         self._act_counter = 0
         self.timers = {"rollout": 0.0, "update": 0.0}
-
-    # ------------------------------------------------------------------ distributed
-    def _init_distributed(self):
-        self.world_size = int(os.environ.get("WORLD_SIZE", "1"))
-        self.rank = int(os.environ.get("RANK", "0"))
-        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-        if self.world_size > 1 and not dist.is_initialized():
-            torch.cuda.set_device(self.local_rank)
-            dist.init_process_group(backend="nccl")  # "nccl" is RCCL on ROCm
-
-    def _all_reduce(self, t):
-        if self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
 
     # ------------------------------------------------------------------ config / seed / checkpoint (runner.py:44-97)
     def _get_args(self, args=None):
@@ -253,7 +239,7 @@ class Runner:
                 last_values = self.model.critic(critic_last).squeeze(-1)
                 gae(buf["rewards"], buf["dones"], buf["time_outs"], values.detach().view(T, N), last_values, alg["gamma"], alg["lam"],
                     advantages=self._adv, returns=self._ret, sums=self._adv_sums)
-                self._all_reduce(self._adv_sums)
+                self.dp.sum_(self._adv_sums)
             mu = self.model.actor(obs_flat)
             with torch.no_grad():
                 ppo_loss_fused(mu.detach(), self.model.logstd.detach().reshape(-1), act_flat, old_mu, old_logstd, self._old_logp,
@@ -262,10 +248,8 @@ class Runner:
             self.optimizer.zero_grad()
             torch.autograd.backward([mu, values], [self._grad_mu, self._grad_val])
             self._logstd_grad_view.copy_(self._grad_logstd)
-            if self.world_size > 1:
-                self._all_reduce(self.optimizer.grad)
-                self.optimizer.grad.mul_(1.0 / self.world_size)
-                self._all_reduce(self._stats)
+            self.dp.average_(self.optimizer.grad)
+            self.dp.sum_(self._stats)
             self.optimizer.step()
             self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
             self._stats_acc += self._stats

@@ -1,0 +1,177 @@
+"""Parity of the fused PPO kernels (through the C ABI) with the reference-generated golden vectors (tests/golden/ppo_*.npz) and with
+the torch restatement of the reference update loop (oracle/ppo_ref.py).  fp32; tolerances stated per assert."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = lambda name: np.load(os.path.join(HERE, "golden", name))
+DEV = "cuda:0"
+
+
+def test_gae_matches_reference_fixture():
+    from booster_gym_amd.utils.utils import discount_values, gae
+
+    d = G("ppo_gae.npz")
+    t = lambda k: torch.tensor(d[k], device=DEV)
+    adv = discount_values(t("rewards"), t("dones") | t("time_outs"), t("values"), t("last_values"), float(d["gamma"]), float(d["lam"]))
+    assert torch.allclose(adv, t("advantages"), atol=2e-6)
+    # fused form: time-out overwrite + returns + moments
+    rew = t("rewards").clone()
+    a2, ret, sums = gae(rew, t("dones"), t("time_outs"), t("values"), t("last_values"), float(d["gamma"]), float(d["lam"]))
+    exp_rew = t("rewards").clone(); exp_rew[t("time_outs")] = t("values")[t("time_outs")]
+    assert torch.equal(rew, exp_rew)
+    from oracle.ppo_ref import discount_values as dv_ref
+
+    a_ref = dv_ref(exp_rew.cpu(), (t("dones") | t("time_outs")).cpu(), t("values").cpu(), t("last_values").cpu(), float(d["gamma"]), float(d["lam"]))
+    assert torch.allclose(a2.cpu(), a_ref, atol=2e-6) and torch.allclose(ret.cpu(), t("values").cpu() + a_ref, atol=2e-6)
+    s = sums.cpu().numpy()
+    assert abs(s[0] - a_ref.double().sum().item()) < 1e-3 and abs(s[1] - a_ref.double().square().sum().item()) < 1e-2 and s[2] == a_ref.numel()
+
+
+def test_gae_edge_cases():
+    from booster_gym_amd.utils.utils import gae
+
+    # T = 1, every env done / timed out; N not a multiple of the block
+    T, N = 1, 77
+    rew, val, last = torch.rand(T, N, device=DEV), torch.randn(T, N, device=DEV), torch.randn(N, device=DEV)
+    done = torch.ones(T, N, dtype=torch.bool, device=DEV); to = torch.zeros(T, N, dtype=torch.bool, device=DEV)
+    adv, ret, sums = gae(rew.clone(), done, to, val, last, 0.99, 0.9)
+    assert torch.allclose(adv, rew - val, atol=1e-6) and sums[2].item() == N
+
+
+def _epoch_inputs():
+    d = G("ppo_epoch.npz")
+    t = lambda k: torch.tensor(d[k], device=DEV)
+    from booster_gym_amd.utils.model import ActorCritic
+
+    model = ActorCritic(12, 47, 14).to(DEV)
+    model.load_state_dict({k[3:]: torch.tensor(d[k]) for k in d.files if k.startswith("sd_")})
+    return d, t, model
+
+
+def test_fused_loss_gradients_match_reference_fixture():
+    """One mini-epoch (runner.py:132-163): losses, advantages and every parameter gradient vs the reference-computed fixture."""
+    from booster_gym_amd.utils.utils import gae, gaussian_logp, ppo_loss_fused
+
+    d, t, model = _epoch_inputs()
+    T, N, A = 24, 64, 12
+    B = T * N
+    obs, priv, act = t("obses"), t("priv"), t("actions")
+    values = model.critic(torch.cat((obs, priv), -1).reshape(B, -1)).squeeze(-1)
+    last_values = model.critic(torch.cat((t("last_obs"), t("last_priv")), -1)).squeeze(-1).detach()
+    rew = t("rewards").clone()
+    adv, ret, sums = gae(rew, t("dones"), t("time_outs"), values.detach().view(T, N).contiguous(), last_values, 0.995, 0.95)
+    assert torch.allclose(rew, t("rewards_after"), atol=1e-6)
+    assert torch.allclose(adv, t("advantages"), atol=2e-5) and torch.allclose(ret, t("returns"), atol=2e-5)
+    mu = model.actor(obs.reshape(B, -1))
+    assert torch.allclose(mu, t("mu").reshape(B, A), atol=1e-5)
+    logstd = model.logstd.detach().reshape(-1).contiguous()
+    lp = gaussian_logp(mu.detach().contiguous(), logstd, act.reshape(B, A).contiguous())
+    assert torch.allclose(lp, t("logp").reshape(B), atol=2e-4)
+    g_mu, g_v = torch.zeros(B, A, device=DEV), torch.zeros(B, device=DEV)
+    g_ls, stats = torch.zeros(A, dtype=torch.float64, device=DEV), torch.zeros(5, dtype=torch.float64, device=DEV)
+    old_logstd = torch.tensor(d["old_logstd"], dtype=torch.float32, device=DEV).contiguous()
+    ppo_loss_fused(mu.detach().contiguous(), logstd, act.reshape(B, A).contiguous(), t("old_mu").reshape(B, A).contiguous(), old_logstd,
+                   t("old_logp").reshape(B).contiguous(), adv.view(B), sums, values.detach().contiguous(), ret.view(B), 0.2, 1.0, -0.01, g_mu, g_v, g_ls, stats)
+    s = stats.cpu().numpy()
+    losses = np.array([s[0] / B, s[1] / B, s[2] / (B * A), s[3] / B, s[4] / B])
+    assert np.allclose(losses, d["losses"], rtol=2e-4, atol=1e-6), (losses, d["losses"])
+    torch.autograd.backward([mu, values], [g_mu, g_v])
+    for k, p in model.named_parameters():
+        ref = t("grad_" + k)
+        got = g_ls.float().view_as(ref) if k == "logstd" else p.grad
+        assert torch.allclose(got, ref, rtol=2e-3, atol=2e-6 + 2e-4 * ref.abs().max().item()), k
+
+
+def test_actor_sample_kernel_matches_torch_actor():
+    from booster_gym_amd.utils.model import ActorCritic
+
+    torch.manual_seed(0)
+    model = ActorCritic(12, 47, 14).to(DEV)
+    for n in (1, 37, 4096):
+        obs = torch.randn(n, 47, device=DEV)
+        mu, act = torch.empty(n, 12, device=DEV), torch.empty(n, 12, device=DEV)
+        model.sample_actions(obs, act, seed=5, counter=3, mu_out=mu)
+        with torch.no_grad():
+            ref = model.actor(obs)
+        assert torch.allclose(mu, ref, atol=2e-5), n
+        z = (act - mu) / torch.exp(model.logstd.detach())
+        if n == 4096:
+            assert abs(z.mean().item()) < 0.02 and abs(z.std().item() - 1.0) < 0.02  # unit normal noise
+        # same (seed, counter) -> same sample ; different counter -> different sample
+        act2 = torch.empty_like(act); model.sample_actions(obs, act2, seed=5, counter=3)
+        act3 = torch.empty_like(act); model.sample_actions(obs, act3, seed=5, counter=4)
+        assert torch.equal(act, act2) and not torch.equal(act, act3)
+
+
+def test_adam_step_matches_torch_adam_with_grad_clipping():
+    from booster_gym_amd.utils.runner import FlatAdam
+
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.randn(300, 7, device=DEV)), torch.nn.Parameter(torch.randn(11, device=DEV))]
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    fa = FlatAdam(ps, lr=3e-4)
+    ref = torch.optim.Adam(qs, lr=3e-4)
+    for it in range(5):
+        gs = [torch.randn_like(p) * (3.0 if it % 2 == 0 else 0.01) for p in ps]  # exercises clip and no-clip
+        fa.zero_grad()
+        for p, q, g in zip(ps, qs, gs):
+            p.grad.copy_(g); q.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        ref.step(); fa.step()
+        for p, q in zip(ps, qs):
+            assert torch.allclose(p, q, rtol=1e-5, atol=1e-6), it
+    sd = fa.state_dict()
+    assert set(sd) == {"state", "param_groups"} and sd["state"][0]["exp_avg"].shape == (300, 7)
+
+
+def test_adapt_lr_rule():
+    from booster_gym_amd.utils.runner import FlatAdam
+
+    fa = FlatAdam([torch.nn.Parameter(torch.zeros(4, device=DEV))], lr=1e-3)
+    kl = torch.zeros(1, dtype=torch.float64, device=DEV)
+    for kl_mean, expect in ((0.05, 1e-3 / 1.5), (0.001, 1e-3), (0.01, 1e-3)):  # > 2*desired: /1.5 ; < desired/2: *1.5 ; else unchanged
+        kl.fill_(kl_mean * 100)
+        fa.adapt_lr(kl, 100, 0.01)
+        assert abs(fa.lr.item() - expect) < 1e-9, (kl_mean, fa.lr.item())
+    fa.lr.fill_(1.2e-5); kl.fill_(1.0 * 100); fa.adapt_lr(kl, 100, 0.01)
+    assert abs(fa.lr.item() - 1e-5) < 1e-12  # floor
+    fa.lr.fill_(9e-3); kl.fill_(0.0); fa.adapt_lr(kl, 100, 0.01)
+    assert abs(fa.lr.item() - 1e-2) < 1e-9  # ceiling
+
+
+def test_full_update_matches_reference_loop():
+    """Runner.update() (fused kernels, flat Adam, device-side LR) vs oracle/ppo_ref.ppo_update_reference (the reference loop op by op)
+    from the same weights on the same rollout data: parameters after 3 mini-epochs agree, and so do the logged losses and the LR."""
+    from booster_gym_amd.utils.config import load_cfg
+    from booster_gym_amd.utils.model import ActorCritic
+    from booster_gym_amd.utils.runner import Runner
+    from oracle.ppo_ref import ppo_update_reference
+
+    n, E = 128, 3
+    cfg = load_cfg("T1", {"env.num_envs": n, "terrain.type": "plane", "runner.mini_epochs": E})
+    r = Runner(cfg=cfg)
+    obs, infos = r.env.reset()
+    r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+    r.rollout()
+    T = cfg["runner"]["horizon_length"]
+    ref_model = ActorCritic(12, 47, 14).to(DEV)
+    ref_model.load_state_dict(r.model.state_dict())
+    b = r.buffer
+    rewards_ref = b["rewards"].clone()
+    stats_ref, lr_ref = ppo_update_reference(ref_model, torch.optim.Adam(ref_model.parameters(), lr=1e-5), b["obses"][:T].clone(), b["privileged_obses"][:T].clone(),
+                                             b["actions"].clone(), rewards_ref, b["dones"].clone(), b["time_outs"].clone(), b["obses"][T].clone(),
+                                             b["privileged_obses"][T].clone(), mini_epochs=E, learning_rate=1e-5)
+    acc = r.update()
+    summ = r._summarize(acc)
+    for (k, p), (k2, q) in zip(r.model.named_parameters(), ref_model.named_parameters()):
+        assert k == k2
+        assert torch.allclose(p, q, rtol=1e-3, atol=2e-6), (k, (p - q).abs().max().item())
+    assert torch.allclose(b["rewards"], rewards_ref, atol=1e-5)  # in-place time-out overwrite, repeated every mini-epoch
+    for k in ("value_loss", "actor_loss", "bound_loss", "entropy", "kl_mean"):
+        assert abs(summ[k] - stats_ref[k]) <= 2e-4 * max(1.0, abs(stats_ref[k])), (k, summ[k], stats_ref[k])
+    assert abs(summ["lr"] - lr_ref) < 1e-9

@@ -1,0 +1,384 @@
+"""CPU tests (-m "not gpu"): the C ABI library loads and exports every declared symbol, host-side mirrors of the reference
+interface behave like the reference (same errors, same config semantics), the product's per-lane dynamics/RNG headers compiled
+for the host agree with the oracle, and the data-parallel path is exact under gloo with world_size 2."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from booster_gym_amd import _lib
+
+    header = open(os.path.join(ROOT, "include", "booster_gym_amd.h")).read()
+    declared = sorted(set(re.findall(r"\b(bg_[a-z_0-9]+)\s*\(", header)))
+    assert declared == sorted(_lib.SYMBOLS), set(declared) ^ set(_lib.SYMBOLS)
+    lib = _lib.load()
+    for s in declared:
+        assert hasattr(lib, s), s
+    assert b"gfx950" in lib.bg_version()
+
+
+def test_ctypes_structs_match_the_c_header(tmp_path):
+    from booster_gym_amd import _lib
+
+    src = tmp_path / "sz.c"
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "booster_gym_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(bg_env_cfg), '
+                   "sizeof(bg_model_desc), offsetof(bg_env_cfg, reward_scale), offsetof(bg_env_cfg, terrain_type), offsetof(bg_env_cfg, noise_gravity), "
+                   "offsetof(bg_model_desc, feet_edge_pos));return 0;}\n")
+    exe = tmp_path / "sz"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
+    E, M = _lib.EnvCfg, _lib.ModelDesc
+    assert got == [C.sizeof(E), C.sizeof(M), E.reward_scale.offset, E.terrain_type.offset, E.noise_gravity.offset, M.feet_edge_pos.offset]
+
+
+def test_abi_argument_errors_without_gpu():
+    """Entry points validate their arguments before touching the device and report through bg_last_error()."""
+    from booster_gym_amd import _lib
+
+    lib = _lib.load()
+    out = C.c_void_p()
+    assert lib.bg_model_create(None, C.byref(out)) < 0 and b"null" in lib.bg_last_error()
+    d = _lib.ModelDesc()
+    d.num_bodies, d.num_dofs = 5, 4
+    assert lib.bg_model_create(C.byref(d), C.byref(out)) < 0 and b"13-body" in lib.bg_last_error()
+    assert lib.bg_gae(0, 4, None, None, None, None, None, 0.9, 0.9, None, None, None, None) < 0
+    assert lib.bg_env_step(None, None, None) < 0
+    if not torch.cuda.is_available():
+        from booster_gym_amd.utils.urdf import FlatModel
+
+        # a valid model is accepted, but an env cannot be created without a HIP device: no CPU path
+        m = FlatModel.load(os.path.join(ROOT, "booster_gym_amd", "resources", "T1", "T1_locomotion.flat.json"))
+        d = _lib.ModelDesc(); d.num_bodies, d.num_dofs = 13, 12
+        for b in range(13):
+            d.parent[b], d.joint_axis[b], d.mass[b] = int(m.parent[b]), int(m.joint_axis[b]), float(m.mass[b])
+        assert lib.bg_model_create(C.byref(d), C.byref(out)) == 0
+        cfg = _lib.EnvCfg(); cfg.num_envs, cfg.decimation, cfg.sim_dt = 4, 10, 0.002
+        env = C.c_void_p()
+        assert lib.bg_env_create(C.byref(cfg), out, C.byref(env)) < 0 and b"no HIP device" in lib.bg_last_error()
+        lib.bg_model_destroy(out)
+
+
+# ------------------------------------------------------------------ host mirrors of the reference interface
+def test_config_surface_is_a_superset_of_the_reference_yaml():
+    from booster_gym_amd.utils.config import load_cfg
+
+    cfg = load_cfg("T1")
+    ref_path = "/root/reference/envs/T1.yaml"
+    if os.path.isfile(ref_path):
+        ref = yaml.safe_load(open(ref_path))
+
+        def walk(a, b, path=""):
+            for k, v in b.items():
+                assert k in a, path + str(k)
+                if isinstance(v, dict):
+                    walk(a[k], v, path + str(k) + ".")
+                elif path + str(k) not in ("basic.headless", "runner.use_wandb", "viewer.record_video", "sim.physics_engine"):
+                    assert a[k] == v, (path + str(k), a[k], v)
+        walk(cfg, ref)
+    assert cfg["env"]["num_envs"] == 4096 and cfg["runner"]["horizon_length"] == 24 and cfg["control"]["decimation"] == 10
+    assert isinstance(cfg["contact"]["stiffness"], float)
+    assert load_cfg("T1", {"env.num_envs": 8})["env"]["num_envs"] == 8
+    with pytest.raises(FileNotFoundError):
+        load_cfg("NoSuchTask")
+
+
+def test_runner_cli_overrides_follow_the_reference():
+    """runner.py:44-68: 8 flags; num_envs lands in cfg['env'], everything else in cfg['basic']; --task is required."""
+    from booster_gym_amd.utils.runner import Runner
+
+    r = object.__new__(Runner)
+    r.test = False
+    r._get_args(["--task", "T1", "--num_envs", "16", "--seed", "7", "--max_iterations", "3", "--sim_device", "cuda:1", "--headless", "x"])
+    r._update_cfg_from_args()
+    assert r.cfg["env"]["num_envs"] == 16 and r.cfg["basic"]["seed"] == 7 and r.cfg["basic"]["max_iterations"] == 3
+    assert r.cfg["basic"]["sim_device"] == "cuda:1" and r.cfg["basic"]["headless"] is True and r.cfg["basic"]["task"] == "T1"
+    assert r.cfg["viewer"]["record_video"] is False
+    with pytest.raises(SystemExit):
+        r._get_args([])
+
+
+def test_env_refuses_cpu_and_bad_configs():
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+
+    with pytest.raises(ValueError, match="GPU only"):
+        T1(load_cfg("T1", {"basic.sim_device": "cpu", "env.num_envs": 4}))
+    with pytest.raises(ValueError, match="Invalid terrain type"):
+        T1(load_cfg("T1", {"terrain.type": "moon", "env.num_envs": 4}))
+    with pytest.raises(ValueError, match="up-axis"):
+        T1(load_cfg("T1", {"sim.up_axis": "y", "env.num_envs": 4}))
+
+
+def test_apply_randomization_matches_reference_and_raises_like_it():
+    from booster_gym_amd.utils.utils import apply_randomization, rand_spec
+
+    d = np.load(os.path.join(HERE, "golden", "apply_randomization.npz"))
+    x = torch.tensor(d["x"])
+    for dist in ("gaussian", "uniform"):
+        for op in ("additive", "scaling"):
+            torch.manual_seed(7)
+            y, noise = apply_randomization(x, {"distribution": dist, "operation": op, "range": [0.3, 0.7]}, return_noise=True)
+            assert torch.allclose(y, torch.tensor(d[f"{dist}_{op}_y"])) and torch.allclose(noise, torch.tensor(d[f"{dist}_{op}_noise"]))
+    assert apply_randomization(x, None) is x
+    with pytest.raises(ValueError, match="distribution"):
+        apply_randomization(x, {"distribution": "cauchy", "operation": "additive", "range": [0, 1]})
+    with pytest.raises(ValueError, match="operation"):
+        apply_randomization(x, {"distribution": "uniform", "operation": "xor", "range": [0, 1]})
+    assert isinstance(apply_randomization(1.0, {"distribution": "uniform", "operation": "scaling", "range": [2.0, 2.0]}), float)
+    assert rand_spec(None) == (0, 0.0, 0.0) and rand_spec({"distribution": "gaussian", "operation": "scaling", "range": [1, 2]}) == (2, 1.0, 2.0)
+    assert rand_spec({"distribution": "uniform", "operation": "additive", "range": [1, 2]})[0] == 3
+
+
+def test_terrain_generation_and_height_query():
+    from booster_gym_amd.utils.config import load_cfg
+    from booster_gym_amd.utils.terrain import Terrain
+    from oracle.task_ref import terrain_heights
+
+    cfg = load_cfg("T1")
+    t = Terrain("cpu", cfg["terrain"], seed=42)
+    hf = t.height_field_raw
+    assert hf.shape == (900, 200) and hf.dtype == np.int16  # 8 x 100 px + 2 x 50 px border (terrain.py:38-45)
+    assert (hf[:50] == 0).all() and (hf[:, :50] == 0).all() and (hf[-50:] == 0).all()  # flat border
+    rough, obst = hf[50:450, 50:150], hf[450:850, 50:150]
+    assert np.abs(rough).max() <= 10 and rough.std() > 1  # +-0.05 m / 0.005
+    assert set(np.unique(obst)).issubset({-4, -2, 0, 2, 4})  # +-0.02 m, +-0.01 m obstacles
+    assert (obst[35:65, 35:65] == 0).all()  # 3 m flat platform of the first obstacle strip
+    assert (Terrain("cpu", cfg["terrain"], seed=42).height_field_raw == hf).all() and (Terrain("cpu", cfg["terrain"], seed=43).height_field_raw != hf).any()
+    xy = np.random.default_rng(0).uniform([0, 0], [80, 10], (200, 2))
+    tdict = dict(height_field_raw=hf, hscale=0.1, vscale=0.005, border_px=50)
+    assert np.allclose(t.terrain_heights(torch.tensor(np.c_[xy, np.zeros(200)])).numpy(), terrain_heights(tdict, xy), atol=1e-6)
+    plane = Terrain("cpu", dict(cfg["terrain"], type="plane"))
+    assert plane.terrain_heights(torch.zeros(5, 3)).abs().max() == 0
+    with pytest.raises(ValueError):
+        Terrain("cpu", dict(cfg["terrain"], type="lava"))
+
+
+def test_urdf_loader_collapses_fixed_joints(tmp_path):
+    from booster_gym_amd.utils.urdf import FlatModel, load_urdf
+
+    urdf = """<robot name="toy"><link name="a"><inertial><origin xyz="0 0 0" rpy="0 0 0"/><mass value="2"/><inertia ixx="1" ixy="0" ixz="0" iyy="1" iyz="0" izz="1"/></inertial>
+    <collision><origin xyz="0 0 0" rpy="0 0 0"/><geometry><box size="1 1 1"/></geometry></collision></link>
+    <link name="b"><inertial><origin xyz="0 0 0" rpy="0 0 0"/><mass value="2"/><inertia ixx="1" ixy="0" ixz="0" iyy="2" iyz="0" izz="3"/></inertial></link>
+    <link name="c"><inertial><origin xyz="0 0 -0.1" rpy="0 0 0"/><mass value="1"/><inertia ixx="0.1" ixy="0" ixz="0" iyy="0.1" iyz="0" izz="0.1"/></inertial></link>
+    <joint name="fix" type="fixed"><origin xyz="1 0 0" rpy="0 0 1.5707963267948966"/><parent link="a"/><child link="b"/></joint>
+    <joint name="hinge" type="revolute"><origin xyz="0 0.5 0" rpy="0 0 0"/><parent link="a"/><child link="c"/><axis xyz="0 1 0"/>
+    <limit lower="-1" upper="2" effort="5" velocity="3"/></joint></robot>"""
+    p = tmp_path / "toy.urdf"
+    p.write_text(urdf)
+    m = load_urdf(str(p))
+    assert m.body_names == ["a", "c"] and m.joint_axis.tolist() == [0, 2] and m.parent.tolist() == [-1, 0]
+    assert np.isclose(m.mass[0], 4.0) and np.allclose(m.com[0], [0.5, 0, 0])
+    # b's inertia rotated 90 deg about z (ixx<->iyy), both shifted 0.5 m along x: Iyy/Izz += m d^2
+    assert np.allclose(m.inertia[0][:3], [1 + 2, 1 + 1 + 2 * 2 * 0.25, 1 + 3 + 2 * 2 * 0.25])
+    assert m.dof_lower.tolist() == [-1.0] and m.dof_effort.tolist() == [5.0] and m.shapes[0]["type"] == "box"
+    m.save(str(tmp_path / "toy.json"))
+    m2 = FlatModel.load(str(tmp_path / "toy.json"))
+    assert m2.body_names == m.body_names and np.allclose(m2.inertia, m.inertia)
+    bad = urdf.replace('<axis xyz="0 1 0"/>', '<axis xyz="0.7 0.7 0"/>')
+    p.write_text(bad)
+    with pytest.raises(ValueError, match="axis"):
+        load_urdf(str(p))
+
+
+def test_experience_buffer_and_recorder(tmp_path):
+    from booster_gym_amd.utils.buffer import ExperienceBuffer
+    from booster_gym_amd.utils.recorder import Recorder
+
+    b = ExperienceBuffer(4, 3, "cpu")
+    b.add_buffer("obses", (5,), extra_rows=1); b.add_buffer("dones", (), dtype=torch.bool)
+    assert b["obses"].shape == (5, 3, 5) and b["dones"].dtype == torch.bool and len(b) == 2 and set(b.keys()) == {"obses", "dones"}
+    b.update_data("obses", 2, torch.ones(3, 5))
+    assert b["obses"][2].sum() == 15
+    rec = Recorder({"basic": {"task": "T1"}, "runner": {"use_wandb": False}}, root=str(tmp_path))
+    rec.record_statistics({"value_loss": 1.5, "lr": 1e-5}, 3)
+    path = rec.save({"model": {}, "optimizer": {}, "curriculum": torch.zeros(21, 21)}, 100)
+    assert path.endswith(os.path.join("nn", "model_100.pth")) and os.path.isfile(path)
+    assert os.path.isfile(os.path.join(rec.dir, "config.yaml"))
+    lines = open(os.path.join(rec.dir, "summaries", "scalars.jsonl")).read().strip().splitlines()
+    assert len(lines) == 2 and '"value_loss"' in lines[0]
+    assert set(torch.load(path, weights_only=True).keys()) == {"model", "optimizer", "curriculum"}
+
+
+def test_model_state_dict_keys_match_the_reference_layout():
+    from booster_gym_amd.utils.model import ActorCritic
+
+    m = ActorCritic(12, 47, 14)
+    keys = list(m.state_dict().keys())
+    assert keys == ["logstd"] + [f"critic.{i}.{w}" for i in (0, 2, 4, 6) for w in ("weight", "bias")] + [f"actor.{i}.{w}" for i in (0, 2, 4, 6) for w in ("weight", "bias")]
+    assert sum(p.numel() for p in m.parameters()) == 177945
+    assert m.act(torch.zeros(3, 47)).scale[0, 0].item() == pytest.approx(np.exp(-2.0))
+    assert m.est_value(torch.zeros(3, 47), torch.zeros(3, 14)).shape == (3,)
+    # the reference's exported actor (deploy/models/T1.pt) has exactly the actor's tensor shapes
+    W = np.load(os.path.join(HERE, "golden", "t1_actor.npz"))
+    for i in (0, 2, 4, 6):
+        assert tuple(W[f"{i}.weight"].shape) == tuple(m.actor[i].weight.shape)
+
+
+# ------------------------------------------------------------------ product headers compiled for the host vs the oracle
+@pytest.fixture(scope="module")
+def harness(tmp_path_factory):
+    d = tmp_path_factory.mktemp("hh")
+    libs = {}
+    for name in ("harness", "rng_harness"):
+        so = str(d / f"lib{name}.so")
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "host_harness", f"{name}.cpp")])
+        libs[name] = C.CDLL(so)
+    return libs
+
+
+def test_product_rng_header_matches_oracle_philox(harness):
+    from oracle.task_ref import rand4
+
+    hh = harness["rng_harness"]
+    hh.hh_rand4.argtypes = [C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p]
+    for seed, env, step, stream in [(42 | (1 << 32), 0, 0, 0), (7 | (3 << 32), 4095, 123456, 25), (0xFFFFFFFF, 0xFFFFFFFF, 99, 84)]:
+        u, n = np.zeros(4, np.float32), np.zeros(4, np.float32)
+        hh.hh_rand4(seed, env, step, stream, u.ctypes.data, n.ctypes.data)
+        ur, nr = rand4(seed, np.array([env], dtype=np.uint32), step, stream)
+        assert np.array_equal(u, ur[0]) and np.allclose(n, nr[0], atol=2e-6)
+
+
+def test_product_dynamics_header_matches_oracle(harness, flat_model):
+    """The per-lane fp32 articulated-body code of the HIP kernel (bg_dyn.h), compiled for the host, against the float64 oracle."""
+    from oracle.dyn_ref import DEFAULT_PHYS, DynRef
+
+    hh, m = harness["harness"], flat_model
+
+    class ModelDev(C.Structure):
+        _fields_ = [("pos", C.c_float * 3 * 13), ("mass", C.c_float * 13), ("com", C.c_float * 3 * 13), ("inertia", C.c_float * 6 * 13), ("q_lo", C.c_float * 12),
+                    ("q_hi", C.c_float * 12), ("qd_max", C.c_float * 12), ("tau_lim", C.c_float * 12), ("corner", C.c_float * 3 * 4)]
+
+    class Cfg(C.Structure):
+        _fields_ = [("dt", C.c_float), ("g", C.c_float * 3)] + [(k, C.c_float) for k in ("contact_k", "contact_d", "contact_ramp", "friction_visc", "limit_k", "limit_d",
+                                                                                      "terrain_mu", "terrain_restitution")] + [("clamp_qd", C.c_int)]
+
+    class Terr(C.Structure):
+        _fields_ = [("type", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("border_px", C.c_int), ("inv_hscale", C.c_float), ("vscale", C.c_float), ("hf", C.c_void_p)]
+
+    md = ModelDev()
+    for b in range(13):
+        md.mass[b] = m.mass[b]
+        for a in range(3):
+            md.pos[b][a], md.com[b][a] = m.body_pos[b, a], m.com[b, a]
+        for a in range(6):
+            md.inertia[b][a] = m.inertia[b, a]
+    for j in range(12):
+        md.q_lo[j], md.q_hi[j], md.qd_max[j], md.tau_lim[j] = m.dof_lower[j], m.dof_upper[j], m.dof_velocity[j], m.dof_effort[j]
+    corners = [[0.1215, 0.05, -0.03], [0.1215, -0.05, -0.03], [-0.1015, 0.05, -0.03], [-0.1015, -0.05, -0.03]]
+    for k in range(4):
+        for a in range(3):
+            md.corner[k][a] = corners[k][a]
+    cfg = Cfg(); cfg.dt = DEFAULT_PHYS["dt"]; cfg.clamp_qd = 1
+    for a in range(3):
+        cfg.g[a] = DEFAULT_PHYS["g"][a]
+    for k in ("contact_k", "contact_d", "contact_ramp", "friction_visc", "limit_k", "limit_d", "terrain_mu", "terrain_restitution"):
+        setattr(cfg, k, DEFAULT_PHYS[k])
+    rng = np.random.default_rng(1)
+    hf = rng.integers(-10, 10, size=(60, 60)).astype(np.int16)
+    for terrain, contact, tol in ((None, False, 2e-5), (None, True, 5e-4), (dict(height_field_raw=hf, hscale=0.1, vscale=0.005, border_px=30), True, 5e-4)):
+        d = DynRef(m, terrain=terrain)
+        t = Terr()
+        if terrain is not None:
+            t.type, t.rows, t.cols, t.border_px, t.inv_hscale, t.vscale, t.hf = 1, 60, 60, 30, 10.0, 0.005, hf.ctypes.data
+        worst, ncontact = 0.0, 0
+        for _ in range(150):
+            root = np.zeros(13); root[2] = rng.uniform(0.55, 0.72) if contact else 5.0
+            root[:2] = rng.uniform(-1, 1, 2)
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 0.3)
+            root[3:6], root[6] = ax * np.sin(ang / 2), np.cos(ang / 2)
+            root[7:13] = rng.normal(size=6) * (0.3 if contact else 1.0)
+            q = (np.array([-0.2, 0, 0, 0.4, -0.25, 0] * 2) + rng.normal(size=12) * 0.1) if contact else rng.uniform(m.dof_lower - 0.05, m.dof_upper + 0.05)
+            qd, tau, w = rng.normal(size=12), rng.uniform(-m.dof_effort, m.dof_effort), rng.normal(size=6) * 10
+            ms, co = rng.uniform(0.8, 1.2, 13), rng.uniform(-0.05, 0.05, (13, 3))
+            fm = np.array([rng.uniform(0.1, 2), rng.uniform(0.5, 1.5), rng.uniform(0.1, 0.9)] * 2)
+            f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
+            arrs = [f32(ms), f32(co.reshape(39)), f32(fm), f32(root), f32(q), f32(qd), f32(tau), f32(w)]
+            qa, cf32 = np.zeros(18, np.float32), np.zeros(6, np.float32)
+            p = lambda a: a.ctypes.data_as(C.c_void_p)
+            hh.hh_forward(C.byref(md), C.byref(cfg), C.byref(t), *[p(a) for a in arrs], p(qa), p(cf32), 0)
+            qacc, cf = d.forward(arrs[3], arrs[4], arrs[5], arrs[6], base_wrench=arrs[7], mass_scale=arrs[0], com_off=arrs[1].reshape(13, 3), foot_mat=arrs[2])
+            worst = max(worst, np.abs(qa - qacc).max() / max(1.0, np.abs(qacc).max()))
+            ncontact += int(np.abs(cf).max() > 0)
+        assert worst < tol, (terrain is not None, contact, worst)
+        assert (ncontact > 50) == contact
+
+
+# ------------------------------------------------------------------ data parallel under gloo, world_size 2
+def _dp_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BG_DIST_BACKEND="gloo")
+    sys.path.insert(0, ROOT)
+    import torch.nn.functional as F
+
+    from booster_gym_amd.utils.model import ActorCritic
+    from booster_gym_amd.utils.parallel import DataParallel
+    from oracle.ppo_ref import discount_values, surrogate_loss
+
+    torch.set_num_threads(1)
+    dp = DataParallel()
+    d = np.load(os.path.join(HERE, "golden", "ppo_epoch.npz"))
+    model = ActorCritic(12, 47, 14)
+    if rank == 0:
+        model.load_state_dict({k[3:]: torch.tensor(d[k]) for k in d.files if k.startswith("sd_")})
+    dp.broadcast_parameters(model)  # rank 1 starts from different random weights: the broadcast must fix that
+    N = d["obses"].shape[1]
+    sl = slice(rank * N // world, (rank + 1) * N // world)  # shard the ENVIRONMENTS
+    t = lambda k: torch.tensor(d[k])
+    obs, priv, act = t("obses")[:, sl], t("priv")[:, sl], t("actions")[:, sl]
+    rew, dones, touts = t("rewards")[:, sl].clone(), t("dones")[:, sl], t("time_outs")[:, sl]
+    vals = model.est_value(obs, priv)
+    lastv = model.est_value(t("last_obs")[sl], t("last_priv")[sl])
+    with torch.no_grad():
+        rew[touts] = vals[touts]
+        adv = discount_values(rew, dones | touts, vals, lastv, 0.995, 0.95)
+        ret = vals + adv
+        sums = torch.tensor([adv.double().sum(), adv.double().square().sum(), float(adv.numel())], dtype=torch.float64)
+        dp.sum_(sums)  # exchange (1): global advantage moments
+        mean = sums[0] / sums[2]
+        std = torch.sqrt((sums[1] - sums[2] * mean * mean) / (sums[2] - 1.0))
+        advn = ((adv.double() - mean) / (std + 1e-8)).float()
+    dist = model.act(obs)
+    logp = dist.log_prob(act).sum(-1)
+    loss = F.mse_loss(vals, ret) + surrogate_loss(t("old_logp")[:, sl], logp, advn)
+    loss = loss + torch.clip(dist.loc - 1.0, min=0.0).square().mean() + torch.clip(dist.loc + 1.0, max=0.0).square().mean() - 0.01 * dist.entropy().sum(-1).mean()
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in model.parameters()])
+    dp.average_(flat)  # exchange (2): one flat gradient bucket
+    kl = torch.sum(torch.log(dist.scale / torch.exp(t("old_logstd"))) + 0.5 * (torch.exp(t("old_logstd")) ** 2 + (dist.loc - t("old_mu")[:, sl]) ** 2) / dist.scale**2 - 0.5, -1)
+    klsum = torch.tensor([kl.double().sum().item(), float(kl.numel())], dtype=torch.float64)
+    dp.sum_(klsum)  # exchange (3): KL for the learning-rate rule
+    ref = torch.cat([t("grad_" + k).reshape(-1) for k, _ in model.named_parameters()])
+    q.put((rank, float((flat - ref).abs().max()), float(ref.abs().max()), float(klsum[0] / klsum[1]), float(d["losses"][4]), flat.numel()))
+    dp.shutdown()
+
+
+def test_data_parallel_update_equals_single_process_full_batch():
+    """Two gloo ranks, each with half of the environments of the reference-generated fixture, reproduce the fixture's FULL-BATCH
+    parameter gradients and KL after the three all-reduces (advantage moments, flat gradient, KL sum)."""
+    import torch.multiprocessing as mp
+
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 1000)
+    procs = [ctx.Process(target=_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, err, scale, kl, kl_ref, n in res:
+        assert n == 177945
+        assert err < 2e-4 * scale + 2e-6, (rank, err, scale)
+        assert abs(kl - kl_ref) < 1e-3 * abs(kl_ref)
