@@ -258,6 +258,36 @@ __global__ void adapt_lr_kernel(const double* __restrict__ kl_sum, float count, 
     *lr = l;
 }
 
+
+// ------------------------------------------------------------------ MLP backward helper: g <- g * elu'(a) in place and db = column sums of g
+// (replaces torch's elu_backward + the separate bias-gradient reduction: the gradient tile is read once).  elu'(z) expressed through the
+// OUTPUT a = elu(z): 1 if a > 0 else a + 1.  Deterministic two-stage column sum (no float atomics).
+constexpr int CS_ROWS = 128;
+__global__ __launch_bounds__(256) void elu_bwd_colsum_kernel(int B, int C, float* __restrict__ g, const float* __restrict__ act,
+                                                             float* __restrict__ partial /*[gridDim.x][C]*/) {
+    const int r0 = blockIdx.x * CS_ROWS, r1 = min(B, r0 + CS_ROWS);
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int r = r0; r < r1; r++) {
+            const size_t k = (size_t)r * C + c;
+            float v = g[k];
+            if (act) { const float a = act[k]; v *= a > 0.f ? 1.0f : a + 1.0f; g[k] = v; }
+            acc += v;
+        }
+        partial[(size_t)blockIdx.x * C + c] = acc;
+    }
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(int nb, int C, const float* __restrict__ partial, float* __restrict__ out) {
+    __shared__ float sm[256];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) acc += partial[(size_t)b * C + c];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[c] = sm[0];
+}
+
 // ------------------------------------------------------------------ ABI
 extern "C" int bg_gae(int32_t T, int32_t N, float* rewards, const uint8_t* dones, const uint8_t* time_outs, const float* values,
                       const float* last_values, float gamma, float lam, float* advantages, float* returns, double* sums, void* stream) {
@@ -320,6 +350,15 @@ extern "C" int bg_adam_step(int32_t n, float* params, const float* grads, float*
 extern "C" int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_min, float lr_max, float* lr_device, void* stream) {
     if (!kl_sum || !lr_device || !(count > 0.f)) return bg_set_error(-1, "bg_adapt_lr: bad argument");
     hipLaunchKernelGGL(adapt_lr_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, kl_sum, count, desired_kl, lr_min, lr_max, lr_device);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_elu_backward_colsum(int32_t B, int32_t C, float* grad, const float* act, float* colsum, float* scratch, void* stream) {
+    if (B <= 0 || C <= 0 || !grad || !colsum || !scratch) return bg_set_error(-1, "bg_elu_backward_colsum: bad argument");
+    const int nb = (B + CS_ROWS - 1) / CS_ROWS;
+    hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3(nb), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0, (hipStream_t)stream, B, C, grad, act, scratch);
+    hipLaunchKernelGGL(colsum_finish_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, nb, C, scratch, colsum);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -7,8 +7,9 @@ Same surface: `Runner(test=False)` parses the reference's 8 CLI flags (runner.py
   rollout   per env-step: ONE fused actor+sample launch (bg_actor_sample) and ONE env launch (bg_env_step_to) that
             writes obs / privileged obs / reward / done / time-out directly into rows of the experience buffer;
             no `.to(device)` copies, no per-done-env `.item()` (runner.py:112-121).
-  update    per mini-epoch: critic + actor GEMMs through PyTorch-ROCm (fp32 MFMA), GAE as one backward scan (bg_gae),
-            the whole loss forward+backward as one pass (bg_ppo_loss) feeding autograd for the two MLPs, global-norm clip +
+  update    per mini-epoch: critic + actor GEMMs through PyTorch-ROCm (fp32 MFMA) on a hand-scheduled forward/backward
+            (model.MLPTrainer: split-K weight gradients, fused ELU-backward + bias gradient), GAE as one backward scan (bg_gae),
+            the whole loss forward+backward as one pass (bg_ppo_loss), global-norm clip +
             Adam on one flat buffer (bg_adam_step) and the KL-adaptive learning rate on the device (bg_adapt_lr): no host
             sync inside the 20 mini-epochs (reference: 4 per mini-epoch, runner.py:175,182-184).
   multi-GPU one process per GPU (torchrun), environments sharded, three all-reduces per mini-epoch on RCCL: advantage
@@ -30,7 +31,7 @@ from .. import _lib
 from ..envs import TASKS
 from .buffer import ExperienceBuffer
 from .config import load_cfg
-from .model import ActorCritic
+from .model import ActorCritic, MLPTrainer
 from .parallel import DataParallel
 from .recorder import Recorder
 from .utils import gae, gaussian_logp, ppo_loss_fused
@@ -144,6 +145,7 @@ class Runner:
         self._stats_acc = torch.zeros(5, dtype=torch.float64, device=dev)
         self._old_logp = torch.zeros(B, device=dev)
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
+        self._actor_tr, self._critic_tr = MLPTrainer(self.model.actor), MLPTrainer(self.model.critic)
         self._act_counter = 0
         self.timers = {"rollout": 0.0, "update": 0.0}
 
@@ -233,26 +235,25 @@ class Runner:
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
             gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
         self._stats_acc.zero_()
-        for _ in range(cfg["runner"]["mini_epochs"]):
-            values = self.model.critic(critic_in).squeeze(-1)
-            with torch.no_grad():
+        with torch.no_grad():
+            for _ in range(cfg["runner"]["mini_epochs"]):
+                values = self._critic_tr.forward(critic_in).squeeze(-1)
                 last_values = self.model.critic(critic_last).squeeze(-1)
-                gae(buf["rewards"], buf["dones"], buf["time_outs"], values.detach().view(T, N), last_values, alg["gamma"], alg["lam"],
+                gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
                     advantages=self._adv, returns=self._ret, sums=self._adv_sums)
                 self.dp.sum_(self._adv_sums)
-            mu = self.model.actor(obs_flat)
-            with torch.no_grad():
-                ppo_loss_fused(mu.detach(), self.model.logstd.detach().reshape(-1), act_flat, old_mu, old_logstd, self._old_logp,
-                               self._adv.view(B), self._adv_sums, values.detach(), self._ret.view(B), 0.2, alg["bound_coef"],
-                               alg["entropy_coef"], self._grad_mu, self._grad_val, self._grad_logstd, self._stats)
-            self.optimizer.zero_grad()
-            torch.autograd.backward([mu, values], [self._grad_mu, self._grad_val])
-            self._logstd_grad_view.copy_(self._grad_logstd)
-            self.dp.average_(self.optimizer.grad)
-            self.dp.sum_(self._stats)
-            self.optimizer.step()
-            self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
-            self._stats_acc += self._stats
+                mu = self._actor_tr.forward(obs_flat)
+                ppo_loss_fused(mu, self.model.logstd.reshape(-1), act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
+                               values, self._ret.view(B), 0.2, alg["bound_coef"], alg["entropy_coef"], self._grad_mu, self._grad_val,
+                               self._grad_logstd, self._stats)
+                self._actor_tr.backward(self._grad_mu)
+                self._critic_tr.backward(self._grad_val.view(B, 1))
+                self._logstd_grad_view.copy_(self._grad_logstd)
+                self.dp.average_(self.optimizer.grad)
+                self.dp.sum_(self._stats)
+                self.optimizer.step()
+                self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
+                self._stats_acc += self._stats
         return self._stats_acc
 
     def iteration(self):

@@ -171,6 +171,11 @@ int bg_adam_step(int32_t n, float* params, const float* grads, float* exp_avg, f
 /* KL-adaptive learning rate on the device (runner.py:174-180): kl_sum [1] float64 (= stats[4] of bg_ppo_loss), count = samples -> lr_device [1] updated in place */
 int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_min, float lr_max, float* lr_device, void* stream);
 
+/* MLP backward helper for the ELU layers of utils/model.py:9-26: grad [B][C] <- grad * elu'(.) in place, expressed through the layer OUTPUT
+ * act [B][C] (1 if act > 0 else act + 1; act == NULL: identity), and colsum [C] = column sums of the result (= bias gradient).
+ * scratch: ceil(B/128) * C floats.  Deterministic (no atomics). */
+int bg_elu_backward_colsum(int32_t B, int32_t C, float* grad, const float* act, float* colsum, float* scratch, void* stream);
+
 const char* bg_last_error(void);
 const char* bg_version(void);
 
