@@ -263,6 +263,7 @@ __global__ void adapt_lr_kernel(const double* __restrict__ kl_sum, float count, 
 // (replaces torch's elu_backward + the separate bias-gradient reduction: the gradient tile is read once).  elu'(z) expressed through the
 // OUTPUT a = elu(z): 1 if a > 0 else a + 1.  Deterministic two-stage column sum (no float atomics).
 constexpr int CS_ROWS = 128;
+// generic (any C): one thread per column, used for the narrow output layers (C = 12, 1)
 __global__ __launch_bounds__(256) void elu_bwd_colsum_kernel(int B, int C, float* __restrict__ g, const float* __restrict__ act,
                                                              float* __restrict__ partial /*[gridDim.x][C]*/) {
     const int r0 = blockIdx.x * CS_ROWS, r1 = min(B, r0 + CS_ROWS);
@@ -275,6 +276,55 @@ __global__ __launch_bounds__(256) void elu_bwd_colsum_kernel(int B, int C, float
             acc += v;
         }
         partial[(size_t)blockIdx.x * C + c] = acc;
+    }
+}
+// C % 4 == 0 and C <= 256: 16-byte accesses, 1 KiB per wave instruction, 4 independent rows in flight per thread.
+// thread = (row lane, column group of 4); a 256-thread block covers CS_ROWS rows.
+__global__ __launch_bounds__(256) void elu_bwd_colsum_vec4_kernel(int B, int C, float* __restrict__ g, const float* __restrict__ act,
+                                                                  float* __restrict__ partial) {
+    __shared__ float4 sm[256];
+    const int groups = C >> 2;                 // column groups per row (<= 64)
+    const int lanes = 256 / groups;            // rows processed concurrently by the block
+    const int cg = threadIdx.x % groups, rl = threadIdx.x / groups;
+    const int r0 = blockIdx.x * CS_ROWS, r1 = min(B, r0 + CS_ROWS);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rl < lanes) {
+        int r = r0 + rl;
+        for (; r + 3 * lanes < r1; r += 4 * lanes) {
+            float4 gv[4], av[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const size_t k = ((size_t)(r + u * lanes) * C) / 4 + cg;
+                gv[u] = reinterpret_cast<const float4*>(g)[k];
+                av[u] = reinterpret_cast<const float4*>(act)[k];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const size_t k = ((size_t)(r + u * lanes) * C) / 4 + cg;
+                gv[u].x *= av[u].x > 0.f ? 1.0f : av[u].x + 1.0f; gv[u].y *= av[u].y > 0.f ? 1.0f : av[u].y + 1.0f;
+                gv[u].z *= av[u].z > 0.f ? 1.0f : av[u].z + 1.0f; gv[u].w *= av[u].w > 0.f ? 1.0f : av[u].w + 1.0f;
+                reinterpret_cast<float4*>(g)[k] = gv[u];
+                acc.x += gv[u].x; acc.y += gv[u].y; acc.z += gv[u].z; acc.w += gv[u].w;
+            }
+        }
+        for (; r < r1; r += lanes) {
+            const size_t k = ((size_t)r * C) / 4 + cg;
+            float4 gv = reinterpret_cast<const float4*>(g)[k];
+            const float4 av = reinterpret_cast<const float4*>(act)[k];
+            gv.x *= av.x > 0.f ? 1.0f : av.x + 1.0f; gv.y *= av.y > 0.f ? 1.0f : av.y + 1.0f;
+            gv.z *= av.z > 0.f ? 1.0f : av.z + 1.0f; gv.w *= av.w > 0.f ? 1.0f : av.w + 1.0f;
+            reinterpret_cast<float4*>(g)[k] = gv;
+            acc.x += gv.x; acc.y += gv.y; acc.z += gv.z; acc.w += gv.w;
+        }
+    }
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    if (rl == 0) {
+        for (int l = 1; l < lanes; l++) {
+            const float4 o = sm[l * groups + cg];
+            acc.x += o.x; acc.y += o.y; acc.z += o.z; acc.w += o.w;
+        }
+        reinterpret_cast<float4*>(partial + (size_t)blockIdx.x * C)[cg] = acc;
     }
 }
 __global__ __launch_bounds__(256) void colsum_finish_kernel(int nb, int C, const float* __restrict__ partial, float* __restrict__ out) {
@@ -357,7 +407,10 @@ extern "C" int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, 
 extern "C" int bg_elu_backward_colsum(int32_t B, int32_t C, float* grad, const float* act, float* colsum, float* scratch, void* stream) {
     if (B <= 0 || C <= 0 || !grad || !colsum || !scratch) return bg_set_error(-1, "bg_elu_backward_colsum: bad argument");
     const int nb = (B + CS_ROWS - 1) / CS_ROWS;
-    hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3(nb), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0, (hipStream_t)stream, B, C, grad, act, scratch);
+    if (act && C % 4 == 0 && C <= 256 && 256 % (C / 4) == 0)
+        hipLaunchKernelGGL(elu_bwd_colsum_vec4_kernel, dim3(nb), dim3(256), 0, (hipStream_t)stream, B, C, grad, act, scratch);
+    else
+        hipLaunchKernelGGL(elu_bwd_colsum_kernel, dim3(nb), dim3(C >= 256 ? 256 : (C >= 128 ? 128 : 64)), 0, (hipStream_t)stream, B, C, grad, act, scratch);
     hipLaunchKernelGGL(colsum_finish_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, nb, C, scratch, colsum);
     HIP_OK(hipGetLastError());
     return 0;

@@ -175,3 +175,21 @@ def test_full_update_matches_reference_loop():
     for k in ("value_loss", "actor_loss", "bound_loss", "entropy", "kl_mean"):
         assert abs(summ[k] - stats_ref[k]) <= 2e-4 * max(1.0, abs(stats_ref[k])), (k, summ[k], stats_ref[k])
     assert abs(summ["lr"] - lr_ref) < 1e-9
+
+
+@pytest.mark.parametrize("B,C,with_act", [(98304, 256, True), (98304, 128, True), (3000, 256, True), (1000, 128, True), (777, 12, False), (98304, 1, False),
+                                          (130, 20, True)])
+def test_elu_backward_colsum_matches_torch(B, C, with_act):
+    from booster_gym_amd import _lib
+
+    torch.manual_seed(B + C)
+    z = torch.randn(B, C, device=DEV)
+    act = torch.nn.functional.elu(z)
+    g = torch.randn(B, C, device=DEV)
+    exp = g * torch.where(z > 0, torch.ones_like(z), act + 1.0) if with_act else g.clone()
+    got, col = g.clone(), torch.zeros(C, device=DEV)
+    scratch = torch.empty(((B + 127) // 128) * C, device=DEV)
+    _lib.check(_lib.load().bg_elu_backward_colsum(B, C, _lib.ptr(got), _lib.ptr(act) if with_act else None, _lib.ptr(col), _lib.ptr(scratch),
+                                                  _lib.current_stream_ptr()))
+    assert torch.allclose(got, exp, atol=1e-6)
+    assert torch.allclose(col, exp.double().sum(0).float(), rtol=1e-4, atol=1e-3)
