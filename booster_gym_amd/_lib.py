@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libbooster_gym_amd.so")
+LIB_PATH = os.environ.get("BG_LIB") or os.path.join(_HERE, "libbooster_gym_amd.so")  # BG_LIB: alternative build (kernel experiments)
 
 NUM_BODIES, NUM_DOFS, NUM_OBS, NUM_PRIV, NUM_REWARD_TERMS = 13, 12, 47, 14, 26
 

@@ -175,14 +175,14 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
         terrain_query(tr, xw.e[0], xw.e[1], &h, &n);
         float pen = (h - xw.e[2]) * n.e[2];
         float vn = dot(vw, n);
-        float ramp = pen < ph.contact_ramp ? pen / ph.contact_ramp : 1.0f;
+        float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
         float d_eff = lp.dn * ramp;
         float fn0 = lp.kn * pen - d_eff * vn;
         if (pen > 0.f && fn0 > 0.f) {
             any = true;
             V3 vt = vw - vn * n;
-            float vtn = sqrtf(dot(vt, vt));
-            float c_t = fminf(ph.friction_visc, lp.mu * fn0 / (vtn + 1e-6f));
+            float vtn = bg_sqrt(dot(vt, vt));
+            float c_t = fminf(ph.friction_visc, lp.mu * fn0 * bg_rcp(vtn + 1e-6f));
             V3 fw = fn0 * n - c_t * vt;
             fw_sum = fw_sum + fw;
             V3 nb = mulT(w.Rfoot, n), fb = mulT(w.Rfoot, fw);
@@ -219,7 +219,7 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
     U.a = v3(Af.e[0][A], Af.e[1][A], Af.e[2][A]);
     U.l = v3(IA.H.e[A][0], IA.H.e[A][1], IA.H.e[A][2]);
     float d = U.a.e[A] + bl;
-    float dinv = 1.0f / d;
+    float dinv = bg_rcp(d);
     float u = tau[I] + t0 - pA.a.e[A];
     w.U[I] = U; w.dinv[I] = dinv; w.u[I] = u;
     // Ia = IA - U U^T / d ;  pa = pA + Ia c + U u / d
@@ -330,10 +330,10 @@ BG_HD void integrate_base(const Phys& ph, BaseState& bs, V3 lin_w, V3 ang_w) {
     float w2 = dot(wv, wv);
     float dqx = 0.f, dqy = 0.f, dqz = 0.f, dqw = 1.f;
     if (w2 > 1e-24f) {
-        float wn = sqrtf(w2);
+        float wn = bg_sqrt(w2);
         float sh, ch;
         bg_sincos(0.5f * wn * ph.dt, &sh, &ch);
-        float k = sh / wn;
+        float k = sh * bg_rcp(wn);
         dqx = wv.e[0] * k; dqy = wv.e[1] * k; dqz = wv.e[2] * k; dqw = ch;
     }
     float x = bs.quat[0], y = bs.quat[1], z = bs.quat[2], w = bs.quat[3];
@@ -411,7 +411,7 @@ BG_HD void load_leg_params(const ModelDev& m, const ContactCfg& cc, int leg, int
     for (int k = 0; k < 4; k++) lp.corner[k] = v3(m.corner[k][0], m.corner[k][1], m.corner[k][2]);
     float mu_f = foot_mat[(size_t)(3 * leg) * n + e], compl_f = foot_mat[(size_t)(3 * leg + 1) * n + e], rest_f = foot_mat[(size_t)(3 * leg + 2) * n + e];
     lp.mu = 0.5f * (mu_f + cc.terrain_mu);  // PhysX default material combine: average
-    lp.kn = cc.k / compl_f;
+    lp.kn = cc.k * bg_rcp(compl_f);
     lp.dn = cc.d * (1.0f - 0.5f * (rest_f + cc.terrain_restitution));
 }
 BG_HD LinkConst load_base_link(const ModelDev& m, int e, int n, const float* mass_scale, const float* com_off) {

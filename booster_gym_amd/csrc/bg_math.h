@@ -20,6 +20,21 @@ struct S3 { float e[6]; };  // symmetric: xx yy zz xy xz yz
 struct SV { V3 a, l; };     // spatial vector: angular, linear (motion: w,v  force: n,f)
 struct SI { S3 A; M3 H; S3 M; };  // spatial inertia [A H; H^T M]
 
+// reciprocal / square root: the hardware approximations (1 ulp) on the GPU instead of the ~10-instruction IEEE division expansion
+BG_HD float bg_rcp(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_rcpf(x);
+#else
+    return 1.0f / x;
+#endif
+}
+BG_HD float bg_sqrt(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_sqrtf(x);
+#else
+    return sqrtf(x);
+#endif
+}
 BG_HD V3 v3(float x, float y, float z) { V3 r; r.e[0] = x; r.e[1] = y; r.e[2] = z; return r; }
 BG_HD V3 operator+(V3 a, V3 b) { return v3(a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2]); }
 BG_HD V3 operator-(V3 a, V3 b) { return v3(a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2]); }
@@ -103,7 +118,7 @@ BG_HD S3 inv_sym(S3 s) {
     float a = s.e[0], b = s.e[1], c = s.e[2], d = s.e[3], e = s.e[4], f = s.e[5];
     float c00 = b * c - f * f, c01 = e * f - d * c, c02 = d * f - b * e;
     float c11 = a * c - e * e, c12 = d * e - a * f, c22 = a * b - d * d;
-    float idet = 1.0f / (a * c00 + d * c01 + e * c02);
+    float idet = bg_rcp(a * c00 + d * c01 + e * c02);
     S3 r;
     r.e[0] = c00 * idet; r.e[1] = c11 * idet; r.e[2] = c22 * idet; r.e[3] = c01 * idet; r.e[4] = c02 * idet; r.e[5] = c12 * idet;
     return r;
@@ -157,7 +172,7 @@ BG_HD void bg_sincos(float x, float* s, float* c) {
 }
 BG_HD float bg_rsqrt(float x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __frsqrt_rn(x);
+    return __builtin_amdgcn_rsqf(x);
 #else
     return 1.0f / sqrtf(x);
 #endif
