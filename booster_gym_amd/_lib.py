@@ -54,6 +54,9 @@ class EnvCfg(C.Structure):
         ("kick_interval", C.c_int32), ("push_interval", C.c_int32), ("push_duration", C.c_int32), ("shared_reset_noise", C.c_int32),
         ("cmd_lin_vel_x", C.c_float * 2), ("cmd_lin_vel_y", C.c_float * 2), ("cmd_ang_vel_yaw", C.c_float * 2),
         ("cmd_gait_frequency", C.c_float * 2), ("still_proportion", C.c_float), ("resample_steps", C.c_int32 * 2),
+        ("curriculum", C.c_int32), ("lin_vel_levels", C.c_int32), ("ang_vel_levels", C.c_int32),
+        ("curriculum_update_rate", C.c_float), ("lin_vel_x_resolution", C.c_float), ("lin_vel_y_resolution", C.c_float), ("ang_vel_resolution", C.c_float),
+        ("episode_length_toler", C.c_float), ("lin_vel_x_toler", C.c_float), ("lin_vel_y_toler", C.c_float), ("ang_vel_yaw_toler", C.c_float),
         ("reward_scale", C.c_float * NUM_REWARD_TERMS), ("only_positive_rewards", C.c_int32),
         ("tracking_sigma", C.c_float), ("base_height_target", C.c_float), ("soft_dof_pos_limit", C.c_float),
         ("soft_dof_vel_limit", C.c_float), ("soft_torque_limit", C.c_float), ("swing_period", C.c_float), ("feet_distance_ref", C.c_float),
@@ -66,7 +69,7 @@ class EnvCfg(C.Structure):
 SYMBOLS = [
     "bg_model_create", "bg_model_get", "bg_model_destroy", "bg_env_create", "bg_env_destroy", "bg_env_set_heightfield",
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
-    "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_step_count", "bg_env_set_step_count",
+    "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
     "bg_env_forward_dynamics", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_elu_backward_colsum",
     "bg_last_error", "bg_version",
 ]
@@ -103,6 +106,8 @@ def load():
         "bg_env_get_field": (i32, [vp, C.c_char_p, vp, vp]),
         "bg_env_set_field": (i32, [vp, C.c_char_p, vp, vp]),
         "bg_env_field_info": (i32, [vp, C.c_char_p, C.POINTER(i32), C.POINTER(i32)]),
+        "bg_env_get_curriculum": (i32, [vp, vp, vp]),
+        "bg_env_set_curriculum": (i32, [vp, vp, vp]),
         "bg_env_step_count": (i64, [vp]),
         "bg_env_set_step_count": (i32, [vp, i64]),
         "bg_env_forward_dynamics": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),

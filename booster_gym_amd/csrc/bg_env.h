@@ -50,7 +50,7 @@ enum {
     F_EP_SUMS = 254,       // 27
     F_COUNT = 281
 };
-enum { I_EP_LEN = 0, I_CMD_TIME = 1, I_DELAY = 2, I_EP_STEPS = 3, I_COUNT = 4 };
+enum { I_EP_LEN = 0, I_CMD_TIME = 1, I_DELAY = 2, I_EP_STEPS = 3, I_CURR_LIN = 4, I_CURR_ANG = 5, I_COUNT = 6 };
 // global statistics accumulator: [0] finished episodes, [1] sum of their lengths, [2] sum reward, [3..28] sum of terms, [29] non-finite resets
 constexpr int STATS_COUNT = 4 + BG_NUM_REWARD_TERMS;  // last entry: resets caused by a non-finite state
 
@@ -58,6 +58,8 @@ struct EnvDev {
     float* f;
     int32_t* i;
     float* stats;  // [STATS_COUNT], atomics
+    float* curr;   // curriculum_prob running sums [(2L+1)*(2A+1)], atomics
+    const float* curr_read;  // snapshot taken before this launch: what the samplers read (deterministic)
     const ModelDev* model;
     TerrainDev terrain;
     bg_env_cfg cfg;
@@ -356,6 +358,28 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
 
     // ------------------------------------------------------------ reset (t1.py:301-341)
     V3 pf_store = pf;
+    // ------------------------------------------------------------ command curriculum update (t1.py:391-413), pre-reset values
+    if (reset_flag && mode == 0 && C.curriculum && leg == 0 && valid && bad == 0.f) {
+        const int nx = 2 * C.lin_vel_levels + 1, ny = 2 * C.ang_vel_levels + 1;
+        bool success = (float)ep_len > ceilf((float)C.max_episode_length) * (1.0f - C.episode_length_toler);
+        success = success && fabsf(filt_lin.e[0] - cmd[0]) < C.lin_vel_x_toler && fabsf(filt_lin.e[1] - cmd[1]) < C.lin_vel_y_toler &&
+                  fabsf(filt_ang.e[2] - cmd[2]) < C.ang_vel_yaw_toler;
+        if (success) {
+            const int cx = II[(size_t)I_CURR_LIN * n + e] + C.lin_vel_levels, cy = II[(size_t)I_CURR_ANG * n + e] + C.ang_vel_levels;
+            const float r = C.curriculum_update_rate;
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BG_ACC(ix, iy) atomicAdd(&E.curr[(ix) * ny + (iy)], r)
+#else
+#define BG_ACC(ix, iy) (E.curr[(ix) * ny + (iy)] += r)
+#endif
+            BG_ACC(cx, cy);
+            if (cx > 0) BG_ACC(cx - 1, cy);
+            if (cx < nx - 1) BG_ACC(cx + 1, cy);
+            if (cy > 0) BG_ACC(cx, cy - 1);
+            if (cy < ny - 1) BG_ACC(cx, cy + 1);
+#undef BG_ACC
+        }
+    }
     if (reset_flag) {
         uint32_t noise_env = C.shared_reset_noise ? 0xFFFFFFFFu : (uint32_t)e;
         Rand4 d0 = rand4(C.seed, noise_env, step, so + RS_RESETDOF + leg * 2), d1 = rand4(C.seed, noise_env, step, so + RS_RESETDOF + leg * 2 + 1);
@@ -393,9 +417,29 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
     // ------------------------------------------------------------ command resample (t1.py:362-389)
     if (ep_len == cmd_time) {
         Rand4 c0 = rand4(C.seed, (uint32_t)e, step, so + RS_CMD0), c1 = rand4(C.seed, (uint32_t)e, step, so + RS_CMD1);
-        cmd[0] = C.cmd_lin_vel_x[0] + (C.cmd_lin_vel_x[1] - C.cmd_lin_vel_x[0]) * c0.u[0];
-        cmd[1] = C.cmd_lin_vel_y[0] + (C.cmd_lin_vel_y[1] - C.cmd_lin_vel_y[0]) * c0.u[1];
-        cmd[2] = C.cmd_ang_vel_yaw[0] + (C.cmd_ang_vel_yaw[1] - C.cmd_ang_vel_yaw[0]) * c0.u[2];
+        if (C.curriculum) {
+            // t1.py:415-435: draw a grid cell ~ multinomial(curriculum_prob as of the start of this step), then jitter inside the cell.  The reference decodes
+            // lin = idx % cols - L and ang = idx // cols - A although it updates prob[lin + L][ang + A] (a transposition); kept.
+            Rand4 cr = rand4(C.seed, (uint32_t)e, step, so + RS_CURR);
+            const int ny = 2 * C.ang_vel_levels + 1, cells = (2 * C.lin_vel_levels + 1) * ny;
+            float total = 0.f;
+            for (int k = 0; k < cells; k++) total += fminf(E.curr_read[k], 1.0f);
+            float target = cr.u[0] * total, run = 0.f;
+            int idx = cells - 1;
+            for (int k = 0; k < cells; k++) {
+                run += fminf(E.curr_read[k], 1.0f);
+                if (run > target) { idx = k; break; }
+            }
+            const int lin_level = idx % ny - C.lin_vel_levels, ang_level = idx / ny - C.ang_vel_levels;
+            if (leg == 0 && valid) { II[(size_t)I_CURR_LIN * n + e] = lin_level; II[(size_t)I_CURR_ANG * n + e] = ang_level; }
+            cmd[0] = ((float)lin_level + (cr.u[1] - 0.5f)) * C.lin_vel_x_resolution;
+            cmd[1] = fabsf((float)lin_level) * (2.0f * cr.u[2] - 1.0f) * C.lin_vel_y_resolution;
+            cmd[2] = ((float)ang_level + (cr.u[3] - 0.5f)) * C.ang_vel_resolution;
+        } else {
+            cmd[0] = C.cmd_lin_vel_x[0] + (C.cmd_lin_vel_x[1] - C.cmd_lin_vel_x[0]) * c0.u[0];
+            cmd[1] = C.cmd_lin_vel_y[0] + (C.cmd_lin_vel_y[1] - C.cmd_lin_vel_y[0]) * c0.u[1];
+            cmd[2] = C.cmd_ang_vel_yaw[0] + (C.cmd_ang_vel_yaw[1] - C.cmd_ang_vel_yaw[0]) * c0.u[2];
+        }
         gait_f = C.cmd_gait_frequency[0] + (C.cmd_gait_frequency[1] - C.cmd_gait_frequency[0]) * c0.u[3];
         if (c1.u[0] < C.still_proportion) { cmd[0] = cmd[1] = cmd[2] = 0.f; gait_f = 0.f; }  // per-env Bernoulli (reference: exact count via randperm)
         int span = C.resample_steps[1] - C.resample_steps[0];

@@ -55,6 +55,7 @@ enum {
     RS_RESETDOF = 20, // + leg*2 + k
     RS_CMD0 = 24,     // vx vy yaw gait_frequency
     RS_CMD1 = 25,     // still, resample time
+    RS_CURR = 26,     // curriculum: grid cell, cmd x / y / yaw jitter
     RS_ACTOR = 32     // + k : action noise (bg_actor_sample)
 };
 

@@ -34,6 +34,9 @@ struct bg_env {
     float* f = nullptr;
     int32_t* i = nullptr;
     float* stats = nullptr;
+    float* curr = nullptr;
+    float* curr_read = nullptr;
+    int curr_cells = 0;
     ModelDev* model_dev = nullptr;
     int16_t* hf = nullptr;
     TerrainDev terrain;
@@ -192,7 +195,7 @@ extern "C" void bg_model_destroy(bg_model* m) { delete m; }
 // ------------------------------------------------------------------ ABI: env
 static EnvDev env_dev(const bg_env* e) {
     EnvDev E;
-    E.f = e->f; E.i = e->i; E.stats = e->stats; E.model = e->model_dev; E.terrain = e->terrain; E.cfg = e->cfg; E.n = e->n;
+    E.f = e->f; E.i = e->i; E.stats = e->stats; E.curr = e->curr; E.curr_read = e->curr_read; E.model = e->model_dev; E.terrain = e->terrain; E.cfg = e->cfg; E.n = e->n;
     return E;
 }
 
@@ -212,6 +215,17 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
     HIP_OK(hipMalloc(&e->i, sizeof(int32_t) * n * I_COUNT));
     HIP_OK(hipMalloc(&e->stats, sizeof(float) * STATS_COUNT));
     HIP_OK(hipMalloc(&e->model_dev, sizeof(ModelDev)));
+    if (cfg->lin_vel_levels < 0 || cfg->ang_vel_levels < 0 || cfg->lin_vel_levels > 64 || cfg->ang_vel_levels > 64)
+        return fail(-1, "bg_env_create: curriculum levels out of range");
+    e->curr_cells = (2 * cfg->lin_vel_levels + 1) * (2 * cfg->ang_vel_levels + 1);
+    HIP_OK(hipMalloc(&e->curr, sizeof(float) * e->curr_cells));
+    HIP_OK(hipMalloc(&e->curr_read, sizeof(float) * e->curr_cells));
+    {   // t1.py:249-255: all mass on the centre cell
+        std::vector<float> c0(e->curr_cells, 0.f);
+        c0[cfg->lin_vel_levels * (2 * cfg->ang_vel_levels + 1) + cfg->ang_vel_levels] = 1.f;
+        HIP_OK(hipMemcpy(e->curr, c0.data(), sizeof(float) * e->curr_cells, hipMemcpyHostToDevice));
+        HIP_OK(hipMemcpy(e->curr_read, c0.data(), sizeof(float) * e->curr_cells, hipMemcpyHostToDevice));
+    }
     HIP_OK(hipMemset(e->f, 0, sizeof(float) * n * F_COUNT));
     HIP_OK(hipMemset(e->i, 0, sizeof(int32_t) * n * I_COUNT));
     HIP_OK(hipMemset(e->stats, 0, sizeof(float) * STATS_COUNT));
@@ -244,7 +258,7 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
 
 extern "C" void bg_env_destroy(bg_env* e) {
     if (!e) return;
-    (void)hipFree(e->f); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf);
+    (void)hipFree(e->f); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
     delete e;
 }
 
@@ -295,6 +309,8 @@ static int launch_step(bg_env* e, const float* actions, int mode, const StepOut&
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
     hipLaunchKernelGGL(env_step_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), actions, (uint32_t)e->step_count, mode, out);
     HIP_OK(hipGetLastError());
+    if (e->cfg.curriculum && mode == 0)  // publish this step's curriculum increments to the next step's samplers
+        HIP_OK(hipMemcpyAsync(e->curr_read, e->curr, sizeof(float) * e->curr_cells, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 
@@ -341,6 +357,7 @@ static const FieldInfo kFields[] = {
     {"feet_pos", F_FEET_POS, 6, 0}, {"feet_roll", F_FEET_ROLL, 2, 0}, {"feet_yaw", F_FEET_YAW, 2, 0}, {"feet_contact", F_FEET_CONTACT, 2, 0},
     {"torques", F_TORQUES, 12, 0}, {"base_lin_vel", F_BASE_LIN, 3, 0}, {"base_ang_vel", F_BASE_ANG, 3, 0}, {"projected_gravity", F_PROJ_G, 3, 0},
     {"episode_sums", F_EP_SUMS, 27, 0},
+    {"env_curriculum_level_lin", I_CURR_LIN, 1, 1}, {"env_curriculum_level_ang", I_CURR_ANG, 1, 1},
     {"episode_length_buf", I_EP_LEN, 1, 1}, {"cmd_resample_time", I_CMD_TIME, 1, 1}, {"delay_steps", I_DELAY, 1, 1}, {"episode_steps", I_EP_STEPS, 1, 1},
 };
 static const FieldInfo* find_field(const char* name) {
@@ -381,6 +398,22 @@ extern "C" int bg_env_set_field(bg_env* e, const char* name, const void* src, vo
     int total = e->n * f->comps;
     hipLaunchKernelGGL(aos_to_soa_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, e->n, f->comps);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+__global__ void clamp_copy_kernel(const float* src, float* dst, int n) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = fminf(src[i], 1.0f);
+}
+extern "C" int bg_env_get_curriculum(bg_env* e, float* prob, void* stream) {
+    if (!e || !prob) return fail(-1, "bg_env_get_curriculum: null argument");
+    hipLaunchKernelGGL(clamp_copy_kernel, dim3((e->curr_cells + 255) / 256), dim3(256), 0, (hipStream_t)stream, e->curr, prob, e->curr_cells);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+extern "C" int bg_env_set_curriculum(bg_env* e, const float* prob, void* stream) {
+    if (!e || !prob) return fail(-1, "bg_env_set_curriculum: null argument");
+    HIP_OK(hipMemcpyAsync(e->curr, prob, sizeof(float) * e->curr_cells, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    HIP_OK(hipMemcpyAsync(e->curr_read, prob, sizeof(float) * e->curr_cells, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return 0;
 }
 extern "C" int64_t bg_env_step_count(const bg_env* e) { return e ? e->step_count : -1; }

@@ -170,11 +170,10 @@ class T1(BaseTask):
             cfg["init_state"]["pos"] + cfg["init_state"]["rot"] + cfg["init_state"]["lin_vel"] + cfg["init_state"]["ang_vel"],
             dtype=torch.float, device=dev)
         lv, av = cfg["commands"]["lin_vel_levels"], cfg["commands"]["ang_vel_levels"]
-        self.curriculum_prob = torch.zeros(1 + 2 * lv, 1 + 2 * av, dtype=torch.float, device=dev)
-        self.curriculum_prob[lv, av] = 1.0
+        self._curriculum_init = torch.zeros(1 + 2 * lv, 1 + 2 * av, dtype=torch.float, device=dev)
+        self._curriculum_init[lv, av] = 1.0
+        self._curriculum_shape = (1 + 2 * lv, 1 + 2 * av)
         self.mean_lin_vel_level = self.mean_ang_vel_level = self.max_lin_vel_level = self.max_ang_vel_level = 0.0
-        if cfg["commands"].get("curriculum", False):
-            raise NotImplementedError("commands.curriculum: the command curriculum (t1.py:391-435) is not built yet in this round")
 
     def _prepare_reward_function(self):
         scales = dict(self.cfg["rewards"]["scales"])
@@ -231,6 +230,12 @@ class T1(BaseTask):
             c.cmd_ang_vel_yaw[k], c.cmd_gait_frequency[k] = cm["ang_vel_yaw"][k], cm["gait_frequency"][k]
             c.resample_steps[k] = int(cm["resampling_time_s"][k] / self.dt)
         c.still_proportion = cm["still_proportion"]
+        c.curriculum = int(bool(cm.get("curriculum", False)))
+        c.lin_vel_levels, c.ang_vel_levels = int(cm["lin_vel_levels"]), int(cm["ang_vel_levels"])
+        c.curriculum_update_rate = cm["update_rate"]
+        c.lin_vel_x_resolution, c.lin_vel_y_resolution, c.ang_vel_resolution = cm["lin_vel_x_resolution"], cm["lin_vel_y_resolution"], cm["ang_vel_resolution"]
+        c.episode_length_toler, c.lin_vel_x_toler = cm["episode_length_toler"], cm["lin_vel_x_toler"]
+        c.lin_vel_y_toler, c.ang_vel_yaw_toler = cm["lin_vel_y_toler"], cm["ang_vel_yaw_toler"]
         rw = cfg["rewards"]
         for k, name in enumerate(_lib.REWARD_NAMES):
             c.reward_scale[k] = self.reward_scales.get(name, 0.0)
@@ -370,6 +375,28 @@ class T1(BaseTask):
                                                      _lib.current_stream_ptr()), "bg_env_forward_dynamics")
         torch.cuda.current_stream().synchronize()
         return qacc
+
+    # ---- command curriculum state (t1.py:249-262; r/w by the runner for checkpoints, runner.py:91,211)
+    @property
+    def curriculum_prob(self):
+        out = torch.empty(self._curriculum_shape, dtype=torch.float32, device=self.device)
+        _lib.check(self._lib.bg_env_get_curriculum(self._env, _lib.ptr(out), _lib.current_stream_ptr()), "bg_env_get_curriculum")
+        return out
+
+    @curriculum_prob.setter
+    def curriculum_prob(self, value):
+        v = torch.as_tensor(value, dtype=torch.float32).to(self.device).reshape(self._curriculum_shape).contiguous()
+        _lib.check(self._lib.bg_env_set_curriculum(self._env, _lib.ptr(v), _lib.current_stream_ptr()), "bg_env_set_curriculum")
+        torch.cuda.current_stream().synchronize()
+
+    def refresh_curriculum_levels(self):
+        """mean / max |level| over all envs (t1.py:421-424); one small device->host read, called once per iteration by the runner."""
+        if not self.cfg["commands"].get("curriculum", False):
+            return
+        lin = self.get_field("env_curriculum_level_lin").abs().float()
+        ang = self.get_field("env_curriculum_level_ang").abs().float()
+        self.mean_lin_vel_level, self.mean_ang_vel_level = float(lin.mean()), float(ang.mean())
+        self.max_lin_vel_level, self.max_ang_vel_level = float(lin.max()), float(ang.max())
 
     @property
     def root_states(self):

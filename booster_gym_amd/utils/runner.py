@@ -266,6 +266,20 @@ class Runner:
         buf["privileged_obses"][0].copy_(buf["privileged_obses"][T])
         return stats
 
+    def _sync_curriculum(self):
+        """Multi-rank command curriculum: sum every rank's increments of the probability grid since the last sync."""
+        if not (self.dp.active and self.cfg["commands"].get("curriculum", False)):
+            return
+        cur = self.env.curriculum_prob
+        last = getattr(self, "_curr_last", None)
+        if last is None:
+            last = self.env._curriculum_init
+        delta = cur - last
+        self.dp.sum_(delta)
+        new = torch.clamp(last + delta, max=1.0)
+        self.env.curriculum_prob = new
+        self._curr_last = new
+
     def _summarize(self, stats_acc):
         """Host-side means of the loss terms over the mini-epochs (runner.py:182-204); one device->host read."""
         T, N = self.cfg["runner"]["horizon_length"], self.env.num_envs
@@ -286,6 +300,8 @@ class Runner:
             stats = self.iteration()
             summary = self._summarize(stats)
             self.recorder.record_episode_statistics(self.env, self.env.reward_names, it)
+            self._sync_curriculum()
+            self.env.refresh_curriculum_levels()
             summary.update({"curriculum/mean_lin_vel_level": self.env.mean_lin_vel_level, "curriculum/mean_ang_vel_level": self.env.mean_ang_vel_level,
                             "curriculum/max_lin_vel_level": self.env.max_lin_vel_level, "curriculum/max_ang_vel_level": self.env.max_ang_vel_level})
             self.recorder.record_statistics(summary, it)

@@ -84,6 +84,11 @@ typedef struct {
     float cmd_lin_vel_x[2], cmd_lin_vel_y[2], cmd_ang_vel_yaw[2], cmd_gait_frequency[2];
     float still_proportion;
     int32_t resample_steps[2]; /* int(seconds / dt), t1.py:384-385 */
+    /* command curriculum (T1.yaml:124-133, t1.py:391-435); levels are +-lin_vel_levels x +-ang_vel_levels */
+    int32_t curriculum;
+    int32_t lin_vel_levels, ang_vel_levels;
+    float curriculum_update_rate, lin_vel_x_resolution, lin_vel_y_resolution, ang_vel_resolution;
+    float episode_length_toler, lin_vel_x_toler, lin_vel_y_toler, ang_vel_yaw_toler;
     /* rewards (T1.yaml:251-291) */
     float reward_scale[BG_NUM_REWARD_TERMS]; /* yaml value * dt; 0 = dropped */
     int32_t only_positive_rewards;
@@ -131,6 +136,11 @@ int bg_env_set_state(bg_env* env, const float* root, const float* dof, void* str
 int bg_env_get_field(bg_env* env, const char* name, void* dst_device, void* stream);
 int bg_env_set_field(bg_env* env, const char* name, const void* src_device, void* stream);
 int bg_env_field_info(bg_env* env, const char* name, int32_t* components, int32_t* is_int);
+/* curriculum_prob grid [(2*lin_vel_levels+1)][(2*ang_vel_levels+1)] (t1.py:249-255), device float pointers.  The library keeps the
+ * UNCLAMPED running sums (increments are positive, so min(sum, 1) equals the reference's clamp_(max=1) after every update);
+ * get returns min(sum, 1). */
+int bg_env_get_curriculum(bg_env* env, float* prob_device, void* stream);
+int bg_env_set_curriculum(bg_env* env, const float* prob_device, void* stream);
 int64_t bg_env_step_count(const bg_env* env);
 int bg_env_set_step_count(bg_env* env, int64_t count);
 

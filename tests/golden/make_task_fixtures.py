@@ -148,3 +148,37 @@ for dist in ("gaussian", "uniform"):
         y, noise = ref_utils.apply_randomization(x, {"distribution": dist, "operation": op, "range": [0.3, 0.7]}, return_noise=True)
         cases[f"{dist}_{op}_y"], cases[f"{dist}_{op}_noise"] = y.numpy(), noise.numpy()
 np.savez_compressed(os.path.join(HERE, "apply_randomization.npz"), x=x.numpy(), **cases)
+
+# ---- command curriculum (t1.py:391-435): deterministic part via the reference's own methods; the two RNG sources inside
+# `_resample_curriculum_commands` (torch.multinomial, torch_rand_float) are replaced by recorded draws
+import envs.t1 as ref_t1  # noqa: E402
+
+cfg["commands"]["curriculum"] = True
+lv, av = cfg["commands"]["lin_vel_levels"], cfg["commands"]["ang_vel_levels"]
+env.env_curriculum_level = torch.stack([torch.randint(-lv, lv + 1, (N,)), torch.randint(-av, av + 1, (N,))], dim=1)
+env.env_curriculum_level[0] = torch.tensor([-lv, av]); env.env_curriculum_level[1] = torch.tensor([lv, -av])  # grid corners
+env.curriculum_prob = torch.rand(2 * lv + 1, 2 * av + 1) * 1.05
+env.episode_length_buf = torch.randint(1200, 1600, (N,))
+env.filtered_lin_vel = env.commands + torch.randn(N, 3) * 0.25
+env.filtered_ang_vel = env.commands[:, [2, 2, 2]] + torch.randn(N, 3) * 0.15
+ids = torch.arange(0, N, 2)
+cur_in = dict(curr_levels=env.env_curriculum_level.numpy().copy(), curr_prob=env.curriculum_prob.numpy().copy(), curr_ep_len=env.episode_length_buf.numpy().copy(),
+              curr_filt_lin=env.filtered_lin_vel.numpy().copy(), curr_filt_ang=env.filtered_ang_vel.numpy().copy(), curr_cmd=env.commands.numpy().copy(),
+              curr_ids=ids.numpy().copy())
+env._update_curriculum(ids)
+cur_out = dict(curr_prob_after=env.curriculum_prob.numpy().copy())
+grid_idx = torch.randint(0, (2 * lv + 1) * (2 * av + 1), (len(ids),))
+draws = [torch.rand(len(ids), 1) - 0.5, torch.rand(len(ids), 1) * 2 - 1, torch.rand(len(ids), 1) - 0.5]
+it = iter(draws)
+real_multinomial, real_rand = torch.multinomial, ref_t1.torch_rand_float
+torch.multinomial = lambda p, n, replacement=True: grid_idx
+ref_t1.torch_rand_float = lambda lo, hi, shape, device: next(it)
+try:
+    env._resample_curriculum_commands(ids)
+finally:
+    torch.multinomial, ref_t1.torch_rand_float = real_multinomial, real_rand
+cur_in.update(curr_grid_idx=grid_idx.numpy(), curr_ux=draws[0][:, 0].numpy(), curr_uy=draws[1][:, 0].numpy(), curr_uyaw=draws[2][:, 0].numpy())
+cur_out.update(curr_commands=env.commands.numpy().copy(), curr_levels_after=env.env_curriculum_level.numpy().copy(),
+               curr_level_stats=np.array([float(env.mean_lin_vel_level), float(env.mean_ang_vel_level), float(env.max_lin_vel_level), float(env.max_ang_vel_level)]))
+np.savez_compressed(os.path.join(HERE, "curriculum.npz"), **cur_in, **cur_out)
+print("curriculum.npz written; successes:", int((cur_out["curr_prob_after"] != np.minimum(cur_in["curr_prob"], 1.0)).sum()), "cells changed")

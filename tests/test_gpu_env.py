@@ -120,6 +120,47 @@ def test_step_matches_oracle(terrain, start_count):
     assert st[0] >= 6  # the forced time-outs were counted as finished episodes
 
 
+def test_command_curriculum_matches_oracle():
+    """commands.curriculum = true (t1.py:391-435): grid update on successful episodes, multinomial resampling, level bookkeeping."""
+    n = 96
+    cfg, env, ref = _make("plane", n, {"commands.curriculum": True})
+    env.reset(); ref.reset()
+    rng = np.random.default_rng(3)
+    for _ in range(12):
+        env.step(torch.tensor(rng.uniform(-0.3, 0.3, (n, 12)), dtype=torch.float32, device=env.device))
+    # a non-trivial grid, levels for every env, and a batch of envs that end a SUCCESSFUL long episode in the window
+    prob0 = rng.uniform(0.0, 0.8, (21, 21)).astype(np.float32); prob0[10, 10] = 1.0
+    env.curriculum_prob = torch.tensor(prob0)
+    ref.curr_prob = prob0.astype(np.float64); ref.curr_prob_read = ref.curr_prob.copy()
+    lin0, ang0 = rng.integers(-10, 11, n), rng.integers(-10, 11, n)
+    env.set_field("env_curriculum_level_lin", torch.tensor(lin0, dtype=torch.int32)); env.set_field("env_curriculum_level_ang", torch.tensor(ang0, dtype=torch.int32))
+    ep = env.get_field("episode_length_buf"); ep[:24, 0] = 1499; env.set_field("episode_length_buf", ep)
+    ct = env.get_field("cmd_resample_time"); ct[:24, 0] = 9000; ct[24:40, 0] = ep[24:40, 0] + 2; env.set_field("cmd_resample_time", ct)
+    cmd = env.get_field("commands"); filt_l = env.get_field("filtered_lin_vel"); filt_a = env.get_field("filtered_ang_vel")
+    cmd[:24] = 0.0; filt_l[:12] = 0.0; filt_a[:12] = 0.0  # 12 successes (tracking error 0), 12 probable failures
+    filt_l[12:24, 0] = 1.0
+    env.set_field("commands", cmd); env.set_field("filtered_lin_vel", filt_l); env.set_field("filtered_ang_vel", filt_a)
+    changed = False
+    for s in range(4):
+        _sync_oracle(env, ref)
+        ref.curr_levels[:, 0] = env.get_field("env_curriculum_level_lin").cpu().numpy()[:, 0]
+        ref.curr_levels[:, 1] = env.get_field("env_curriculum_level_ang").cpu().numpy()[:, 0]
+        act = rng.uniform(-0.3, 0.3, (n, 12)).astype(np.float32)
+        obs, rew, done, extras = env.step(torch.tensor(act, device=env.device))
+        o_ref, p_ref, r_ref, d_ref, t_ref, terms_ref, derived = ref.step(act.astype(np.float64))
+        keep = done.cpu().numpy() == d_ref
+        assert keep.mean() > 0.97
+        got = env.curriculum_prob.cpu().numpy()
+        assert np.allclose(got, np.minimum(ref.curr_prob, 1.0), atol=1e-5), f"step {s}: grid differs"
+        changed = changed or np.abs(got - prob0).max() > 0.05
+        assert (env.get_field("env_curriculum_level_lin").cpu().numpy()[:, 0][keep] == ref.curr_levels[keep, 0]).all()
+        assert (env.get_field("env_curriculum_level_ang").cpu().numpy()[:, 0][keep] == ref.curr_levels[keep, 1]).all()
+        _close(env.commands.cpu().numpy()[keep], ref.cmd[keep], 1e-5, frac=1.0, what=f"step {s} curriculum commands")
+    assert changed, "no successful episode updated the grid"
+    env.refresh_curriculum_levels()
+    assert env.max_lin_vel_level >= 1.0 and 0.0 < env.mean_ang_vel_level <= 10.0
+
+
 def test_trained_reference_policy_walks_on_the_gpu():
     """Closed loop on the GPU: the reference's trained actor drives 256 envs on flat ground for 6 s; most robots stay up and
     track their commanded velocity sign.  (A trained PhysX policy is a strong end-to-end check of obs layout + dynamics.)"""

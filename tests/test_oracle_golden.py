@@ -89,6 +89,24 @@ def test_pd_torque_matches_reference(task):
     assert np.allclose(t, o["pd_torque"], atol=1e-4)
 
 
+def test_command_curriculum_matches_reference():
+    """t1.py:391-435 via the reference's own `_update_curriculum` / `_resample_curriculum_commands` (RNG draws recorded in the fixture)."""
+    d = G("curriculum.npz")
+    cm = dict(lin_vel_levels=10, ang_vel_levels=10, update_rate=0.1, lin_vel_x_resolution=0.2, lin_vel_y_resolution=0.1, ang_vel_resolution=0.2,
+              episode_length_toler=0.1, lin_vel_x_toler=0.4, lin_vel_y_toler=0.2, ang_vel_yaw_toler=0.2)
+    prob = tr.update_curriculum(d["curr_prob"].astype(np.float64), d["curr_levels"], d["curr_ep_len"], d["curr_filt_lin"].astype(np.float64),
+                                d["curr_filt_ang"].astype(np.float64), d["curr_cmd"].astype(np.float64), d["curr_ids"], cm, REW_CFG, 0.02)
+    assert np.allclose(prob, d["curr_prob_after"], atol=1e-6)
+    assert (np.abs(prob - np.minimum(d["curr_prob"], 1.0)) > 1e-6).sum() >= 10  # the update did something
+    lin, ang, cmd = tr.curriculum_commands(d["curr_grid_idx"], d["curr_ux"].astype(np.float64), d["curr_uy"].astype(np.float64),
+                                           d["curr_uyaw"].astype(np.float64), cm, 21)
+    ids = d["curr_ids"]
+    assert np.allclose(cmd, d["curr_commands"][ids], atol=1e-6)
+    assert (lin == d["curr_levels_after"][ids, 0]).all() and (ang == d["curr_levels_after"][ids, 1]).all()
+    lv = d["curr_levels_after"]
+    assert np.allclose([np.abs(lv[:, 0]).mean(), np.abs(lv[:, 1]).mean(), np.abs(lv[:, 0]).max(), np.abs(lv[:, 1]).max()], d["curr_level_stats"], atol=1e-5)
+
+
 def test_philox_known_answer():
     # Random123 known-answer vectors for philox4x32-10
     o = tr.philox4x32_10(0, 0, np.uint32(0), np.uint32(0), np.uint32(0), np.uint32(0))
