@@ -36,8 +36,8 @@ class MLPTrainer:
     def __init__(self, seq, max_split=32):
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
         self.max_split = max_split
-        self.acts = None
-        self._tmp = {}
+        self.x = None
+        self._B = None
 
     def _split(self, B):
         s = self.max_split
@@ -45,42 +45,44 @@ class MLPTrainer:
             s -= 1
         return s
 
+    def _alloc(self, B, dev):
+        """Static workspaces for batch size B (no allocator traffic inside the update loop; safe to use from a side stream)."""
+        self._B, self._S = B, self._split(B)
+        self.acts = [torch.empty(B, l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
+        self.gin = [None] + [torch.empty(B, l.weight.shape[1], dtype=torch.float32, device=dev) for l in self.layers[1:]]
+        self.cs = [torch.empty(((B + 127) // 128) * l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
+        self.dw = [torch.empty(self._S, *l.weight.shape, dtype=torch.float32, device=dev) for l in self.layers]
+
     def forward(self, x):
-        acts, h = [x], x
+        if self._B != x.shape[0]:
+            self._alloc(x.shape[0], x.device)
+        self.x, h = x, x
         last = len(self.layers) - 1
         for i, l in enumerate(self.layers):
-            h = torch.addmm(l.bias, h, l.weight.t())
+            torch.addmm(l.bias, h, l.weight.t(), out=self.acts[i])
+            h = self.acts[i]
             if i < last:
-                h = torch.nn.functional.elu_(h)
-            acts.append(h)
-        self.acts = acts
+                torch.nn.functional.elu_(h)
         return h
 
     def backward(self, grad_out):
         """grad_out [B, out] is consumed (modified in place).  Fills weight.grad / bias.grad of every layer."""
         lib = _lib.load()
-        g = grad_out
-        B = g.shape[0]
-        S = self._split(B)
+        g, B, S = grad_out, self._B, self._S
         stream = _lib.current_stream_ptr()
         last = len(self.layers) - 1
         for i in range(last, -1, -1):
-            l, a_in = self.layers[i], self.acts[i]
+            l = self.layers[i]
+            a_in = self.acts[i - 1] if i > 0 else self.x
             C_out, C_in = l.weight.shape
-            key = ("cs", C_out)
-            if key not in self._tmp:
-                self._tmp[key] = torch.empty(((B + 127) // 128) * C_out, dtype=torch.float32, device=g.device)
-            act = self.acts[i + 1] if i < last else None
-            _lib.check(lib.bg_elu_backward_colsum(B, C_out, _lib.ptr(g), _lib.ptr(act), _lib.ptr(l.bias.grad), _lib.ptr(self._tmp[key]), stream),
+            act = self.acts[i] if i < last else None
+            _lib.check(lib.bg_elu_backward_colsum(B, C_out, _lib.ptr(g), _lib.ptr(act), _lib.ptr(l.bias.grad), _lib.ptr(self.cs[i]), stream),
                        "bg_elu_backward_colsum")
-            key = ("dw", C_out, C_in)
-            if key not in self._tmp:
-                self._tmp[key] = torch.empty(S, C_out, C_in, dtype=torch.float32, device=g.device)
-            torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self._tmp[key])
-            torch.sum(self._tmp[key], dim=0, out=l.weight.grad)
+            torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
+            torch.sum(self.dw[i], dim=0, out=l.weight.grad)
             if i > 0:
-                g = torch.mm(g, l.weight)
-        self.acts = None
+                torch.mm(g, l.weight, out=self.gin[i])
+                g = self.gin[i]
 
 
 class ActorCritic(torch.nn.Module):

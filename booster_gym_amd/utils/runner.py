@@ -147,6 +147,7 @@ class Runner:
         self._old_logp = torch.zeros(B, device=dev)
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
         self._actor_tr, self._critic_tr = MLPTrainer(self.model.actor), MLPTrainer(self.model.critic)
+        self._side_stream = torch.cuda.Stream(device=self.device)
         self._act_counter = 0
         self.timers = {"rollout": 0.0, "update": 0.0}
 
@@ -236,20 +237,31 @@ class Runner:
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
             gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
         self._stats_acc.zero_()
+        # Two HIP streams: the actor and the critic are independent networks, so the HBM-bound elementwise kernels of one overlap
+        # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
+        main = torch.cuda.current_stream()
+        side = self._side_stream
         with torch.no_grad():
             for _ in range(cfg["runner"]["mini_epochs"]):
-                values = self._critic_tr.forward(critic_in).squeeze(-1)
-                last_values = self.model.critic(critic_last).squeeze(-1)
-                gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
-                    advantages=self._adv, returns=self._ret, sums=self._adv_sums)
-                self.dp.sum_(self._adv_sums)
+                side.wait_stream(main)  # parameters updated by the previous optimiser step
+                with torch.cuda.stream(side):
+                    values = self._critic_tr.forward(critic_in).squeeze(-1)
+                    last_values = self.model.critic(critic_last).squeeze(-1)
+                    gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
+                        advantages=self._adv, returns=self._ret, sums=self._adv_sums)
+                    last_values.record_stream(side)
                 mu = self._actor_tr.forward(obs_flat)
+                main.wait_stream(side)
+                self.dp.sum_(self._adv_sums)
                 ppo_loss_fused(mu, self.model.logstd.reshape(-1), act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
                                values, self._ret.view(B), 0.2, alg["bound_coef"], alg["entropy_coef"], self._grad_mu, self._grad_val,
                                self._grad_logstd, self._stats)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._critic_tr.backward(self._grad_val.view(B, 1))
                 self._actor_tr.backward(self._grad_mu)
-                self._critic_tr.backward(self._grad_val.view(B, 1))
                 self._logstd_grad_view.copy_(self._grad_logstd)
+                main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)
                 self.dp.sum_(self._stats)
                 self.optimizer.step()
