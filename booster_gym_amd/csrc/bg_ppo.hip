@@ -160,58 +160,94 @@ __global__ void gaussian_logp_kernel(int B, const float* __restrict__ mu, const 
     logp[b] = s;
 }
 
-// ------------------------------------------------------------------ fused actor MLP + Gaussian sample (rollout inference)
-// One workgroup = ROWS observation rows.  Activations live in LDS; every thread owns output neurons and
-// streams its weight rows (L2-resident: 253 KB for the whole actor) with 16-byte loads.
-constexpr int AROWS = 8;
+// ------------------------------------------------------------------ fused actor MLP + Gaussian sample (rollout inference), fp32 MFMA
+// One workgroup (4 waves) = 16 observation rows; activations ping-pong between two LDS tiles; every wave owns output-neuron
+// tiles of 16 and accumulates them with v_mfma_f32_16x16x4_f32 (exact fp32, D = A*B + C):
+//     A[i = lane & 15][k = lane >> 4] = X[row i][k]          (from LDS, one ds_read_b128 feeds 4 MFMAs)
+//     B[k = lane >> 4][j = lane & 15] = W[neuron j][k]       (straight from L2: torch layout [out][in], one 16-byte load feeds 4 MFMAs)
+//     C/D: neuron j = lane & 15, row i = (lane >> 4) * 4 + reg
+// The k index inside a group of 16 is permuted identically for A and B (k = 16 t + 4 (lane >> 4) + step), which a sum over k allows.
+// 63,244 weights = 253 kB stay L2-resident; 992 MFMAs per workgroup.
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int AROWS = 16;
+constexpr int ALD = 260;  // LDS row stride (floats)
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
 
+// K % 16 == 0, weight rows 16-byte aligned.  Computes out[:, n0 .. n0+15] for NT neuron tiles starting at tile `first`, stride 4 waves.
 template <int K, int OUT, bool ACT>
-__device__ __forceinline__ void dense_layer(const float* __restrict__ W, const float* __restrict__ bias, const float (*in)[260], float (*out)[260]) {
-    for (int o = threadIdx.x; o < OUT; o += blockDim.x) {
-        float acc[AROWS];
-        const float bv = bias[o];
-        for (int r = 0; r < AROWS; r++) acc[r] = bv;
-        const float* w = W + (size_t)o * K;
-        if constexpr (K % 4 == 0) {
-            for (int k = 0; k < K; k += 4) {
-                const float4 wv = *reinterpret_cast<const float4*>(w + k);
-                for (int r = 0; r < AROWS; r++) {
-                    acc[r] = fmaf(wv.x, in[r][k], acc[r]); acc[r] = fmaf(wv.y, in[r][k + 1], acc[r]);
-                    acc[r] = fmaf(wv.z, in[r][k + 2], acc[r]); acc[r] = fmaf(wv.w, in[r][k + 3], acc[r]);
-                }
-            }
-        } else {
-            for (int k = 0; k < K; k++) {
-                const float wv = w[k];
-                for (int r = 0; r < AROWS; r++) acc[r] = fmaf(wv, in[r][k], acc[r]);
-            }
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ W, const float* __restrict__ bias, const float* in /*LDS [16][ALD]*/,
+                                           float* out /*LDS [16][ALD]*/, int wave, int lane) {
+    constexpr int TILES = (OUT + 15) / 16, G = K / 16;
+    const int r = lane & 15, kg = lane >> 4;
+    for (int tile = wave; tile < TILES; tile += 4) {
+        const int n = tile * 16 + r;
+        const bool nv = n < OUT;
+        const float* wrow = W + (size_t)(nv ? n : 0) * K + 4 * kg;
+        float4 bfrag[G];
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            bfrag[t] = *reinterpret_cast<const float4*>(wrow + 16 * t);
+            if (!nv) bfrag[t] = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        for (int r = 0; r < AROWS; r++) out[r][o] = ACT ? elu(acc[r]) : acc[r];
+        const float bv = nv ? bias[n] : 0.f;
+        f32x4 acc = {bv, bv, bv, bv};
+#pragma unroll
+        for (int t = 0; t < G; t++) {
+            const float4 a = *reinterpret_cast<const float4*>(in + r * ALD + 16 * t + 4 * kg);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bfrag[t].x, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bfrag[t].y, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bfrag[t].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bfrag[t].w, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const float v = ACT ? elu(acc[q]) : acc[q];
+            out[(kg * 4 + q) * ALD + tile * 16 + r] = v;
+        }
     }
 }
 
-__global__ __launch_bounds__(128) void actor_sample_kernel(int N, const float* __restrict__ obs, const float* __restrict__ w0,
+// first layer: K = 47 (rows not 16-byte aligned, K not a multiple of 4): scalar operand loads, k padded to 48 with zeros
+template <int K, int OUT>
+__device__ __forceinline__ void mfma_layer_first(const float* __restrict__ W, const float* __restrict__ bias, const float* in, float* out, int wave,
+                                                 int lane) {
+    constexpr int TILES = OUT / 16, STEPS = (K + 3) / 4;
+    const int r = lane & 15, kg = lane >> 4;
+    for (int tile = wave; tile < TILES; tile += 4) {
+        const int n = tile * 16 + r;
+        float bfrag[STEPS];
+#pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) { const int k = 4 * s2 + kg; bfrag[s2] = k < K ? W[(size_t)n * K + k] : 0.f; }
+        const float bv = bias[n];
+        f32x4 acc = {bv, bv, bv, bv};
+#pragma unroll
+        for (int s2 = 0; s2 < STEPS; s2++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(in[r * ALD + 4 * s2 + kg], bfrag[s2], acc, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 4; q++) out[(kg * 4 + q) * ALD + tile * 16 + r] = elu(acc[q]);
+    }
+}
+
+__global__ __launch_bounds__(256) void actor_sample_kernel(int N, const float* __restrict__ obs, const float* __restrict__ w0,
                                                            const float* __restrict__ b0, const float* __restrict__ w1,
                                                            const float* __restrict__ b1, const float* __restrict__ w2,
                                                            const float* __restrict__ b2, const float* __restrict__ w3,
                                                            const float* __restrict__ b3, const float* __restrict__ logstd, uint64_t seed,
                                                            uint32_t counter, float* __restrict__ mu_out, float* __restrict__ act_out) {
-    __shared__ float bufA[AROWS][260];
-    __shared__ float bufB[AROWS][260];
-    const int r0 = blockIdx.x * AROWS;
-    for (int k = threadIdx.x; k < AROWS * BG_NUM_OBS; k += blockDim.x) {
-        const int r = k / BG_NUM_OBS, c = k % BG_NUM_OBS;
-        bufA[r][c] = (r0 + r < N) ? obs[(size_t)(r0 + r) * BG_NUM_OBS + c] : 0.f;
+    __shared__ __attribute__((aligned(16))) float bufA[AROWS * ALD];
+    __shared__ __attribute__((aligned(16))) float bufB[AROWS * ALD];
+    const int r0 = blockIdx.x * AROWS, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    for (int k = threadIdx.x; k < AROWS * 48; k += blockDim.x) {  // obs tile, k padded 47 -> 48 with zeros
+        const int r = k / 48, c = k % 48;
+        bufA[r * ALD + c] = (r0 + r < N && c < BG_NUM_OBS) ? obs[(size_t)(r0 + r) * BG_NUM_OBS + c] : 0.f;
     }
     __syncthreads();
-    dense_layer<BG_NUM_OBS, 256, true>(w0, b0, bufA, bufB);
+    mfma_layer_first<BG_NUM_OBS, 256>(w0, b0, bufA, bufB, wave, lane);
     __syncthreads();
-    dense_layer<256, 128, true>(w1, b1, bufB, bufA);
+    mfma_layer<256, 128, true>(w1, b1, bufB, bufA, wave, lane);
     __syncthreads();
-    dense_layer<128, 128, true>(w2, b2, bufA, bufB);
+    mfma_layer<128, 128, true>(w2, b2, bufA, bufB, wave, lane);
     __syncthreads();
-    dense_layer<128, BG_NUM_DOFS, false>(w3, b3, bufB, bufA);
+    mfma_layer<128, BG_NUM_DOFS, false>(w3, b3, bufB, bufA, wave, lane);
     __syncthreads();
     // sample: one thread per (row, group of 4 actions)
     if (threadIdx.x < AROWS * 3) {
@@ -220,7 +256,7 @@ __global__ __launch_bounds__(128) void actor_sample_kernel(int N, const float* _
             bg::Rand4 rn = bg::rand4(seed, (uint32_t)row, counter, bg::RS_ACTOR + g);
             for (int k = 0; k < 4; k++) {
                 const int a = g * 4 + k;
-                const float m = bufA[r][a];
+                const float m = bufA[r * ALD + a];
                 if (mu_out) mu_out[(size_t)row * BG_NUM_DOFS + a] = m;
                 act_out[(size_t)row * BG_NUM_DOFS + a] = m + expf(logstd[a]) * rn.n[k];
             }
@@ -377,7 +413,8 @@ extern "C" int bg_actor_sample(int32_t N, const float* obs, const float* w0, con
                                float* actions, void* stream) {
     if (N <= 0 || !obs || !w0 || !b0 || !w1 || !b1 || !w2 || !b2 || !w3 || !b3 || !logstd || !actions)
         return bg_set_error(-1, "bg_actor_sample: bad argument");
-    hipLaunchKernelGGL(actor_sample_kernel, dim3((N + AROWS - 1) / AROWS), dim3(128), 0, (hipStream_t)stream, N, obs, w0, b0, w1, b1, w2, b2, w3, b3,
+    if (((uintptr_t)w1 | (uintptr_t)w2 | (uintptr_t)w3) & 15) return bg_set_error(-1, "bg_actor_sample: weight matrices must be 16-byte aligned");
+    hipLaunchKernelGGL(actor_sample_kernel, dim3((N + AROWS - 1) / AROWS), dim3(256), 0, (hipStream_t)stream, N, obs, w0, b0, w1, b1, w2, b2, w3, b3,
                        logstd, seed, (uint32_t)counter, mu, actions);
     HIP_OK(hipGetLastError());
     return 0;

@@ -44,17 +44,20 @@ class FlatAdam:
         self.params = list(params)
         dev = self.params[0].device
         self.sizes = [p.numel() for p in self.params]
-        n = sum(self.sizes)
+        # every tensor starts on a 16-byte boundary of the flat buffer (the MFMA actor kernel reads weight rows with 16-byte loads);
+        # the padding floats stay zero in params / grads / moments, so norms, Adam and the all-reduce are unaffected
+        self.offsets, n = [], 0
+        for k in self.sizes:
+            self.offsets.append(n)
+            n += (k + 3) // 4 * 4
         self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
         self.grad = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg = torch.zeros_like(self.flat)
         self.exp_avg_sq = torch.zeros_like(self.flat)
-        off = 0
-        for p, k in zip(self.params, self.sizes):
+        for p, k, off in zip(self.params, self.sizes, self.offsets):
             self.flat[off : off + k].copy_(p.data.reshape(-1))
             p.data = self.flat[off : off + k].view_as(p)
             p.grad = self.grad[off : off + k].view_as(p)
-            off += k
         self.lr = torch.full((1,), float(lr), dtype=torch.float32, device=dev)
         self.betas, self.eps, self.max_grad_norm = betas, eps, max_grad_norm
         self.step_count = 0
@@ -74,24 +77,21 @@ class FlatAdam:
                    "bg_adapt_lr")
 
     def state_dict(self):
-        state, off = {}, 0
-        for i, k in enumerate(self.sizes):
+        state = {}
+        for i, (k, off) in enumerate(zip(self.sizes, self.offsets)):
             state[i] = {"step": torch.tensor(float(self.step_count)), "exp_avg": self.exp_avg[off : off + k].view_as(self.params[i]).clone(),
                         "exp_avg_sq": self.exp_avg_sq[off : off + k].view_as(self.params[i]).clone()}
-            off += k
         group = {"lr": float(self.lr.item()), "betas": self.betas, "eps": self.eps, "weight_decay": 0, "amsgrad": False, "maximize": False,
                  "foreach": None, "capturable": False, "differentiable": False, "fused": None, "params": list(range(len(self.sizes)))}
         return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        off = 0
-        for i, k in enumerate(self.sizes):
+        for i, (k, off) in enumerate(zip(self.sizes, self.offsets)):
             st = sd["state"].get(i)
             if st is not None:
                 self.exp_avg[off : off + k].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[off : off + k].copy_(st["exp_avg_sq"].reshape(-1))
                 self.step_count = int(float(st["step"]))
-            off += k
         self.lr.fill_(float(sd["param_groups"][0]["lr"]))
 
 

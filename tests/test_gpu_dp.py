@@ -41,7 +41,7 @@ def _worker(rank, world, port, q):
     full = {k: gather(b[k].to(torch.uint8) if b[k].dtype == torch.bool else b[k], 1) for k in ("obses", "privileged_obses", "actions", "rewards", "dones", "time_outs")}
     acc = r.update()
     summ = r._summarize(acc)
-    flat = r.optimizer.flat.detach().clone()
+    flat = torch.cat([p.detach().reshape(-1) for p in r.model.parameters()])
     other = gather(flat.view(1, -1), 0)
     ref_model = ActorCritic(12, 47, 14).to(r.device)
     ref_model.load_state_dict(sd0)
