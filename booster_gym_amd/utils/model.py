@@ -75,9 +75,11 @@ class MLPTrainer:
             l = self.layers[i]
             a_in = self.acts[i - 1] if i > 0 else self.x
             C_out, C_in = l.weight.shape
-            act = self.acts[i] if i < last else None
-            _lib.check(lib.bg_elu_backward_colsum(B, C_out, _lib.ptr(g), _lib.ptr(act), _lib.ptr(l.bias.grad), _lib.ptr(self.cs[i]), stream),
-                       "bg_elu_backward_colsum")
+            if i < last:
+                _lib.check(lib.bg_elu_backward_colsum(B, C_out, _lib.ptr(g), _lib.ptr(self.acts[i]), _lib.ptr(l.bias.grad), _lib.ptr(self.cs[i]), stream),
+                           "bg_elu_backward_colsum")
+            else:  # linear output layer (12 or 1 columns): a plain column sum
+                torch.sum(g, dim=0, out=l.bias.grad)
             torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
             torch.sum(self.dw[i], dim=0, out=l.weight.grad)
             if i > 0:
