@@ -1,0 +1,140 @@
+"""Edge cases and size-independent properties of the HIP env (through the C ABI): ragged / tiny / huge env counts, determinism,
+independence of environments, state invariants, the non-finite guard, dropped reward terms, argument errors."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+NO_DR = {"randomization.dof_stiffness": None, "randomization.dof_damping": None, "randomization.dof_friction": None, "randomization.friction": None,
+         "randomization.compliance": None, "randomization.restitution": None, "randomization.base_com": None, "randomization.base_mass": None,
+         "randomization.other_com": None, "randomization.other_mass": None}
+
+
+def _env(n, terrain="plane", extra=None):
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+
+    ov = {"env.num_envs": n, "terrain.type": terrain}
+    ov.update(extra or {})
+    return T1(load_cfg("T1", ov))
+
+
+def _actions(n, steps, dev, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return [(torch.rand(262144, 12, generator=g) * 1.2 - 0.6)[:n].to(dev) for _ in range(steps)]
+
+
+def _rollout(env, acts):
+    obs, _ = env.reset()
+    outs = [obs.clone()]
+    for a in acts:
+        obs, rew, done, extras = env.step(a)
+        outs.append(torch.cat([obs, extras["privileged_obs"], rew[:, None], done[:, None].float(), extras["time_outs"][:, None].float()], dim=1).clone())
+    return outs
+
+
+@pytest.mark.parametrize("n", [1, 33, 100])
+def test_ragged_env_counts_match_the_leading_envs_of_a_full_block(n):
+    """Environments are independent and RNG streams are keyed by the env index, so with build-time randomisation off the first n envs of
+    a 128-env run are BITWISE the n envs of an n-env run (n not a multiple of the 32-env workgroup; n = 1 = half a lane pair's wave)."""
+    acts = _actions(128, 12, "cuda:0")
+    full = _rollout(_env(128, "plane", NO_DR), acts)  # plane: env origins (which depend on N) do not enter the dynamics
+    part = _rollout(_env(n, "plane", NO_DR), [a[:n] for a in acts])
+    for a, b in zip(full, part):
+        assert torch.equal(a[:n], b)
+        assert torch.isfinite(b).all()
+
+
+def test_full_size_launch_has_the_same_leading_envs():
+    """BASELINE-size property: 262,144 envs in one launch; its first 64 envs equal a 64-env run bit for bit, everything stays finite."""
+    n = 262144
+    acts = _actions(n, 4, "cuda:0")
+    big = _rollout(_env(n, "plane", NO_DR), acts)
+    small = _rollout(_env(64, "plane", NO_DR), [a[:64] for a in acts])
+    for a, b in zip(big, small):
+        assert torch.equal(a[:64], b)
+        assert torch.isfinite(a).all()
+
+
+def test_determinism_and_seed_sensitivity():
+    acts = _actions(96, 10, "cuda:0")
+    a = _rollout(_env(96), acts)
+    b = _rollout(_env(96), acts)
+    c = _rollout(_env(96, extra={"basic.seed": 43}), acts)
+    assert all(torch.equal(x, y) for x, y in zip(a, b))
+    assert not torch.equal(a[-1], c[-1])
+
+
+def test_state_invariants_after_random_rollout():
+    n = 512
+    env = _env(n, "trimesh")
+    env.reset()
+    for a in _actions(n, 60, env.device, seed=3):
+        obs, rew, done, extras = env.step(a)
+    root, q, qd = env.root_states, env.dof_pos, env.dof_vel
+    assert torch.allclose(root[:, 3:7].norm(dim=1), torch.ones(n, device=env.device), atol=1e-5)
+    lo, hi = env.dof_pos_limits[:, 0], env.dof_pos_limits[:, 1]
+    assert ((q > lo - 0.25) & (q < hi + 0.25)).all()  # soft joint limits hold
+    assert (qd.abs() <= env.dof_vel_limits + 1e-4).all()  # velocity clamp
+    assert (rew >= 0).all()  # only_positive_rewards
+    assert torch.isfinite(obs).all() and float(env.episode_stats(reset=False)[-1]) == 0
+    # dropped terms (scale 0 in the yaml) are not exported, exported rows are finite
+    assert set(extras["rew_terms"].keys()) == set(env.reward_names) and "feet_vel_z" not in extras["rew_terms"]
+    ep = env.episode_length_buf
+    assert (ep >= 0).all() and (ep <= 61).all()
+
+
+def test_nonfinite_state_is_reset_and_counted():
+    n = 64
+    acts = _actions(n, 3, "cuda:0")
+    ref = _env(n, extra=NO_DR); ref.reset()
+    env = _env(n, extra=NO_DR); env.reset()
+    root = env.root_states
+    root[5, 7] = float("nan"); root[9, 2] = float("inf")
+    env.set_field("root_states", root)
+    o1, r1, d1, e1 = env.step(acts[0])
+    o0, r0, d0, e0 = ref.step(acts[0])
+    assert bool(d1[5]) and bool(d1[9]) and r1[5] == 0 and r1[9] == 0
+    assert torch.isfinite(o1).all() and torch.isfinite(env.root_states).all()
+    keep = torch.ones(n, dtype=torch.bool, device=env.device); keep[[5, 9]] = False
+    assert torch.equal(o1[keep], o0[keep])  # the other envs never noticed
+    assert float(env.episode_stats(reset=False)[-1]) == 2.0
+    o1, _, _, _ = env.step(acts[1])
+    assert torch.isfinite(o1).all()
+
+
+def test_argument_errors():
+    env = _env(8)
+    env.reset()
+    with pytest.raises(ValueError, match="shape"):
+        env.step(torch.zeros(7, 12, device=env.device))
+    with pytest.raises(RuntimeError, match="unknown field"):
+        env.get_field("no_such_field")
+    # host / double / non-contiguous actions are accepted (copied), like the reference accepts any tensor
+    out = env.step(torch.zeros(8, 12, dtype=torch.float64))
+    assert out[0].shape == (8, 47)
+    with pytest.raises(RuntimeError, match="contiguous CUDA"):
+        env.step_to(torch.zeros(8, 12, device=env.device), torch.zeros(8, 47), env.privileged_obs_buf, env.rew_buf, env.reset_buf, env.time_out_buf)
+
+
+def test_config5_full_domain_randomisation_16384_envs():
+    """BASELINE configs[4] shape: every randomisation of T1.yaml active (mass / com / friction / latency / kick / push), 16,384 envs, rough
+    terrain; fp32 state (the fp16-state variant is not built).  Kick (cnt % 100) and push (cnt % 250) fall inside the window."""
+    n = 16384
+    env = _env(n, "trimesh")
+    env.reset()
+    env.common_step_counter = 240
+    act = torch.zeros(n, 12, device=env.device)
+    dones = 0
+    for s in range(20):
+        obs, rew, done, extras = env.step(act)
+        dones += int(done.sum())
+    assert torch.isfinite(obs).all() and torch.isfinite(extras["privileged_obs"]).all()
+    push = env.get_field("pushing")
+    assert push.abs().max() > 1.0 and push[:, :3].std() > 5.0  # N(0, 10) N forces were drawn at cnt = 250
+    delay = env.get_field("delay_steps")[:, 0]
+    assert delay.min() == 0 and delay.max() == 9  # latency randomisation over the 10 substeps
+    ms = env.get_field("mass_scale")
+    assert 0.79 < float(ms[:, 0].min()) < 0.85 and 1.15 < float(ms[:, 0].max()) < 1.21  # base mass x U(0.8, 1.2)
+    assert float(env.episode_stats(reset=False)[-1]) == 0 and dones < n // 4
