@@ -134,6 +134,26 @@ def main():
         sim_gbs = env_bytes / (step_ms * 1e-3) / 1e9
         flops = gemm_flops_per_iteration(N, T, E)
         stats = runner.env.episode_stats(reset=False).cpu().tolist()
+        # dominant kernel by GPU time = the update's fp32 GEMMs (rocprof: profiles/): time the largest one live, on the update's own buffers
+        B = T * N
+        tr = runner._critic_tr
+        xg, lg, og = tr.acts[0], tr.layers[1], torch.empty_like(tr.acts[1])
+        with torch.no_grad():
+            for _ in range(5):
+                torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(50):
+                torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
+            g1.record(); torch.cuda.synchronize()
+        gemm_us = g0.elapsed_time(g1) / 50 * 1e3
+        gemm_flop = 2.0 * B * lg.weight.shape[0] * lg.weight.shape[1]
+        gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "r01_b_env_pmc.json")
+        if N == 4096 and os.path.isfile(pmc):  # PMC counters are collected offline by tools/profile.sh (separate rocprofv3 passes)
+            k = json.load(open(pmc))["kernels"]["env_step_kernel"]
+            traffic = (k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
         out = {
             "metric": "env-steps/sec (whole node), PPO rollout+update, T1 4096 envs/GPU",
             "value": world * N * T * args.steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -143,14 +163,18 @@ def main():
                        "envs_per_gpu": N, "parallelism": f"dp{world}"},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms},
-            "roofline": {"kernel": "env_step_kernel (fused 10 substeps + task logic)", "bound": "hbm", "achieved": sim_gbs, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS, "traffic": None, "avg_launch_us": step_ms * 1e3,
-                         "algorithmic_bytes_per_launch": env_bytes},
+            "roofline": {"kernel": f"critic layer-2 forward GEMM [{B}x256]x[256x256] fp32 (hipBLASLt via torch.addmm; the update's GEMMs are ~60% of GPU time)",
+                         "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF, "traffic": None,
+                         "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop},
+            "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",
+                                  "achieved": sim_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                                  "avg_launch_us": step_ms * 1e3, "algorithmic_bytes_per_launch": env_bytes,
+                                  "note": "issue-latency-bound at 128 waves: SQ counters in profiles/ show VALU busy 73% of wave cycles at 4 cycles/instruction"},
             "roofline_update": {"bound": "mfma", "achieved": flops / (upd_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                                "note": "actor+critic GEMM flops of the update phase / update-phase time (which also holds GAE, loss, Adam)"},
+                                "frac": flops / (upd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
+                                "note": "all actor+critic GEMM flops of the update phase / update-phase wall time (which also holds GAE, loss, ELU, Adam)"},
             "nonfinite_resets": stats[-1],
         }
-        out["roofline_update"]["frac"] = out["roofline_update"]["achieved"] / MFMA_F32_PEAK_TF
         if not args.no_cpu_baseline and world == 1:
             try:
                 log("cpu baseline ...")
