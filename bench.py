@@ -147,7 +147,7 @@ def main():
                 torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
             g1.record(); torch.cuda.synchronize()
         gemm_us = g0.elapsed_time(g1) / 50 * 1e3
-        gemm_flop = 2.0 * B * lg.weight.shape[0] * lg.weight.shape[1]
+        gemm_flop = 2.0 * xg.shape[0] * lg.weight.shape[0] * lg.weight.shape[1]
         gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_b_env_pmc.json")
@@ -163,7 +163,7 @@ def main():
                        "envs_per_gpu": N, "parallelism": f"dp{world}"},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms},
-            "roofline": {"kernel": f"critic layer-2 forward GEMM [{B}x256]x[256x256] fp32 (hipBLASLt via torch.addmm; the update's GEMMs are ~60% of GPU time)",
+            "roofline": {"kernel": f"critic layer-2 forward GEMM [{xg.shape[0]}x256]x[256x256] fp32 (hipBLASLt via torch.addmm; the update's GEMMs are ~60% of GPU time)",
                          "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF, "traffic": None,
                          "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop},
             "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",

@@ -37,7 +37,7 @@ class MLPTrainer:
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
         self.max_split = max_split
         self.x = None
-        self._B = None
+        self._B = self._rows = None
 
     def _split(self, B):
         s = self.max_split
@@ -45,17 +45,20 @@ class MLPTrainer:
             s -= 1
         return s
 
-    def _alloc(self, B, dev):
-        """Static workspaces for batch size B (no allocator traffic inside the update loop; safe to use from a side stream)."""
-        self._B, self._S = B, self._split(B)
-        self.acts = [torch.empty(B, l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
+    def _alloc(self, rows, B, dev):
+        """Static workspaces (no allocator traffic inside the update loop; safe to use from a side stream).  `rows` >= B: extra inference-only
+        rows may ride along in the forward pass (the critic evaluates the T+1'th observation in the same GEMMs)."""
+        self._rows, self._B, self._S = rows, B, self._split(B)
+        self.acts = [torch.empty(rows, l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
         self.gin = [None] + [torch.empty(B, l.weight.shape[1], dtype=torch.float32, device=dev) for l in self.layers[1:]]
         self.cs = [torch.empty(((B + 127) // 128) * l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
         self.dw = [torch.empty(self._S, *l.weight.shape, dtype=torch.float32, device=dev) for l in self.layers]
 
-    def forward(self, x):
-        if self._B != x.shape[0]:
-            self._alloc(x.shape[0], x.device)
+    def forward(self, x, train_rows=None):
+        """x [rows, in].  The first `train_rows` rows (default: all) are the batch the backward pass differentiates."""
+        B = x.shape[0] if train_rows is None else train_rows
+        if self._B != B or self._rows != x.shape[0]:
+            self._alloc(x.shape[0], B, x.device)
         self.x, h = x, x
         last = len(self.layers) - 1
         for i, l in enumerate(self.layers):
@@ -73,7 +76,7 @@ class MLPTrainer:
         last = len(self.layers) - 1
         for i in range(last, -1, -1):
             l = self.layers[i]
-            a_in = self.acts[i - 1] if i > 0 else self.x
+            a_in = (self.acts[i - 1] if i > 0 else self.x)[:B]
             C_out, C_in = l.weight.shape
             if i < last:
                 _lib.check(lib.bg_elu_backward_colsum(B, C_out, _lib.ptr(g), _lib.ptr(self.acts[i]), _lib.ptr(l.bias.grad), _lib.ptr(self.cs[i]), stream),

@@ -245,8 +245,7 @@ class Runner:
         obs_flat = buf["obses"][:T].reshape(B, -1)
         act_flat = buf["actions"].reshape(B, A)
         torch.cat((buf["obses"], buf["privileged_obses"]), dim=-1, out=self._critic_in)
-        critic_in = self._critic_in[:T].reshape(B, -1)
-        critic_last = self._critic_in[T]
+        critic_all = self._critic_in.reshape((T + 1) * N, -1)  # rows [B, B+N) = the observation after the last step (last_values)
         with torch.no_grad():
             old_mu = self.model.actor(obs_flat)
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
@@ -260,11 +259,10 @@ class Runner:
             for _ in range(cfg["runner"]["mini_epochs"]):
                 side.wait_stream(main)  # parameters updated by the previous optimiser step
                 with torch.cuda.stream(side):
-                    values = self._critic_tr.forward(critic_in).squeeze(-1)
-                    last_values = self.model.critic(critic_last).squeeze(-1)
+                    v_all = self._critic_tr.forward(critic_all, train_rows=B).squeeze(-1)
+                    values, last_values = v_all[:B], v_all[B:]
                     gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
                         advantages=self._adv, returns=self._ret, sums=self._adv_sums)
-                    last_values.record_stream(side)
                 mu = self._actor_tr.forward(obs_flat)
                 main.wait_stream(side)
                 self.dp.sum_(self._adv_sums)
