@@ -176,6 +176,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
         float target[LEG_LINKS];
         for (int i = 0; i < LEG_LINKS; i++) {
             float a = act[(size_t)e * BG_NUM_DOFS + j0 + i];
+            if (((float_bits(a) >> 23) & 0xFFu) == 0xFFu) a = 0.f;  // NaN / Inf action -> 0 (bit test, see the non-finite guard below)
             a = fminf(fmaxf(a, -C.clip_actions), C.clip_actions);
             a6[i] = a;
             target[i] = C.default_dof_pos[j0 + i] + C.action_scale * a;
@@ -207,10 +208,19 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
 
     // ------------------------------------------------------------ non-finite guard (PhysX clamps internally; here a blown-up
     // state is treated as a termination so that one diverged env cannot poison its lane pair forever)
-    float chk = dot(bs.pos, bs.pos) + dot(bs.vlin, bs.vlin) + dot(bs.vang, bs.vang);
-    for (int i = 0; i < LEG_LINKS; i++) chk += ls.q[i] * ls.q[i] + ls.qd[i] * ls.qd[i];
-    float bad = (chk < 1.0e12f) ? 0.f : 1.f;  // false for NaN and Inf
-    bad = fmaxf(bad, x.swap(bad));
+    // (bit tests: the kernels are compiled with -ffinite-math-only, so floating-point comparisons may not be used to detect NaN / Inf)
+    uint32_t expo = 0;
+    {
+        const float st[13] = {bs.pos.e[0], bs.pos.e[1], bs.pos.e[2], bs.quat[0], bs.quat[1], bs.quat[2], bs.quat[3],
+                              bs.vlin.e[0], bs.vlin.e[1], bs.vlin.e[2], bs.vang.e[0], bs.vang.e[1], bs.vang.e[2]};
+        for (int k = 0; k < 13; k++) expo |= (uint32_t)(((float_bits(st[k]) >> 23) & 0xFFu) >= 0xE6u);  // |x| >= 2^103, Inf or NaN
+        for (int i = 0; i < LEG_LINKS; i++) {
+            expo |= (uint32_t)(((float_bits(ls.q[i]) >> 23) & 0xFFu) >= 0xE6u);
+            expo |= (uint32_t)(((float_bits(ls.qd[i]) >> 23) & 0xFFu) >= 0xE6u);
+        }
+    }
+    float bad = expo ? 1.f : 0.f;
+    bad = (bad != 0.f || x.swap(bad) != 0.f) ? 1.f : 0.f;
     if (bad != 0.f) {
         bs.pos = v3(0.f, 0.f, 1.f); bs.quat[0] = bs.quat[1] = bs.quat[2] = 0.f; bs.quat[3] = 1.f;
         bs.vlin = v3(0.f, 0.f, 0.f); bs.vang = v3(0.f, 0.f, 0.f);

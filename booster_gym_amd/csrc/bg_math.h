@@ -35,6 +35,13 @@ BG_HD float bg_sqrt(float x) {
     return sqrtf(x);
 #endif
 }
+BG_HD uint32_t float_bits(float x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __float_as_uint(x);
+#else
+    uint32_t u; __builtin_memcpy(&u, &x, 4); return u;
+#endif
+}
 BG_HD V3 v3(float x, float y, float z) { V3 r; r.e[0] = x; r.e[1] = y; r.e[2] = z; return r; }
 BG_HD V3 operator+(V3 a, V3 b) { return v3(a.e[0] + b.e[0], a.e[1] + b.e[1], a.e[2] + b.e[2]); }
 BG_HD V3 operator-(V3 a, V3 b) { return v3(a.e[0] - b.e[0], a.e[1] - b.e[1], a.e[2] - b.e[2]); }
