@@ -299,3 +299,18 @@ def test_trained_reference_policy_walks_in_the_oracle(dyn, flat_model):
         gp = np.fmod(gp + 0.002 * gf, 1.0)
     up = -tr.quat_rotate_inverse(root[3:7], np.array([0, 0, -1.0]))[2]
     assert root[0] > 2.0 and root[2] > 0.55 and up > 0.95, (root[:3], up)
+
+
+def test_cross_sim_player_gait_rule_and_walk():
+    """tools/play_oracle.py (headless play_mujoco.py:692-764 equivalent): gait-frequency rule and a 5 s commanded walk with the reference's trained actor."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("play_oracle", os.path.join(HERE, "..", "tools", "play_oracle.py"))
+    po = importlib.util.module_from_spec(spec); spec.loader.exec_module(po)
+    cm = {"gait_frequency": [1.0, 2.0]}
+    assert po.gait_frequency(np.zeros(3), cm) == 0.0 and po.gait_frequency(np.array([0.05, 0, 0]), cm) == 0.0
+    assert po.gait_frequency(np.array([0.5, 0, 0]), cm) == pytest.approx(1.5) and po.gait_frequency(np.array([2.0, 0, 0]), cm) == pytest.approx(2.0)
+    tr_ = po.rollout(po.load_actor(os.path.join(HERE, "golden", "t1_actor.npz")), [0.5, 0.0, 0.0], 5.0)
+    assert tr_[-1, 0] > 1.5 and tr_[:, 2].min() > 0.55
+    stand = po.rollout(po.load_actor(os.path.join(HERE, "golden", "t1_actor.npz")), [0.0, 0.0, 0.0], 3.0)
+    assert abs(stand[-1, 0]) < 0.5 and stand[:, 2].min() > 0.55  # zero command: gait frequency 0, the policy stands
