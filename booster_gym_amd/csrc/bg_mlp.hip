@@ -17,6 +17,7 @@ extern int bg_set_error(int code, const char* msg);
     } while (0)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's float4 struct blocked SROA here)
 
 // exp(x) - 1 through v_exp_f32: absolute error ~1e-7 on (-1, 0], far below fp32 activation noise; expm1f costs ~20 VALU per element
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
@@ -25,10 +26,55 @@ constexpr int FW_BM = 128;   // rows per workgroup (4 waves x 32 rows)
 constexpr int FW_KC = 32;    // k-chunk staged in LDS
 constexpr int FW_LDW = 36;   // LDS row stride (floats): 16-byte aligned rows, spreads the 16-byte reads over the banks
 
-template <int K, int N, bool ACT>
-__global__ __launch_bounds__(256, (N <= 128 ? 2 : 1)) void mlp_fwd_kernel(int M, const float* __restrict__ X, const float* __restrict__ W, const float* __restrict__ bias,
-                                                      float* __restrict__ Y) {
-    constexpr int NT = N / 32;
+// one k-chunk (32 k-values) of MFMAs for this wave: 4 sub-steps x NT column tiles x 4 MFMAs
+template <int NT>
+__device__ __forceinline__ void mfma_chunk(f32x16 (&acc)[NT], const f32x4 (&a4)[4], const float* sw /* &sW[buf][i * FW_LDW + 4 * h] */) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) {
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const f32x4 b4 = *reinterpret_cast<const f32x4*>(sw + t * 32 * FW_LDW + s * 8);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].x, b4.x, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].y, b4.y, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].z, b4.z, acc[t], 0, 0, 0);
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].w, b4.w, acc[t], 0, 0, 0);
+        }
+    }
+}
+template <int K, int LD4>
+__device__ __forceinline__ void load_w_chunk(f32x4 (&wreg)[LD4], const float* __restrict__ W, int kc) {
+#pragma unroll
+    for (int u = 0; u < LD4; u++) {
+        const int idx = threadIdx.x + u * 256, n = idx >> 3, c4 = idx & 7;
+        wreg[u] = *reinterpret_cast<const f32x4*>(W + (size_t)n * K + kc * FW_KC + 4 * c4);
+    }
+}
+template <int LD4>
+__device__ __forceinline__ void store_w_chunk(const f32x4 (&wreg)[LD4], float* sWbuf) {
+#pragma unroll
+    for (int u = 0; u < LD4; u++) {
+        const int idx = threadIdx.x + u * 256, n = idx >> 3, c4 = idx & 7;
+        *reinterpret_cast<f32x4*>(&sWbuf[n * FW_LDW + 4 * c4]) = wreg[u];
+    }
+}
+__device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, int kc) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) a4[s] = *reinterpret_cast<const f32x4*>(xrow + kc * FW_KC + s * 8);
+}
+
+// Software pipeline, two k-chunks per loop trip with two explicit register sets (no copies, no scratch): the global loads of chunk c+1 are
+// issued before the MFMAs of chunk c and first waited for after them, so HBM latency hides under 64 MFMAs (4096 cycles) of this wave alone.
+// Each workgroup computes 128 rows x 128 columns (blockIdx.y = column block): with N = 256 the two column blocks of a row slab run
+// concurrently and the second read of the X rows is served by L2 / Infinity Cache.
+template <int K, bool ACT>
+__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(int M, int ldy, const float* __restrict__ X, const float* __restrict__ Wfull,
+                                                         const float* __restrict__ biasfull, float* __restrict__ Yfull) {
+    constexpr int N = 128;
+    constexpr int NT = N / 32, CH = K / FW_KC, LD4 = N * (FW_KC / 4) / 256;
+    const float* __restrict__ W = Wfull + (size_t)blockIdx.y * N * K;
+    const float* __restrict__ bias = biasfull + blockIdx.y * N;
+    float* __restrict__ Y = Yfull + blockIdx.y * N;
+    static_assert(CH % 2 == 0, "K must be a multiple of 64");
     __shared__ __attribute__((aligned(16))) float sW[2][N * FW_LDW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int row = blockIdx.x * FW_BM + wave * 32 + i;
@@ -38,56 +84,27 @@ __global__ __launch_bounds__(256, (N <= 128 ? 2 : 1)) void mlp_fwd_kernel(int M,
     for (int t = 0; t < NT; t++)
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
-
-    // stage chunk 0 of W: N rows x 32 floats = N * 8 float4, 256 threads
-    constexpr int LD4 = N * (FW_KC / 4) / 256;  // float4 per thread per chunk
-    float4 wreg[LD4];
-    auto load_w = [&](int kc) {
-#pragma unroll
-        for (int u = 0; u < LD4; u++) {
-            const int idx = threadIdx.x + u * 256, n = idx >> 3, c4 = idx & 7;
-            wreg[u] = *reinterpret_cast<const float4*>(W + (size_t)n * K + kc * FW_KC + 4 * c4);
-        }
-    };
-    auto store_w = [&](int buf) {
-#pragma unroll
-        for (int u = 0; u < LD4; u++) {
-            const int idx = threadIdx.x + u * 256, n = idx >> 3, c4 = idx & 7;
-            *reinterpret_cast<float4*>(&sW[buf][n * FW_LDW + 4 * c4]) = wreg[u];
-        }
-    };
-    load_w(0);
-    store_w(0);
-    float4 a4[4];
-#pragma unroll
-    for (int s = 0; s < 4; s++) a4[s] = *reinterpret_cast<const float4*>(xrow + s * 8);
+    f32x4 wA[LD4], wB[LD4], aA[4], aB[4];
+    load_w_chunk<K, LD4>(wA, W, 0);
+    load_a_chunk(aA, xrow, 0);
+    store_w_chunk<LD4>(wA, sW[0]);
     __syncthreads();
-    constexpr int CH = K / FW_KC;
-    for (int kc = 0; kc < CH; kc++) {
-        const int buf = kc & 1;
-        float4 a_next[4];
-        if (kc + 1 < CH) {
-            load_w(kc + 1);
-#pragma unroll
-            for (int s = 0; s < 4; s++) a_next[s] = *reinterpret_cast<const float4*>(xrow + (kc + 1) * FW_KC + s * 8);
+    const float* sw0 = &sW[0][i * FW_LDW + 4 * h];
+    const float* sw1 = &sW[1][i * FW_LDW + 4 * h];
+    for (int kc = 0; kc < CH; kc += 2) {
+        // chunk kc on (aA, sW[0]); prefetch kc+1 into (aB, wB)
+        load_w_chunk<K, LD4>(wB, W, kc + 1);
+        load_a_chunk(aB, xrow, kc + 1);
+        mfma_chunk<NT>(acc, aA, sw0);
+        store_w_chunk<LD4>(wB, sW[1]);
+        __syncthreads();
+        // chunk kc+1 on (aB, sW[1]); prefetch kc+2 into (aA, wA)
+        if (kc + 2 < CH) {
+            load_w_chunk<K, LD4>(wA, W, kc + 2);
+            load_a_chunk(aA, xrow, kc + 2);
         }
-        const float* sw = &sW[buf][i * FW_LDW + 4 * h];
-#pragma unroll
-        for (int s = 0; s < 4; s++) {
-#pragma unroll
-            for (int t = 0; t < NT; t++) {
-                const float4 b4 = *reinterpret_cast<const float4*>(sw + t * 32 * FW_LDW + s * 8);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].x, b4.x, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].y, b4.y, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].z, b4.z, acc[t], 0, 0, 0);
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s].w, b4.w, acc[t], 0, 0, 0);
-            }
-        }
-        if (kc + 1 < CH) {
-            store_w(buf ^ 1);
-#pragma unroll
-            for (int s = 0; s < 4; s++) a4[s] = a_next[s];
-        }
+        mfma_chunk<NT>(acc, aB, sw1);
+        if (kc + 2 < CH) store_w_chunk<LD4>(wA, sW[0]);
         __syncthreads();
     }
     // epilogue: C layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
@@ -100,7 +117,7 @@ __global__ __launch_bounds__(256, (N <= 128 ? 2 : 1)) void mlp_fwd_kernel(int M,
             const int rr = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
             float v = acc[t][r] + bv;
             if (ACT) v = elu_f(v);
-            if (rr < M) Y[(size_t)rr * N + t * 32 + i] = v;
+            if (rr < M) Y[(size_t)rr * ldy + t * 32 + i] = v;
         }
     }
 }
@@ -109,18 +126,19 @@ extern "C" int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float
                                     void* stream) {
     if (M <= 0 || !X || !W || !bias || !Y) return bg_set_error(-1, "bg_mlp_layer_forward: bad argument");
     if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15) != 0) return bg_set_error(-1, "bg_mlp_layer_forward: pointers must be 16-byte aligned");
-    dim3 grid((M + FW_BM - 1) / FW_BM), block(256);
+    if (N % 128 != 0 || N > 1024) return bg_set_error(-4, "bg_mlp_layer_forward: unsupported N (multiples of 128 up to 1024)");
+    dim3 grid((M + FW_BM - 1) / FW_BM, N / 128), block(256);
     hipStream_t st = (hipStream_t)stream;
-#define BG_FWD(KK, NN)                                                                                                         \
-    if (K == KK && N == NN) {                                                                                                  \
-        if (elu) hipLaunchKernelGGL((mlp_fwd_kernel<KK, NN, true>), grid, block, 0, st, M, X, W, bias, Y);                     \
-        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, NN, false>), grid, block, 0, st, M, X, W, bias, Y);                        \
-        HIP_OK(hipGetLastError());                                                                                             \
-        return 0;                                                                                                              \
+#define BG_FWD(KK)                                                                                                      \
+    if (K == KK) {                                                                                                      \
+        if (elu) hipLaunchKernelGGL((mlp_fwd_kernel<KK, true>), grid, block, 0, st, M, N, X, W, bias, Y);               \
+        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, false>), grid, block, 0, st, M, N, X, W, bias, Y);                  \
+        HIP_OK(hipGetLastError());                                                                                      \
+        return 0;                                                                                                       \
     }
-    BG_FWD(256, 256)
-    BG_FWD(256, 128)
-    BG_FWD(128, 128)
+    BG_FWD(256)
+    BG_FWD(128)
+    BG_FWD(64)
 #undef BG_FWD
-    return bg_set_error(-4, "bg_mlp_layer_forward: unsupported (K, N); supported: (256,256) (256,128) (128,128)");
+    return bg_set_error(-4, "bg_mlp_layer_forward: unsupported K (64, 128, 256)");
 }

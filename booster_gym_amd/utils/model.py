@@ -33,10 +33,14 @@ class MLPTrainer:
       * gradients are WRITTEN into the parameters' `.grad` views of the flat Adam buffer (no AccumulateGrad adds, no zero_grad).
     """
 
-    # (K, N) of hidden layers routed to the hand-written fused MFMA layer (bg_mlp.hip).  Measured on MI355X (tools/mlp_probe.py): standalone it beats
-    # addmm + elu_ for (128,128) 41.7 vs 56.2 us and (256,128) 73.2 vs 76.5 us, loses for (256,256) 203 vs 154 us; inside the two-stream update
-    # loop the total did not improve (31.1 vs 30.8 ms), so the default stays on the library GEMM.  BG_FUSED_MLP=1 turns the two winning shapes on.
-    FUSED_SHAPES = {(128, 128), (256, 128)} if __import__("os").environ.get("BG_FUSED_MLP", "0") == "1" else set()
+    # Hidden layers with K in {64, 128, 256} and N % 128 == 0 run on the hand-written fused fp32-MFMA layer (bg_mlp.hip: bias + ELU in the GEMM
+    # epilogue).  Measured on MI355X at M = 98,304 (tools/mlp_probe.py): 131.8 vs 151.3 us (256x256), 63.9 vs 76.3 us (256x128), 37.5 vs 55.8 us
+    # (128x128) against hipBLASLt addmm + elu_.  BG_FUSED_MLP=0 falls back to the library GEMM + elementwise ELU.
+    FUSED = __import__("os").environ.get("BG_FUSED_MLP", "1") == "1"
+
+    @classmethod
+    def _fusable(cls, k_in, n_out):
+        return cls.FUSED and k_in in (64, 128, 256) and n_out % 128 == 0
 
     def __init__(self, seq, max_split=32):
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
@@ -69,7 +73,7 @@ class MLPTrainer:
         lib, stream = _lib.load(), _lib.current_stream_ptr()
         for i, l in enumerate(self.layers):
             n_out, k_in = l.weight.shape
-            if i < last and (k_in, n_out) in self.FUSED_SHAPES:
+            if i < last and self._fusable(k_in, n_out):
                 # hand-written fp32-MFMA layer with bias + ELU in the epilogue (bg_mlp.hip); measured faster than addmm + elu_ for these shapes
                 _lib.check(lib.bg_mlp_layer_forward(h.shape[0], k_in, n_out, _lib.ptr(h), _lib.ptr(l.weight), _lib.ptr(l.bias), _lib.ptr(self.acts[i]), 1,
                                                     stream), "bg_mlp_layer_forward")

@@ -187,7 +187,7 @@ int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_mi
 int bg_elu_backward_colsum(int32_t B, int32_t C, float* grad, const float* act, float* colsum, float* scratch, void* stream);
 
 /* Fused MLP layer forward: Y [M][N] = act(X [M][K] . W[N][K]^T + bias[N]) in fp32 MFMA with bias + ELU in the GEMM epilogue
- * (utils/model.py:9-26 Linear + ELU).  Supported (K, N): (256,256) (256,128) (128,128); other shapes return -4 (caller uses the library GEMM). */
+ * (utils/model.py:9-26 Linear + ELU).  Supported: K in {64, 128, 256}, N a multiple of 128; other shapes return -4 (caller uses the library GEMM). */
 int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const float* W, const float* bias, float* Y, int32_t elu, void* stream);
 
 const char* bg_last_error(void);

@@ -8,7 +8,7 @@ DEV = "cuda:0"
 
 
 @pytest.mark.parametrize("M,K,N,elu", [(98304, 256, 256, True), (102400, 256, 128, True), (98304, 128, 128, True), (4096, 256, 256, False), (1000, 128, 128, True),
-                                       (130, 256, 128, True)])
+                                       (130, 256, 128, True), (4096, 64, 384, True)])
 def test_mlp_layer_forward_matches_torch(M, K, N, elu):
     from booster_gym_amd import _lib
 
