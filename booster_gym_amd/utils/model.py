@@ -46,7 +46,7 @@ class MLPTrainer:
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
         self.max_split = max_split
         self.x = None
-        self._B = self._rows = None
+        self._B = self._rows = self._kin = None
 
     def _split(self, B):
         s = self.max_split
@@ -54,32 +54,41 @@ class MLPTrainer:
             s -= 1
         return s
 
-    def _alloc(self, rows, B, dev):
+    def _alloc(self, rows, B, dev, k_in):
         """Static workspaces (no allocator traffic inside the update loop; safe to use from a side stream).  `rows` >= B: extra inference-only
-        rows may ride along in the forward pass (the critic evaluates the T+1'th observation in the same GEMMs)."""
-        self._rows, self._B, self._S = rows, B, self._split(B)
+        rows may ride along in the forward pass (the critic evaluates the T+1'th observation in the same GEMMs).  `k_in` > in_features of
+        the first layer means the caller zero-padded the input columns (61 -> 64, 47 -> 64) so that the first layer, too, runs on the fused kernel."""
+        self._rows, self._B, self._S, self._kin = rows, B, self._split(B), k_in
         self.acts = [torch.empty(rows, l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
         self.gin = [None] + [torch.empty(B, l.weight.shape[1], dtype=torch.float32, device=dev) for l in self.layers[1:]]
         self.cs = [torch.empty(((B + 127) // 128) * l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
-        self.dw = [torch.empty(self._S, *l.weight.shape, dtype=torch.float32, device=dev) for l in self.layers]
+        self.dw = [torch.empty(self._S, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1], dtype=torch.float32, device=dev)
+                   for i, l in enumerate(self.layers)]
+        l0 = self.layers[0]
+        self.w0pad = torch.zeros(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if k_in != l0.weight.shape[1] else None
+        self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
 
     def forward(self, x, train_rows=None):
-        """x [rows, in].  The first `train_rows` rows (default: all) are the batch the backward pass differentiates."""
+        """x [rows, in (possibly zero-padded)].  The first `train_rows` rows (default: all) are the batch the backward pass differentiates."""
         B = x.shape[0] if train_rows is None else train_rows
-        if self._B != B or self._rows != x.shape[0]:
-            self._alloc(x.shape[0], B, x.device)
+        if self._B != B or self._rows != x.shape[0] or self._kin != x.shape[1]:
+            self._alloc(x.shape[0], B, x.device, x.shape[1])
         self.x, h = x, x
         last = len(self.layers) - 1
         lib, stream = _lib.load(), _lib.current_stream_ptr()
         for i, l in enumerate(self.layers):
             n_out, k_in = l.weight.shape
+            w = l.weight
+            if i == 0 and self.w0pad is not None:
+                self.w0pad[:, :k_in].copy_(l.weight)  # weights change every optimiser step; 16k floats
+                w, k_in = self.w0pad, self._kin
             if i < last and self._fusable(k_in, n_out):
-                # hand-written fp32-MFMA layer with bias + ELU in the epilogue (bg_mlp.hip); measured faster than addmm + elu_ for these shapes
-                _lib.check(lib.bg_mlp_layer_forward(h.shape[0], k_in, n_out, _lib.ptr(h), _lib.ptr(l.weight), _lib.ptr(l.bias), _lib.ptr(self.acts[i]), 1,
+                # hand-written fp32-MFMA layer with bias + ELU in the epilogue (bg_mlp.hip)
+                _lib.check(lib.bg_mlp_layer_forward(h.shape[0], k_in, n_out, _lib.ptr(h), _lib.ptr(w), _lib.ptr(l.bias), _lib.ptr(self.acts[i]), 1,
                                                     stream), "bg_mlp_layer_forward")
                 h = self.acts[i]
                 continue
-            torch.addmm(l.bias, h, l.weight.t(), out=self.acts[i])
+            torch.addmm(l.bias, h, w.t(), out=self.acts[i])
             h = self.acts[i]
             if i < last:
                 torch.nn.functional.elu_(h)
@@ -100,8 +109,13 @@ class MLPTrainer:
                            "bg_elu_backward_colsum")
             else:  # linear output layer (12 or 1 columns): a plain column sum
                 torch.sum(g, dim=0, out=l.bias.grad)
-            torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
-            torch.sum(self.dw[i], dim=0, out=l.weight.grad)
+            if i == 0 and self.w0pad is not None:  # padded input columns: their gradient columns are dropped
+                torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, self._kin), out=self.dw[0])
+                torch.sum(self.dw[0], dim=0, out=self.dw0sum)
+                l.weight.grad.copy_(self.dw0sum[:, :C_in])
+            else:
+                torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
+                torch.sum(self.dw[i], dim=0, out=l.weight.grad)
             if i > 0:
                 torch.mm(g, l.weight, out=self.gin[i])
                 g = self.gin[i]

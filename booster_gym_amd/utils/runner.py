@@ -150,7 +150,10 @@ class Runner:
         self.buffer.add_buffer("time_outs", (), dtype=torch.bool)
         B, A = T * N, self.env.num_actions
         dev = self.device
-        self._critic_in = torch.zeros(T + 1, N, self.env.num_obs + self.env.num_privileged_obs, device=dev)
+        # network inputs with the feature dimension zero-padded to 64 (47 -> 64, 61 -> 64) so that the first layers run on the fused MFMA kernel
+        self._pad_in = 64 if MLPTrainer.FUSED else None
+        self._critic_in = torch.zeros(T + 1, N, self._pad_in or (self.env.num_obs + self.env.num_privileged_obs), device=dev)
+        self._actor_in = torch.zeros(T, N, self._pad_in, device=dev) if self._pad_in else None
         self._adv = torch.zeros(T, N, device=dev)
         self._ret = torch.zeros(T, N, device=dev)
         self._adv_sums = torch.zeros(3, dtype=torch.float64, device=dev)
@@ -242,12 +245,18 @@ class Runner:
         T, N = cfg["runner"]["horizon_length"], self.env.num_envs
         B, A = T * N, self.env.num_actions
         alg = cfg["algorithm"]
-        obs_flat = buf["obses"][:T].reshape(B, -1)
         act_flat = buf["actions"].reshape(B, A)
-        torch.cat((buf["obses"], buf["privileged_obses"]), dim=-1, out=self._critic_in)
+        no, npv = self.env.num_obs, self.env.num_privileged_obs
+        self._critic_in[:, :, :no].copy_(buf["obses"])
+        self._critic_in[:, :, no : no + npv].copy_(buf["privileged_obses"])
+        if self._actor_in is not None:
+            self._actor_in[:, :, :no].copy_(buf["obses"][:T])
+            obs_flat = self._actor_in.reshape(B, -1)
+        else:
+            obs_flat = buf["obses"][:T].reshape(B, -1)
         critic_all = self._critic_in.reshape((T + 1) * N, -1)  # rows [B, B+N) = the observation after the last step (last_values)
         with torch.no_grad():
-            old_mu = self.model.actor(obs_flat)
+            old_mu = self.model.actor(buf["obses"][:T].reshape(B, -1))
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
             gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
         self._stats_acc.zero_()
