@@ -70,7 +70,7 @@ SYMBOLS = [
     "bg_model_create", "bg_model_get", "bg_model_destroy", "bg_env_create", "bg_env_destroy", "bg_env_set_heightfield",
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
     "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
-    "bg_env_forward_dynamics", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_elu_backward_colsum", "bg_mlp_layer_forward",
+    "bg_env_forward_dynamics", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward",
     "bg_last_error", "bg_version",
 ]
 
@@ -119,6 +119,7 @@ def load():
         "bg_adapt_lr": (i32, [vp, f32, f32, f32, f32, vp, vp]),
         "bg_elu_backward_colsum": (i32, [i32, i32, vp, vp, vp, vp, vp]),
         "bg_mlp_layer_forward": (i32, [i32, i32, i32, vp, vp, vp, vp, i32, vp]),
+        "bg_mlp_layer_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "bg_last_error": (C.c_char_p, []),
         "bg_version": (C.c_char_p, []),
     }

@@ -66,13 +66,18 @@ __device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, 
 // issued before the MFMAs of chunk c and first waited for after them, so HBM latency hides under 64 MFMAs (4096 cycles) of this wave alone.
 // Each workgroup computes 128 rows x 128 columns (blockIdx.y = column block): with N = 256 the two column blocks of a row slab run
 // concurrently and the second read of the X rows is served by L2 / Infinity Cache.
-template <int K, bool ACT>
+// EPI 0: Y = X W^T + bias          EPI 1: Y = elu(X W^T + bias)                                   (forward)
+// EPI 2: Y = (X W^T) * elu'(aux), aux = the layer's OUTPUT activations (1 if aux > 0 else aux + 1), plus per-workgroup column sums of Y
+//        written to colpart[blockIdx.x][ldy]  (backward: X = dL/dz of the layer above, W = its transposed weight, Y = dL/dz of this layer,
+//        column sums = this layer's bias gradient)
+template <int K, int EPI>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(int M, int ldy, const float* __restrict__ X, const float* __restrict__ Wfull,
-                                                         const float* __restrict__ biasfull, float* __restrict__ Yfull) {
+                                                         const float* __restrict__ biasfull, float* __restrict__ Yfull,
+                                                         const float* __restrict__ auxfull, float* __restrict__ colpart) {
     constexpr int N = 128;
     constexpr int NT = N / 32, CH = K / FW_KC, LD4 = N * (FW_KC / 4) / 256;
     const float* __restrict__ W = Wfull + (size_t)blockIdx.y * N * K;
-    const float* __restrict__ bias = biasfull + blockIdx.y * N;
+    const float* __restrict__ bias = EPI <= 1 ? biasfull + blockIdx.y * N : nullptr;
     float* __restrict__ Y = Yfull + blockIdx.y * N;
     static_assert(CH % 2 == 0, "K must be a multiple of 64");
     __shared__ __attribute__((aligned(16))) float sW[2][N * FW_LDW];
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(int M, int ldy, const f
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     f32x4 wA[LD4], wB[LD4], aA[4], aB[4];
+    float auxv[EPI == 2 ? NT : 1][16];
     load_w_chunk<K, LD4>(wA, W, 0);
     load_a_chunk(aA, xrow, 0);
     store_w_chunk<LD4>(wA, sW[0]);
@@ -102,6 +108,17 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(int M, int ldy, const f
         if (kc + 2 < CH) {
             load_w_chunk<K, LD4>(wA, W, kc + 2);
             load_a_chunk(aA, xrow, kc + 2);
+        } else if constexpr (EPI == 2) {
+            // last chunk: fetch the epilogue's elu' operand now, so that its HBM latency hides under the final 64 MFMAs
+            const float* __restrict__ auxp = auxfull + blockIdx.y * N;
+            const int rb = blockIdx.x * FW_BM + wave * 32;
+#pragma unroll
+            for (int t = 0; t < NT; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int rr = rb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    auxv[t][r] = auxp[(size_t)(rr < M ? rr : M - 1) * ldy + t * 32 + i];
+                }
         }
         mfma_chunk<NT>(acc, aB, sw1);
         if (kc + 2 < CH) store_w_chunk<LD4>(wA, sW[0]);
@@ -109,17 +126,53 @@ __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(int M, int ldy, const f
     }
     // epilogue: C layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int rbase = blockIdx.x * FW_BM + wave * 32;
+    if constexpr (EPI <= 1) {
 #pragma unroll
-    for (int t = 0; t < NT; t++) {
-        const float bv = bias[t * 32 + i];
+        for (int t = 0; t < NT; t++) {
+            const float bv = bias[t * 32 + i];
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int rr = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-            float v = acc[t][r] + bv;
-            if (ACT) v = elu_f(v);
-            if (rr < M) Y[(size_t)rr * ldy + t * 32 + i] = v;
+            for (int r = 0; r < 16; r++) {
+                const int rr = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                float v = acc[t][r] + bv;
+                if (EPI == 1) v = elu_f(v);
+                if (rr < M) Y[(size_t)rr * ldy + t * 32 + i] = v;
+            }
         }
+    } else {
+        float* csum = &sW[0][0];  // reuse the weight staging buffer: [4 waves][128 columns]
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            float cs = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int rr = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (rr < M) {
+                    const float a = auxv[t][r];
+                    const float v = acc[t][r] * (a > 0.f ? 1.0f : a + 1.0f);
+                    Y[(size_t)rr * ldy + t * 32 + i] = v;
+                    cs += v;
+                }
+            }
+            cs += __shfl_xor(cs, 32);  // the two lane halves hold different rows of the same column
+            if (h == 0) csum[wave * N + t * 32 + i] = cs;
+        }
+        __syncthreads();
+        if (threadIdx.x < N)
+            colpart[(size_t)blockIdx.x * ldy + blockIdx.y * N + threadIdx.x] =
+                csum[threadIdx.x] + csum[N + threadIdx.x] + csum[2 * N + threadIdx.x] + csum[3 * N + threadIdx.x];
     }
+}
+
+__global__ __launch_bounds__(256) void mlp_colsum_finish_kernel(int nb, int C, const float* __restrict__ partial, float* __restrict__ out) {
+    __shared__ float sm[256];
+    const int c = blockIdx.x;
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < nb; b += blockDim.x) acc += partial[(size_t)b * C + c];
+    sm[threadIdx.x] = acc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) { if ((int)threadIdx.x < o) sm[threadIdx.x] += sm[threadIdx.x + o]; __syncthreads(); }
+    if (threadIdx.x == 0) out[c] = sm[0];
 }
 
 extern "C" int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const float* W, const float* bias, float* Y, int32_t elu,
@@ -131,8 +184,8 @@ extern "C" int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float
     hipStream_t st = (hipStream_t)stream;
 #define BG_FWD(KK)                                                                                                      \
     if (K == KK) {                                                                                                      \
-        if (elu) hipLaunchKernelGGL((mlp_fwd_kernel<KK, true>), grid, block, 0, st, M, N, X, W, bias, Y);               \
-        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, false>), grid, block, 0, st, M, N, X, W, bias, Y);                  \
+        if (elu) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 1>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr); \
+        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, 0>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr);    \
         HIP_OK(hipGetLastError());                                                                                      \
         return 0;                                                                                                       \
     }
@@ -141,4 +194,26 @@ extern "C" int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float
     BG_FWD(64)
 #undef BG_FWD
     return bg_set_error(-4, "bg_mlp_layer_forward: unsupported K (64, 128, 256)");
+}
+
+extern "C" int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const float* G, const float* Wt, const float* act_below, float* Gout,
+                                     float* bias_grad_below, float* scratch, void* stream) {
+    if (M <= 0 || !G || !Wt || !act_below || !Gout || !bias_grad_below || !scratch) return bg_set_error(-1, "bg_mlp_layer_backward: bad argument");
+    if ((((uintptr_t)G | (uintptr_t)Wt | (uintptr_t)Gout | (uintptr_t)act_below) & 15) != 0)
+        return bg_set_error(-1, "bg_mlp_layer_backward: pointers must be 16-byte aligned");
+    if (N % 128 != 0 || N > 1024) return bg_set_error(-4, "bg_mlp_layer_backward: unsupported N (multiples of 128 up to 1024)");
+    const int nb = (M + FW_BM - 1) / FW_BM;
+    dim3 grid(nb, N / 128), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define BG_BWD(KK)                                                                                                                \
+    if (K == KK) {                                                                                                                \
+        hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch);           \
+        hipLaunchKernelGGL(mlp_colsum_finish_kernel, dim3(N), dim3(256), 0, st, nb, N, scratch, bias_grad_below);                  \
+        HIP_OK(hipGetLastError());                                                                                                \
+        return 0;                                                                                                                 \
+    }
+    BG_BWD(256)
+    BG_BWD(128)
+#undef BG_BWD
+    return bg_set_error(-4, "bg_mlp_layer_backward: unsupported K (128, 256)");
 }

@@ -64,6 +64,7 @@ class MLPTrainer:
         self.cs = [torch.empty(((B + 127) // 128) * l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
         self.dw = [torch.empty(self._S, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1], dtype=torch.float32, device=dev)
                    for i, l in enumerate(self.layers)]
+        self.wt = [None] * len(self.layers)  # transposed weights for the fused backward kernel
         l0 = self.layers[0]
         self.w0pad = torch.zeros(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if k_in != l0.weight.shape[1] else None
         self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
@@ -95,20 +96,20 @@ class MLPTrainer:
         return h
 
     def backward(self, grad_out):
-        """grad_out [B, out] is consumed (modified in place).  Fills weight.grad / bias.grad of every layer."""
+        """grad_out [B, out] is consumed (modified in place).  Fills weight.grad / bias.grad of every layer.
+
+        g always holds dL/dz of layer i (z = pre-activation).  For the linear output layer that is grad_out itself; going down, the fused
+        kernel bg_mlp_layer_backward produces dL/dz of layer i-1 = (g W_i) * elu'(a_{i-1}) together with layer i-1's bias gradient in one
+        pass; the skinny output layers (12 / 1 columns) use torch.mm + the fused ELU-backward/column-sum kernel instead."""
         lib = _lib.load()
         g, B, S = grad_out, self._B, self._S
         stream = _lib.current_stream_ptr()
         last = len(self.layers) - 1
+        torch.sum(g, dim=0, out=self.layers[last].bias.grad)  # linear output layer: plain column sum
         for i in range(last, -1, -1):
             l = self.layers[i]
             a_in = (self.acts[i - 1] if i > 0 else self.x)[:B]
             C_out, C_in = l.weight.shape
-            if i < last:
-                _lib.check(lib.bg_elu_backward_colsum(B, C_out, _lib.ptr(g), _lib.ptr(self.acts[i]), _lib.ptr(l.bias.grad), _lib.ptr(self.cs[i]), stream),
-                           "bg_elu_backward_colsum")
-            else:  # linear output layer (12 or 1 columns): a plain column sum
-                torch.sum(g, dim=0, out=l.bias.grad)
             if i == 0 and self.w0pad is not None:  # padded input columns: their gradient columns are dropped
                 torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, self._kin), out=self.dw[0])
                 torch.sum(self.dw[0], dim=0, out=self.dw0sum)
@@ -117,7 +118,17 @@ class MLPTrainer:
                 torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
                 torch.sum(self.dw[i], dim=0, out=l.weight.grad)
             if i > 0:
-                torch.mm(g, l.weight, out=self.gin[i])
+                below = self.layers[i - 1]
+                if self.FUSED and C_out in (128, 256) and C_in % 128 == 0:
+                    if self.wt[i] is None:
+                        self.wt[i] = torch.empty(C_in, C_out, dtype=torch.float32, device=g.device)
+                    self.wt[i].copy_(l.weight.t())
+                    _lib.check(lib.bg_mlp_layer_backward(B, C_out, C_in, _lib.ptr(g), _lib.ptr(self.wt[i]), _lib.ptr(a_in), _lib.ptr(self.gin[i]),
+                                                         _lib.ptr(below.bias.grad), _lib.ptr(self.cs[i - 1]), stream), "bg_mlp_layer_backward")
+                else:
+                    torch.mm(g, l.weight, out=self.gin[i])
+                    _lib.check(lib.bg_elu_backward_colsum(B, C_in, _lib.ptr(self.gin[i]), _lib.ptr(a_in), _lib.ptr(below.bias.grad), _lib.ptr(self.cs[i - 1]),
+                                                          stream), "bg_elu_backward_colsum")
                 g = self.gin[i]
 
 

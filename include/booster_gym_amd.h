@@ -190,6 +190,13 @@ int bg_elu_backward_colsum(int32_t B, int32_t C, float* grad, const float* act, 
  * (utils/model.py:9-26 Linear + ELU).  Supported: K in {64, 128, 256}, N a multiple of 128; other shapes return -4 (caller uses the library GEMM). */
 int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const float* W, const float* bias, float* Y, int32_t elu, void* stream);
 
+/* Fused MLP layer backward through one Linear and the ELU below it:  Gout [M][N] = (G [M][K] . Wt[N][K]^T) * elu'(act_below [M][N]) and
+ * bias_grad_below [N] = column sums of Gout.  G = dL/dz of the upper layer (K = its width), Wt = that layer's weight TRANSPOSED to [N][K]
+ * (N = width of the layer below), act_below = the lower layer's output activations.  scratch: ceil(M/128) * N floats.
+ * Replaces torch.mm(G, W) + elu_backward + the bias-gradient reduction.  K in {128, 256}, N a multiple of 128; otherwise -4. */
+int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const float* G, const float* Wt, const float* act_below, float* Gout,
+                          float* bias_grad_below, float* scratch, void* stream);
+
 const char* bg_last_error(void);
 const char* bg_version(void);
 

@@ -38,3 +38,28 @@ def test_mlp_layer_forward_rejects_unsupported_shapes():
     x = torch.zeros(128, 61, device=DEV); w = torch.zeros(256, 61, device=DEV); b = torch.zeros(256, device=DEV); y = torch.zeros(128, 256, device=DEV)
     rc = _lib.load().bg_mlp_layer_forward(128, 61, 256, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), 1, _lib.current_stream_ptr())
     assert rc == -4 and b"unsupported" in _lib.load().bg_last_error()
+
+
+@pytest.mark.parametrize("M,K,N", [(98304, 256, 256), (98304, 128, 256), (98304, 128, 128), (1000, 256, 128), (130, 128, 384)])
+def test_mlp_layer_backward_matches_torch(M, K, N):
+    """Gout = (G W) * elu'(act_below), bias_grad_below = column sums; W is [K][N] in torch layout (out = K, in = N), the kernel takes W^T."""
+    from booster_gym_amd import _lib
+
+    torch.manual_seed(M + 3 * K + N)
+    G = torch.randn(M, K, device=DEV)
+    W = torch.randn(K, N, device=DEV) * (1.0 / K**0.5)
+    W[2, 7] = 5.0; W[K - 1, 0] = -4.0
+    z = torch.randn(M, N, device=DEV)
+    act = torch.nn.functional.elu(z)
+    ref = (G.double() @ W.double()) * torch.where(z > 0, torch.ones_like(z), act + 1.0).double()
+    Wt = W.t().contiguous()
+    out = torch.full((M, N), float("nan"), device=DEV)
+    bg = torch.zeros(N, device=DEV)
+    scratch = torch.empty(((M + 127) // 128) * N, device=DEV)
+    _lib.check(_lib.load().bg_mlp_layer_backward(M, K, N, _lib.ptr(G), _lib.ptr(Wt), _lib.ptr(act), _lib.ptr(out), _lib.ptr(bg), _lib.ptr(scratch),
+                                                 _lib.current_stream_ptr()))
+    ref32 = (G @ W) * torch.where(z > 0, torch.ones_like(z), act + 1.0)
+    err, err_t = (out.double() - ref).abs().max().item(), (ref32.double() - ref).abs().max().item()
+    assert torch.isfinite(out).all() and err <= max(4 * err_t, 1e-5), (err, err_t)
+    cs = ref.sum(0)
+    assert torch.allclose(bg.double(), cs, rtol=1e-4, atol=2e-3 * max(1.0, cs.abs().max().item()))

@@ -18,3 +18,15 @@ for K, N in [(256, 256), (256, 128), (128, 128)]:
     t_gemm = bench(lambda: torch.addmm(b, x, w.t(), out=y))
     t_mine = bench(lambda: lib.bg_mlp_layer_forward(M, K, N, _lib.ptr(x), _lib.ptr(w), _lib.ptr(b), _lib.ptr(y), 1, _lib.current_stream_ptr()))
     print(f"K={K} N={N}: torch addmm {t_gemm:7.1f} us ({fl/t_gemm/1e6:5.1f} TF/s)  addmm+elu_ {t_lib:7.1f} us   fused MFMA kernel {t_mine:7.1f} us ({fl/t_mine/1e6:5.1f} TF/s)")
+print("backward: Gout = (G W) * elu'(a), + column sums")
+for K, N in [(256, 256), (128, 256), (128, 128)]:
+    G = torch.randn(M, K, device=dev); W = torch.randn(K, N, device=dev) * 0.06; a = torch.nn.functional.elu(torch.randn(M, N, device=dev))
+    Wt = W.t().contiguous(); out = torch.empty(M, N, device=dev); bgd = torch.zeros(N, device=dev); scr = torch.empty(((M + 127) // 128) * N, device=dev)
+    def lib_path():
+        torch.mm(G, W, out=out)
+        lib.bg_elu_backward_colsum(M, N, _lib.ptr(out), _lib.ptr(a), _lib.ptr(bgd), _lib.ptr(scr), _lib.current_stream_ptr())
+    t_lib = bench(lib_path)
+    t_mm = bench(lambda: torch.mm(G, W, out=out))
+    t_mine = bench(lambda: lib.bg_mlp_layer_backward(M, K, N, _lib.ptr(G), _lib.ptr(Wt), _lib.ptr(a), _lib.ptr(out), _lib.ptr(bgd), _lib.ptr(scr), _lib.current_stream_ptr()))
+    fl = 2.0 * M * K * N
+    print(f"K={K} N={N}: torch mm {t_mm:7.1f} us  mm+elu_bwd_colsum {t_lib:7.1f} us   fused bwd kernel {t_mine:7.1f} us ({fl/t_mine/1e6:5.1f} TF/s)")
