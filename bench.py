@@ -111,6 +111,7 @@ def main():
         step_events.append((e0, e1))
 
     runner.env.step_to = timed_step_to
+    runner._critic_tr.timed_layer = 1  # critic 256 -> 256 hidden layer: the single largest kernel of the update
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -134,23 +135,31 @@ def main():
         sim_gbs = env_bytes / (step_ms * 1e-3) / 1e9
         flops = gemm_flops_per_iteration(N, T, E)
         stats = runner.env.episode_stats(reset=False).cpu().tolist()
-        # dominant kernel by GPU time = the update's fp32 GEMMs (rocprof: profiles/): time the largest one live, on the update's own buffers
-        B = T * N
-        tr = runner._critic_tr
-        xg, lg, og = tr.acts[0], tr.layers[1], torch.empty_like(tr.acts[1])
-        with torch.no_grad():
-            for _ in range(5):
-                torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record()
-            for _ in range(50):
-                torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
-            g1.record(); torch.cuda.synchronize()
-        gemm_us = g0.elapsed_time(g1) / 50 * 1e3
-        gemm_flop = 2.0 * xg.shape[0] * lg.weight.shape[0] * lg.weight.shape[1]
+        # dominant kernel by GPU time (rocprof, profiles/): the hand-written fused Linear+ELU layer mlp_fwd_kernel<256,1>; its largest instance
+        # (critic 256 -> 256, [rows x 256] x [256 x 256]) is timed inside the timed region with HIP events on the stream it is launched on
+        ev = runner._critic_tr.timed_events
+        if ev:
+            gemm_us = sum(a.elapsed_time(b) for a, b, *_ in ev) / len(ev) * 1e3
+            rows_g, kg, ng = ev[0][2], ev[0][3], ev[0][4]
+            gemm_name = f"mlp_fwd_kernel<256,1>: fused Linear+bias+ELU, critic layer 2, [{rows_g}x{kg}]x[{kg}x{ng}] fp32 MFMA 32x32x2 (hand-written HIP, bg_mlp.hip)"
+        else:  # BG_FUSED_MLP=0: the library GEMM of the same layer
+            tr = runner._critic_tr
+            xg, lg, og = tr.acts[0], tr.layers[1], torch.empty_like(tr.acts[1])
+            with torch.no_grad():
+                for _ in range(5):
+                    torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                for _ in range(50):
+                    torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
+                g1.record(); torch.cuda.synchronize()
+            gemm_us = g0.elapsed_time(g1) / 50 * 1e3
+            rows_g, kg, ng = xg.shape[0], lg.weight.shape[1], lg.weight.shape[0]
+            gemm_name = f"critic layer-2 forward GEMM [{rows_g}x{kg}]x[{kg}x{ng}] fp32 (hipBLASLt via torch.addmm)"
+        gemm_flop = 2.0 * rows_g * kg * ng
         gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_b_env_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_c_env_pmc.json")
         if N == 4096 and os.path.isfile(pmc):  # PMC counters are collected offline by tools/profile.sh (separate rocprofv3 passes)
             k = json.load(open(pmc))["kernels"]["env_step_kernel"]
             traffic = (k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
@@ -163,8 +172,7 @@ def main():
                        "envs_per_gpu": N, "parallelism": f"dp{world}"},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms},
-            "roofline": {"kernel": f"critic layer-2 forward GEMM [{xg.shape[0]}x256]x[256x256] fp32 (hipBLASLt via torch.addmm; the update's GEMMs are ~60% of GPU time)",
-                         "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF, "traffic": None,
+            "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF, "traffic": None,
                          "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop},
             "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",
                                   "achieved": sim_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS, "traffic": traffic,

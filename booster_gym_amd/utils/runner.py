@@ -263,7 +263,7 @@ class Runner:
         # Two HIP streams: the actor and the critic are independent networks, so the HBM-bound elementwise kernels of one overlap
         # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
         main = torch.cuda.current_stream()
-        side = self._side_stream
+        side = self._side_stream if os.environ.get("BG_TWO_STREAMS", "1") == "1" else main
         with torch.no_grad():
             for _ in range(cfg["runner"]["mini_epochs"]):
                 side.wait_stream(main)  # parameters updated by the previous optimiser step
