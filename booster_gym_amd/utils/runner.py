@@ -256,7 +256,7 @@ class Runner:
             obs_flat = buf["obses"][:T].reshape(B, -1)
         critic_all = self._critic_in.reshape((T + 1) * N, -1)  # rows [B, B+N) = the observation after the last step (last_values)
         with torch.no_grad():
-            old_mu = self.model.actor(buf["obses"][:T].reshape(B, -1))
+            old_mu = self._actor_tr.forward(obs_flat).clone()  # same kernels as the mini-epochs: the first ratio is exactly 1
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
             gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
         self._stats_acc.zero_()
