@@ -138,3 +138,34 @@ def test_config5_full_domain_randomisation_16384_envs():
     ms = env.get_field("mass_scale")
     assert 0.79 < float(ms[:, 0].min()) < 0.85 and 1.15 < float(ms[:, 0].max()) < 1.21  # base mass x U(0.8, 1.2)
     assert float(env.episode_stats(reset=False)[-1]) == 0 and dones < n // 4
+
+
+def test_isaac_layout_state_views_through_the_abi():
+    """bg_env_get_state / bg_env_set_state: the Isaac Gym tensor layouts the reference's task code assumes (t1.py:215-220):
+    root [N][13], dof [N][12][2] interleaved (pos, vel), net contact force [N][13][3] (only the feet rows 6 and 12 can be non-zero here)."""
+    import ctypes as C
+
+    from booster_gym_amd import _lib
+
+    n = 40
+    env = _env(n)
+    env.reset()
+    for a in _actions(n, 25, env.device, seed=5):
+        env.step(a * 0.3)
+    lib = _lib.load()
+    root = torch.empty(n, 13, device=env.device); dof = torch.empty(n, 12, 2, device=env.device); contact = torch.empty(n, 13, 3, device=env.device)
+    _lib.check(lib.bg_env_get_state(env._env, _lib.ptr(root), _lib.ptr(dof), _lib.ptr(contact), _lib.current_stream_ptr()))
+    assert torch.equal(root, env.root_states) and torch.equal(dof[:, :, 0], env.dof_pos) and torch.equal(dof[:, :, 1], env.dof_vel)
+    feet = env.get_field("feet_contact_forces").view(n, 2, 3)
+    assert torch.equal(contact[:, 6], feet[:, 0]) and torch.equal(contact[:, 12], feet[:, 1])
+    others = [b for b in range(13) if b not in (6, 12)]
+    assert contact[:, others].abs().max() == 0 and contact[:, [6, 12], 2].max() > 50.0  # somebody is standing on a foot
+    # set_state: write a new root / dof state, read it back through the named fields
+    root2 = root.clone(); root2[:, 2] += 0.25; dof2 = dof.clone(); dof2[:, 3, 0] = 0.77
+    _lib.check(lib.bg_env_set_state(env._env, _lib.ptr(root2), _lib.ptr(dof2), _lib.current_stream_ptr()))
+    assert torch.equal(env.root_states, root2) and torch.allclose(env.dof_pos[:, 3], torch.full((n,), 0.77, device=env.device))
+    # model query round-trips the description
+    d = _lib.ModelDesc()
+    _lib.check(lib.bg_model_get(env._model, C.byref(d)))
+    assert d.num_bodies == 13 and d.num_dofs == 12 and abs(d.mass[0] - 19.4304) < 1e-3 and list(d.joint_axis)[1:7] == [2, 1, 3, 2, 2, 1]
+    assert lib.bg_env_step_count(env._env) == 25
