@@ -272,20 +272,20 @@ class Runner:
                     values, last_values = v_all[:B], v_all[B:]
                     gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
                         advantages=self._adv, returns=self._ret, sums=self._adv_sums)
+                    self.dp.sum_(self._adv_sums)  # exchange (1), on the side stream: hidden under the actor forward
                 mu = self._actor_tr.forward(obs_flat)
                 main.wait_stream(side)
-                self.dp.sum_(self._adv_sums)
                 ppo_loss_fused(mu, self.model.logstd.reshape(-1), act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
                                values, self._ret.view(B), 0.2, alg["bound_coef"], alg["entropy_coef"], self._grad_mu, self._grad_val,
                                self._grad_logstd, self._stats)
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
+                    self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
                     self._critic_tr.backward(self._grad_val.view(B, 1))
                 self._actor_tr.backward(self._grad_mu)
                 self._logstd_grad_view.copy_(self._grad_logstd)
                 main.wait_stream(side)
-                self.dp.average_(self.optimizer.grad)
-                self.dp.sum_(self._stats)
+                self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
                 self.optimizer.step()
                 self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
                 self._stats_acc += self._stats
