@@ -21,9 +21,13 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = os.environ.get("BG_DIST_BACKEND", backend or "nccl")
         self.owns_group = False
+        # device of this rank: LOCAL_RANK, unless the launcher already narrowed the visible devices to one per process
+        # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), or a test shares one GPU between ranks (BG_LOCAL_DEVICE)
+        ndev = torch.cuda.device_count()
+        self.device_index = int(os.environ.get("BG_LOCAL_DEVICE", self.local_rank if self.local_rank < max(ndev, 1) else 0))
         if self.world_size > 1 and not dist.is_initialized():
             if self.backend == "nccl":
-                torch.cuda.set_device(self.local_rank)
+                torch.cuda.set_device(self.device_index)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size)
             self.owns_group = True

@@ -123,8 +123,7 @@ class Runner:
             self.cfg["basic"].setdefault("task", "T1")
         self.cfg["basic"]["rank"] = self.rank
         if self.world_size > 1:  # one process per GPU: each rank simulates and learns on its own device
-            dev_index = int(os.environ.get("BG_LOCAL_DEVICE", self.local_rank))  # BG_LOCAL_DEVICE: tests that share one GPU between ranks
-            self.cfg["basic"]["sim_device"] = self.cfg["basic"]["rl_device"] = f"cuda:{dev_index}"
+            self.cfg["basic"]["sim_device"] = self.cfg["basic"]["rl_device"] = f"cuda:{self.dp.device_index}"
         self._set_seed()
         task = self.cfg["basic"]["task"]
         if task not in TASKS:
