@@ -70,7 +70,8 @@ SYMBOLS = [
     "bg_model_create", "bg_model_get", "bg_model_destroy", "bg_env_create", "bg_env_destroy", "bg_env_set_heightfield",
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
     "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
-    "bg_env_forward_dynamics", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward",
+    "bg_env_forward_dynamics", "bg_sim_bind_state", "bg_sim_set_actuation", "bg_sim_apply_body_wrench_local", "bg_sim_simulate",
+    "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward",
     "bg_last_error", "bg_version",
 ]
 
@@ -111,6 +112,13 @@ def load():
         "bg_env_step_count": (i64, [vp]),
         "bg_env_set_step_count": (i32, [vp, i64]),
         "bg_env_forward_dynamics": (i32, [vp, vp, vp, vp, vp, vp, vp, vp]),
+        "bg_sim_bind_state": (i32, [vp, vp, vp, vp, vp]),
+        "bg_sim_set_actuation": (i32, [vp, vp, vp]),
+        "bg_sim_apply_body_wrench_local": (i32, [vp, vp, vp, vp]),
+        "bg_sim_simulate": (i32, [vp, vp]),
+        "bg_sim_refresh_body_state": (i32, [vp, vp]),
+        "bg_sim_write_root_state": (i32, [vp, vp, i32, vp]),
+        "bg_sim_write_dof_state": (i32, [vp, vp, i32, vp]),
         "bg_gae": (i32, [i32, i32, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp]),
         "bg_ppo_loss": (i32, [i32, i32] + [vp] * 10 + [f32, f32, f32] + [vp] * 5),
         "bg_gaussian_logp": (i32, [i32, i32, vp, vp, vp, vp, vp]),

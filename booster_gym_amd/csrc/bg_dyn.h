@@ -207,7 +207,7 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
 // ---------------------------------------------------------------- inward sweep, link I (child -> parent)
 template <int I>
 BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, const float* tau, LegWork& w, const SV* v, SI IA, SV pA,
-                      BaseContribution* out) {
+                      BaseContribution* out, const SV* fext) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
     // joint limit spring/damper, implicit in the joint velocity: tau_lim = t0 - bl * qdd
     float viol = ls.q[I] < lp.q_lo[I] ? ls.q[I] - lp.q_lo[I] : (ls.q[I] > lp.q_hi[I] ? ls.q[I] - lp.q_hi[I] : 0.f);
@@ -244,8 +244,9 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
         SI IP = rigid_inertia(pk);
         SV vp = v[I - 1];
         SV pP = crf(vp, mul_rigid(pk, vp));
+        if (fext) pP = pP - fext[I - 1];
         IP.A = IP.A + upper(A2); IP.H = IP.H + H2; IP.M = IP.M + upper(M1);
-        leg_inward<I - 1>(ph, lp, ls, tau, w, v, IP, pP + pp, out);
+        leg_inward<I - 1>(ph, lp, ls, tau, w, v, IP, pP + pp, out, fext);
     } else {
         out->I.A = upper(A2); out->I.H = H2; out->I.M = upper(M1);
         out->p = pp;
@@ -254,8 +255,9 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
 
 // Everything a lane does before the pair exchange: kinematics, contact, inward sweep.
 // gb = gravity in base coordinates.  Returns this leg's contribution at the trunk.
+// fext (optional): applied wrench on each link about its own origin, link coordinates (a = torque, l = force).
 BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
-                                  const BaseState& bs, M3 R0, SV v0, LegWork& w, V3* foot_force_w0) {
+                                  const BaseState& bs, M3 R0, SV v0, LegWork& w, V3* foot_force_w0, const SV* fext = nullptr) {
     SV v[LEG_LINKS];
     V3 pfoot;
     leg_outward<0>(lp, ls, w, v0, R0, bs.pos, v, &pfoot);
@@ -263,6 +265,7 @@ BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const Le
     const LinkConst& fk = lp.lk[LEG_LINKS - 1];
     SI IA = rigid_inertia(fk);
     SV pA = crf(v[LEG_LINKS - 1], mul_rigid(fk, v[LEG_LINKS - 1]));
+    if (fext) pA = pA - fext[LEG_LINKS - 1];
     if (w.contact) {
         // f_ext = f0 - B a_true = (f0 - B ag) - B a'   with a' = a_true - ag  (gravity field in foot coords)
         SV ag; ag.a = v3(0.f, 0.f, 0.f); ag.l = mulT(w.Rfoot, ph.g);
@@ -271,7 +274,7 @@ BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const Le
         pA = pA - (w.f0c - Bag);
     }
     BaseContribution out;
-    leg_inward<LEG_LINKS - 1>(ph, lp, ls, tau, w, v, IA, pA, &out);
+    leg_inward<LEG_LINKS - 1>(ph, lp, ls, tau, w, v, IA, pA, &out, fext);
     return out;
 }
 
@@ -369,6 +372,44 @@ BG_HD BaseContribution base_own(const LinkConst& bk, SV v0, SV wrench /* a = tor
     return b;
 }
 
+// A force / torque given in a body's own frame with the force acting at the centre of mass
+// (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE), reference t1.py:522-527) as a wrench about the body origin.
+BG_HD SV local_wrench_at_com(const LinkConst& k, V3 f, V3 t) {
+    SV w;
+    w.l = f;
+    w.a = t + bg_rcp(k.m) * cross(k.mc, f);
+    return w;
+}
+
+// Rigid-body state rows of one leg (Isaac Gym rigid_body_state tensor, t1.py:220): origin position, quaternion xyzw (w >= 0),
+// linear velocity of the origin and angular velocity in the world frame; 13 floats per link, link I at out + 13 * I.
+template <int I>
+BG_HD void leg_body_states(const LegParams& lp, const LegState& ls, SV vpar, M3 Rpar, V3 ppar, float* out) {
+    constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    float s, c;
+    bg_sincos(ls.q[I], &s, &c);
+    SV v;
+    v.a = rotT<AX>(c, s, vpar.a);
+    v.l = rotT<AX>(c, s, vpar.l + cross(vpar.a, lp.lk[I].pos));
+    v.a.e[A] += ls.qd[I];
+    V3 p = ppar + mul(Rpar, lp.lk[I].pos);
+    M3 R = Rpar;
+    {
+        constexpr int J = Plane<AX>::J, K = Plane<AX>::K;
+        for (int r = 0; r < 3; r++) {
+            R.e[r][J] = c * Rpar.e[r][J] + s * Rpar.e[r][K];
+            R.e[r][K] = -s * Rpar.e[r][J] + c * Rpar.e[r][K];
+        }
+    }
+    float qt[4];
+    mat_to_quat(R, qt);
+    V3 vl = mul(R, v.l), va = mul(R, v.a);
+    float* o = out + 13 * I;
+    for (int a = 0; a < 3; a++) { o[a] = p.e[a]; o[7 + a] = vl.e[a]; o[10 + a] = va.e[a]; }
+    for (int a = 0; a < 4; a++) o[3 + a] = qt[a];
+    if constexpr (I + 1 < LEG_LINKS) leg_body_states<I + 1>(lp, ls, v, R, p, out);
+}
+
 // ---------------------------------------------------------------- model constants and per-env parameters
 struct ModelDev {  // nominal (un-randomised) model, shared by all envs; filled by bg_model_create
     float pos[13][3];
@@ -422,11 +463,11 @@ BG_HD LinkConst load_base_link(const ModelDev& m, int e, int n, const float* mas
 struct SubstepCtx { M3 R0; SV v0; LegWork w; };
 
 BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
-                                   const BaseState& bs, SubstepCtx& cx) {
+                                   const BaseState& bs, SubstepCtx& cx, const SV* fext = nullptr) {
     cx.R0 = quat_to_mat(bs.quat);
     cx.v0 = base_body_velocity(cx.R0, bs);
     V3 unused;
-    return leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused);
+    return leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused, fext);
 }
 // `both` = this leg's contribution + the partner leg's.  Returns accelerations; does not integrate.
 BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& lp, LegState& ls, const SubstepCtx& cx, const BaseContribution& both,

@@ -181,7 +181,8 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
             a6[i] = a;
             target[i] = C.default_dof_pos[j0 + i] + C.action_scale * a;
         }
-        SV wrench; wrench.l = push_f; wrench.a = push_t;
+        // applied at the trunk's centre of mass, trunk frame (apply_rigid_body_force_tensors LOCAL_SPACE, t1.py:522-527)
+        SV wrench = local_wrench_at_com(bk, push_f, push_t);
         // ------------------------------------------------------------ physics substeps (t1.py:443-456)
         for (int s = 0; s < C.decimation; s++) {
             float tau[LEG_LINKS];

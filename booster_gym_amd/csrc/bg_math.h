@@ -168,6 +168,25 @@ BG_HD M3 quat_to_mat(const float q[4]) {
     r.e[2][0] = 2.f * (x * z - y * w); r.e[2][1] = 2.f * (y * z + x * w); r.e[2][2] = 1.f - 2.f * (x * x + y * y);
     return r;
 }
+// rotation matrix -> unit quaternion xyzw with w >= 0 (Shepperd's branches)
+BG_HD void mat_to_quat(const M3& R, float q[4]) {
+    float tr = R.e[0][0] + R.e[1][1] + R.e[2][2], x, y, z, w;
+    if (tr > 0.f) {
+        float s = bg_sqrt(tr + 1.0f) * 2.0f, inv = bg_rcp(s);
+        w = 0.25f * s; x = (R.e[2][1] - R.e[1][2]) * inv; y = (R.e[0][2] - R.e[2][0]) * inv; z = (R.e[1][0] - R.e[0][1]) * inv;
+    } else if (R.e[0][0] > R.e[1][1] && R.e[0][0] > R.e[2][2]) {
+        float s = bg_sqrt(1.0f + R.e[0][0] - R.e[1][1] - R.e[2][2]) * 2.0f, inv = bg_rcp(s);
+        w = (R.e[2][1] - R.e[1][2]) * inv; x = 0.25f * s; y = (R.e[0][1] + R.e[1][0]) * inv; z = (R.e[0][2] + R.e[2][0]) * inv;
+    } else if (R.e[1][1] > R.e[2][2]) {
+        float s = bg_sqrt(1.0f + R.e[1][1] - R.e[0][0] - R.e[2][2]) * 2.0f, inv = bg_rcp(s);
+        w = (R.e[0][2] - R.e[2][0]) * inv; x = (R.e[0][1] + R.e[1][0]) * inv; y = 0.25f * s; z = (R.e[1][2] + R.e[2][1]) * inv;
+    } else {
+        float s = bg_sqrt(1.0f + R.e[2][2] - R.e[0][0] - R.e[1][1]) * 2.0f, inv = bg_rcp(s);
+        w = (R.e[1][0] - R.e[0][1]) * inv; x = (R.e[0][2] + R.e[2][0]) * inv; y = (R.e[1][2] + R.e[2][1]) * inv; z = 0.25f * s;
+    }
+    if (w < 0.f) { x = -x; y = -y; z = -z; w = -w; }
+    q[0] = x; q[1] = y; q[2] = z; q[3] = w;
+}
 
 BG_HD void bg_sincos(float x, float* s, float* c) {
 #if defined(__HIP_DEVICE_COMPILE__)

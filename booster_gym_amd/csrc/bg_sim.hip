@@ -42,6 +42,10 @@ struct bg_env {
     TerrainDev terrain;
     StepOut bound;
     int64_t step_count = 0;
+    // granular simulator calls (bg_sim_*): caller-owned Isaac-layout tensors + this library's copies of the last actuation / applied forces
+    float *sim_root = nullptr, *sim_dof = nullptr, *sim_contact = nullptr, *sim_body = nullptr;
+    float *sim_tau = nullptr, *sim_bforce = nullptr, *sim_btorque = nullptr;
+    bool sim_wrench_pending = false;
 };
 
 // ------------------------------------------------------------------ lane-pair exchange: DPP quad_perm [1,0,3,2]
@@ -120,6 +124,103 @@ __global__ __launch_bounds__(64) void forward_dynamics_kernel(EnvDev E, const fl
     if (leg == 0) for (int a = 0; a < 3; a++) { o[a] = lin_w.e[a]; o[3 + a] = ang_w.e[a]; }
     for (int i = 0; i < LEG_LINKS; i++) o[6 + leg * 6 + i] = qdd[i];
     for (int a = 0; a < 3; a++) E.f[(size_t)(F_CONTACT + 3 * leg + a) * n + e] = fw.e[a];
+}
+
+// ------------------------------------------------------------------ granular simulator calls on caller-owned Isaac-layout tensors
+struct SimLane {
+    BaseState bs;
+    LegState ls;
+    LegParams lp;
+    LinkConst bk;
+};
+__device__ __forceinline__ void sim_load(const EnvDev& E, int e, int leg, const float* __restrict__ root, const float* __restrict__ dof, SimLane& L) {
+    const int n = E.n;
+    const float* r = root + (size_t)e * 13;
+    L.bs.pos = v3(r[0], r[1], r[2]);
+    for (int a = 0; a < 4; a++) L.bs.quat[a] = r[3 + a];
+    L.bs.vlin = v3(r[7], r[8], r[9]); L.bs.vang = v3(r[10], r[11], r[12]);
+    for (int i = 0; i < LEG_LINKS; i++) {
+        const float* d = dof + ((size_t)e * 12 + leg * 6 + i) * 2;
+        L.ls.q[i] = d[0]; L.ls.qd[i] = d[1];
+    }
+    ContactCfg cc = make_contact_cfg(E.cfg);
+    load_leg_params(*E.model, cc, leg, e, n, E.f + (size_t)F_MASS_SCALE * n, E.f + (size_t)F_COM_OFF * n, E.f + (size_t)F_FOOT_MAT * n, L.lp);
+    L.bk = load_base_link(*E.model, e, n, E.f + (size_t)F_MASS_SCALE * n, E.f + (size_t)F_COM_OFF * n);
+}
+// rigid-body state rows [13][13] of env e: the trunk row (leg-0 lane) and this lane's six links
+__device__ __forceinline__ void sim_write_body(const SimLane& L, int e, int leg, float* __restrict__ body) {
+    float* b = body + (size_t)e * 13 * 13;
+    if (leg == 0) {
+        for (int a = 0; a < 3; a++) { b[a] = L.bs.pos.e[a]; b[7 + a] = L.bs.vlin.e[a]; b[10 + a] = L.bs.vang.e[a]; }
+        const float sg = L.bs.quat[3] < 0.f ? -1.f : 1.f;
+        for (int a = 0; a < 4; a++) b[3 + a] = sg * L.bs.quat[a];
+    }
+    M3 R0 = quat_to_mat(L.bs.quat);
+    leg_body_states<0>(L.lp, L.ls, base_body_velocity(R0, L.bs), R0, L.bs.pos, b + 13 * (1 + leg * LEG_LINKS));
+}
+
+// one gym.simulate (t1.py:451): a sim.dt step of every env, in place on root [N][13] / dof [N][12][2]
+__global__ __launch_bounds__(64) void sim_substep_kernel(EnvDev E, float* __restrict__ root, float* __restrict__ dof, const float* __restrict__ tau,
+                                                         const float* __restrict__ bforce, const float* __restrict__ btorque,
+                                                         float* __restrict__ contact, float* __restrict__ body) {
+    const int lane = threadIdx.x, leg = lane & 1;
+    int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
+    const bool valid = e < E.n;
+    if (!valid) e = E.n - 1;
+    Phys ph = make_phys(E.cfg);
+    SimLane L;
+    sim_load(E, e, leg, root, dof, L);
+    float t6[LEG_LINKS];
+    for (int i = 0; i < LEG_LINKS; i++) t6[i] = tau[(size_t)e * 12 + leg * 6 + i];
+    SV wr = sv_zero();
+    SV fext[LEG_LINKS];
+    const bool has_w = bforce != nullptr;
+    if (has_w) {
+        const float* f = bforce + (size_t)e * 39;
+        const float* t = btorque + (size_t)e * 39;
+        wr = local_wrench_at_com(L.bk, v3(f[0], f[1], f[2]), v3(t[0], t[1], t[2]));
+        for (int i = 0; i < LEG_LINKS; i++) {
+            const int b = 3 * (1 + leg * LEG_LINKS + i);
+            fext[i] = local_wrench_at_com(L.lp.lk[i], v3(f[b], f[b + 1], f[b + 2]), v3(t[b], t[b + 1], t[b + 2]));
+        }
+    }
+    DppSwap x;
+    SubstepCtx cx;
+    BaseContribution mine = substep_pre(ph, E.terrain, L.lp, L.ls, t6, L.bs, cx, has_w ? fext : nullptr), both;
+    for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
+    for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
+    for (int k = 0; k < 3; k++) { both.p.a.e[k] = mine.p.a.e[k] + x.swap(mine.p.a.e[k]); both.p.l.e[k] = mine.p.l.e[k] + x.swap(mine.p.l.e[k]); }
+    float qdd[LEG_LINKS];
+    V3 lin_w, ang_w, fw;
+    substep_solve(ph, L.bk, L.lp, L.ls, cx, both, wr, qdd, &lin_w, &ang_w, &fw);
+    substep_integrate(ph, L.lp, L.ls, L.bs, qdd, lin_w, ang_w);
+    if (!valid) return;
+    if (leg == 0) {
+        float* r = root + (size_t)e * 13;
+        for (int a = 0; a < 3; a++) { r[a] = L.bs.pos.e[a]; r[7 + a] = L.bs.vlin.e[a]; r[10 + a] = L.bs.vang.e[a]; }
+        for (int a = 0; a < 4; a++) r[3 + a] = L.bs.quat[a];
+    }
+    for (int i = 0; i < LEG_LINKS; i++) {
+        float* d = dof + ((size_t)e * 12 + leg * 6 + i) * 2;
+        d[0] = L.ls.q[i]; d[1] = L.ls.qd[i];
+    }
+    if (contact) {  // net contact force per body, world frame (t1.py:219); only the feet carry collision geometry in this build
+        float* c = contact + (size_t)e * 39;
+        if (leg == 0) c[0] = c[1] = c[2] = 0.f;
+        for (int i = 0; i < LEG_LINKS - 1; i++) for (int a = 0; a < 3; a++) c[3 * (1 + leg * LEG_LINKS + i) + a] = 0.f;
+        for (int a = 0; a < 3; a++) c[3 * (LEG_LINKS + leg * LEG_LINKS) + a] = fw.e[a];
+    }
+    if (body) sim_write_body(L, e, leg, body);
+}
+
+// gym.refresh_rigid_body_state_tensor (t1.py:462): body rows from the current root / dof tensors, no dynamics
+__global__ __launch_bounds__(64) void sim_body_state_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ dof, float* __restrict__ body) {
+    const int lane = threadIdx.x, leg = lane & 1;
+    const int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
+    if (e >= E.n) return;
+    SimLane L;
+    sim_load(E, e, leg, root, dof, L);
+    sim_write_body(L, e, leg, body);
 }
 
 // ------------------------------------------------------------------ layout conversion helpers
@@ -258,6 +359,7 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
 
 extern "C" void bg_env_destroy(bg_env* e) {
     if (!e) return;
+    (void)hipFree(e->sim_tau); (void)hipFree(e->sim_bforce); (void)hipFree(e->sim_btorque);
     (void)hipFree(e->f); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
     delete e;
 }
@@ -430,4 +532,72 @@ extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float
     hipLaunchKernelGGL(forward_dynamics_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc);
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+// ------------------------------------------------------------------ ABI: granular simulator calls (SURVEY.md 8(b) lower seam)
+extern "C" int bg_sim_bind_state(bg_env* e, float* root, float* dof, float* contact, float* body) {
+    if (!e || !root || !dof) return fail(-1, "bg_sim_bind_state: root and dof tensors are required");
+    const size_t n = (size_t)e->n;
+    if (!e->sim_tau) {
+        HIP_OK(hipMalloc(&e->sim_tau, sizeof(float) * n * 12));
+        HIP_OK(hipMalloc(&e->sim_bforce, sizeof(float) * n * 39));
+        HIP_OK(hipMalloc(&e->sim_btorque, sizeof(float) * n * 39));
+        HIP_OK(hipMemset(e->sim_tau, 0, sizeof(float) * n * 12));
+        HIP_OK(hipMemset(e->sim_bforce, 0, sizeof(float) * n * 39));
+        HIP_OK(hipMemset(e->sim_btorque, 0, sizeof(float) * n * 39));
+    }
+    e->sim_root = root; e->sim_dof = dof; e->sim_contact = contact; e->sim_body = body;
+    e->sim_wrench_pending = false;
+    return 0;
+}
+extern "C" int bg_sim_set_actuation(bg_env* e, const float* tau, void* stream) {
+    if (!e || !tau) return fail(-1, "bg_sim_set_actuation: null argument");
+    if (!e->sim_tau) return fail(-1, "bg_sim_set_actuation: call bg_sim_bind_state first");
+    HIP_OK(hipMemcpyAsync(e->sim_tau, tau, sizeof(float) * (size_t)e->n * 12, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+extern "C" int bg_sim_apply_body_wrench_local(bg_env* e, const float* force, const float* torque, void* stream) {
+    if (!e) return fail(-1, "bg_sim_apply_body_wrench_local: null env");
+    if (!e->sim_tau) return fail(-1, "bg_sim_apply_body_wrench_local: call bg_sim_bind_state first");
+    const size_t bytes = sizeof(float) * (size_t)e->n * 39;
+    if (force) HIP_OK(hipMemcpyAsync(e->sim_bforce, force, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else HIP_OK(hipMemsetAsync(e->sim_bforce, 0, bytes, (hipStream_t)stream));
+    if (torque) HIP_OK(hipMemcpyAsync(e->sim_btorque, torque, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    else HIP_OK(hipMemsetAsync(e->sim_btorque, 0, bytes, (hipStream_t)stream));
+    e->sim_wrench_pending = force || torque;
+    return 0;
+}
+extern "C" int bg_sim_simulate(bg_env* e, void* stream) {
+    if (!e) return fail(-1, "bg_sim_simulate: null env");
+    if (!e->sim_root) return fail(-1, "bg_sim_simulate: call bg_sim_bind_state first");
+    dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
+    const bool w = e->sim_wrench_pending;
+    hipLaunchKernelGGL(sim_substep_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), e->sim_root, e->sim_dof, (const float*)e->sim_tau,
+                       w ? (const float*)e->sim_bforce : nullptr, w ? (const float*)e->sim_btorque : nullptr, e->sim_contact, e->sim_body);
+    HIP_OK(hipGetLastError());
+    e->sim_wrench_pending = false;  // applied forces last for one simulate
+    return 0;
+}
+extern "C" int bg_sim_refresh_body_state(bg_env* e, void* stream) {
+    if (!e) return fail(-1, "bg_sim_refresh_body_state: null env");
+    if (!e->sim_root) return fail(-1, "bg_sim_refresh_body_state: call bg_sim_bind_state first");
+    if (!e->sim_body) return 0;
+    dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
+    hipLaunchKernelGGL(sim_body_state_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), (const float*)e->sim_root, (const float*)e->sim_dof, e->sim_body);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+// The bound tensors ARE the simulator state, so an indexed write-back has nothing to copy; the rigid-body rows are re-derived so that
+// they agree with what the caller just wrote.
+extern "C" int bg_sim_write_root_state(bg_env* e, const int32_t* env_ids, int32_t count, void* stream) {
+    (void)env_ids;
+    if (!e) return fail(-1, "bg_sim_write_root_state: null env");
+    if (count < 0 || count > e->n) return fail(-1, "bg_sim_write_root_state: count out of range");
+    return bg_sim_refresh_body_state(e, stream);
+}
+extern "C" int bg_sim_write_dof_state(bg_env* e, const int32_t* env_ids, int32_t count, void* stream) {
+    (void)env_ids;
+    if (!e) return fail(-1, "bg_sim_write_dof_state: null env");
+    if (count < 0 || count > e->n) return fail(-1, "bg_sim_write_dof_state: count out of range");
+    return bg_sim_refresh_body_state(e, stream);
 }

@@ -151,6 +151,33 @@ int bg_env_set_step_count(bg_env* env, int64_t count);
 int bg_env_forward_dynamics(bg_env* env, const float* root, const float* dof_pos, const float* dof_vel, const float* tau,
                             const float* base_wrench, float* qacc, void* stream);
 
+/* ---- granular simulator calls: the Isaac Gym tensor API of envs/t1.py one call at a time (lower seam).
+ * A maintainer who keeps the reference's Python task logic replaces each gym.* call by the entry point named here; the fused
+ * bg_env_step above is the same physics + task logic in one launch.  The tensors are CALLER-OWNED device memory in the Isaac Gym
+ * layouts and are the simulator state for these calls (no hidden copy): root [N][13] = pos, quat xyzw, lin vel, ang vel (world)
+ * (t1.py:215,221-222); dof [N][12][2] = (pos, vel) (t1.py:216-218); contact [N][13][3] net contact force per body, world frame
+ * (t1.py:219; only the feet carry collision geometry in this build, other rows are 0); body [N][13][13] = origin pos, quat xyzw
+ * (w >= 0), lin vel of the origin, ang vel, world frame (t1.py:220).  contact / body may be NULL.  Per-env parameters, model and
+ * terrain are those of the env (bg_env_set_params / bg_env_set_heightfield).  These calls do not touch the env's own task state;
+ * bg_env_get_state / bg_env_set_state move state between the two. */
+/* gym.acquire_actor_root_state_tensor / acquire_dof_state_tensor / acquire_net_contact_force_tensor / acquire_rigid_body_state_tensor
+ * (t1.py:203-220).  Allocates the library's actuation / applied-force copies on first use. */
+int bg_sim_bind_state(bg_env* env, float* root, float* dof, float* contact, float* body);
+/* gym.set_dof_actuation_force_tensor (t1.py:450): tau [N][12], copied; stays in force until set again */
+int bg_sim_set_actuation(bg_env* env, const float* tau, void* stream);
+/* gym.apply_rigid_body_force_tensors(sim, forces, torques, LOCAL_SPACE) (t1.py:522-527): force / torque [N][13][3] in each body's own
+ * frame, the force acting at the body's centre of mass; copied; either may be NULL (= zero); consumed by the next bg_sim_simulate only */
+int bg_sim_apply_body_wrench_local(bg_env* env, const float* force, const float* torque, void* stream);
+/* gym.simulate (t1.py:451): one sim_dt step of all envs, in place on root / dof; writes contact and body.  The refresh_* calls
+ * that follow in the reference (t1.py:452-455, 460-462) have nothing left to do. */
+int bg_sim_simulate(bg_env* env, void* stream);
+/* gym.refresh_rigid_body_state_tensor without a step (t1.py:462 after a reset): body rows from the current root / dof tensors */
+int bg_sim_refresh_body_state(bg_env* env, void* stream);
+/* gym.set_actor_root_state_tensor_indexed (t1.py:341,359,504) / gym.set_dof_state_tensor_indexed (t1.py:323-325): the bound tensors
+ * already are the state, so these only re-derive the body rows; env_ids (device int32 [count]) is accepted for call-site parity */
+int bg_sim_write_root_state(bg_env* env, const int32_t* env_ids, int32_t count, void* stream);
+int bg_sim_write_dof_state(bg_env* env, const int32_t* env_ids, int32_t count, void* stream);
+
 /* ---- PPO math (utils/utils.py:33-52, utils/runner.py:123-180), all pointers device float unless noted */
 /* GAE + returns + advantage moments.  rewards [T][N] is modified in place where time_outs is set (runner.py:135).
  * sums out [3] = (sum adv, sum adv^2, count) as float64, accumulated with atomics; caller zeroes it. */

@@ -357,9 +357,10 @@ static int solve6(double A[6][6], double b[6]) {
  * qacc out: d/dt of (lin vel world, ang vel world, qd)   [18]
  * a_body out (optional): true spatial acceleration of every body, body coords [NB*6]
  */
-int ref_forward(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *mass_scale, const double *com_off,
-                const double *foot_mat, const double *root, const double *q, const double *qd, const double *tau,
-                const double *base_wrench_local, double *qacc, double *contact_force_w, double *a_body) {
+static int forward_core(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *mass_scale, const double *com_off,
+                        const double *foot_mat, const double *root, const double *q, const double *qd, const double *tau,
+                        const double *base_wrench_local, const double *body_force, const double *body_torque, double *qacc,
+                        double *contact_force_w, double *a_body) {
     kin_t k;
     contact_t ct;
     kinematics(m, p, mass_scale, com_off, root, q, qd, &k);
@@ -377,6 +378,18 @@ int ref_forward(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *
     /* external forces enter as  pA -= f_ext  with a' = a - ag as the unknown */
     if (base_wrench_local) {
         for (int a = 0; a < 3; a++) { pA[0][a] -= base_wrench_local[3 + a]; pA[0][3 + a] -= base_wrench_local[a]; }
+    }
+    /* per-body force / torque in the body's own frame, force acting at the body's centre of mass
+     * (gym.apply_rigid_body_force_tensors(..., LOCAL_SPACE), envs/t1.py:522-527): wrench about the origin = (t + c x f, f) */
+    if (body_force || body_torque) {
+        for (int i = 0; i < m->nb; i++) {
+            double f[3] = {0, 0, 0}, tq[3] = {0, 0, 0}, c[3], cxf[3];
+            if (body_force) for (int a = 0; a < 3; a++) f[a] = body_force[3 * i + a];
+            if (body_torque) for (int a = 0; a < 3; a++) tq[a] = body_torque[3 * i + a];
+            for (int a = 0; a < 3; a++) c[a] = m->com[i][a] + (com_off ? com_off[3 * i + a] : 0.0);
+            cross(c, f, cxf);
+            for (int a = 0; a < 3; a++) { pA[i][a] -= tq[a] + cxf[a]; pA[i][3 + a] -= f[a]; }
+        }
     }
     for (int f = 0; f < 2; f++) {
         int b = m->foot_body[f];
@@ -452,6 +465,18 @@ int ref_forward(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *
     return 0;
 }
 
+int ref_forward(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *mass_scale, const double *com_off,
+                const double *foot_mat, const double *root, const double *q, const double *qd, const double *tau,
+                const double *base_wrench_local, double *qacc, double *contact_force_w, double *a_body) {
+    return forward_core(m, p, t, mass_scale, com_off, foot_mat, root, q, qd, tau, base_wrench_local, 0, 0, qacc, contact_force_w, a_body);
+}
+/* same with a force / torque on every body (local frame, force at the centre of mass): the Isaac Gym call of t1.py:522-527 */
+int ref_forward_bw(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *mass_scale, const double *com_off,
+                   const double *foot_mat, const double *root, const double *q, const double *qd, const double *tau,
+                   const double *body_force, const double *body_torque, double *qacc, double *contact_force_w) {
+    return forward_core(m, p, t, mass_scale, com_off, foot_mat, root, q, qd, tau, 0, body_force, body_torque, qacc, contact_force_w, 0);
+}
+
 /* ------------------------------------------------------------------ inverse dynamics (RBDA Table 9.6), independent check.
  * Given the true body accelerations implied by qacc, returns the generalized force residual
  *   res[0:6]  = net spatial force on the base (must equal the applied base wrench [torque; force])
@@ -512,11 +537,27 @@ static void quat_mul(const double a[4], const double b[4], double o[4]) { /* xyz
     o[2] = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
 }
 
+static void integrate(const ref_model_t *m, const ref_phys_t *p, double *root, double *q, double *qd, const double *qacc);
+
 int ref_step(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *mass_scale, const double *com_off,
              const double *foot_mat, double *root, double *q, double *qd, const double *tau, const double *base_wrench_local,
              double *contact_force_w) {
     double qacc[18];
     if (ref_forward(m, p, t, mass_scale, com_off, foot_mat, root, q, qd, tau, base_wrench_local, qacc, contact_force_w, 0)) return -1;
+    integrate(m, p, root, q, qd, qacc);
+    return 0;
+}
+/* one gym.simulate (t1.py:451) with per-body applied forces */
+int ref_step_bw(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *mass_scale, const double *com_off,
+                const double *foot_mat, double *root, double *q, double *qd, const double *tau, const double *body_force,
+                const double *body_torque, double *contact_force_w) {
+    double qacc[18];
+    if (ref_forward_bw(m, p, t, mass_scale, com_off, foot_mat, root, q, qd, tau, body_force, body_torque, qacc, contact_force_w)) return -1;
+    integrate(m, p, root, q, qd, qacc);
+    return 0;
+}
+
+static void integrate(const ref_model_t *m, const ref_phys_t *p, double *root, double *q, double *qd, const double *qacc) {
     for (int a = 0; a < 6; a++) root[7 + a] += p->dt * qacc[a];
     for (int j = 0; j < ND; j++) {
         qd[j] += p->dt * qacc[6 + j];
@@ -539,7 +580,34 @@ int ref_step(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, 
     quat_mul(dq, root + 3, nq);
     double nn = 1.0 / sqrt(nq[0] * nq[0] + nq[1] * nq[1] + nq[2] * nq[2] + nq[3] * nq[3]);
     for (int a = 0; a < 4; a++) root[3 + a] = nq[a] * nn;
-    return 0;
+}
+
+/* rigid-body state tensor row per body (t1.py:220): origin position, orientation quaternion xyzw (w >= 0), linear velocity of the
+ * origin and angular velocity, all in the world frame.  out [NB][13] */
+void ref_body_states(const ref_model_t *m, const double *root, const double *q, const double *qd, double *out) {
+    ref_phys_t p;
+    memset(&p, 0, sizeof(p));
+    kin_t k;
+    kinematics(m, &p, 0, 0, root, q, qd, &k);
+    for (int i = 0; i < m->nb; i++) {
+        double *o = out + 13 * i;
+        for (int a = 0; a < 3; a++) o[a] = k.pw[i][a];
+        const double(*R)[3] = k.Rw[i];
+        double tr = R[0][0] + R[1][1] + R[2][2], qx, qy, qz, qw;
+        if (tr > 0) {
+            double s = sqrt(tr + 1.0) * 2; qw = 0.25 * s; qx = (R[2][1] - R[1][2]) / s; qy = (R[0][2] - R[2][0]) / s; qz = (R[1][0] - R[0][1]) / s;
+        } else if (R[0][0] > R[1][1] && R[0][0] > R[2][2]) {
+            double s = sqrt(1.0 + R[0][0] - R[1][1] - R[2][2]) * 2; qw = (R[2][1] - R[1][2]) / s; qx = 0.25 * s; qy = (R[0][1] + R[1][0]) / s; qz = (R[0][2] + R[2][0]) / s;
+        } else if (R[1][1] > R[2][2]) {
+            double s = sqrt(1.0 + R[1][1] - R[0][0] - R[2][2]) * 2; qw = (R[0][2] - R[2][0]) / s; qx = (R[0][1] + R[1][0]) / s; qy = 0.25 * s; qz = (R[1][2] + R[2][1]) / s;
+        } else {
+            double s = sqrt(1.0 + R[2][2] - R[0][0] - R[1][1]) * 2; qw = (R[1][0] - R[0][1]) / s; qx = (R[0][2] + R[2][0]) / s; qy = (R[1][2] + R[2][1]) / s; qz = 0.25 * s;
+        }
+        if (qw < 0) { qx = -qx; qy = -qy; qz = -qz; qw = -qw; }
+        o[3] = qx; o[4] = qy; o[5] = qz; o[6] = qw;
+        m3_vec(R, k.v[i] + 3, o + 7);
+        m3_vec(R, k.v[i], o + 10);
+    }
 }
 
 /* ------------------------------------------------------------------ decimation loop with the PD actuator

@@ -188,6 +188,36 @@ class DynRef:
             raise RuntimeError("ref_step failed")
         return cf
 
+    def forward_bw(self, root, q, qd, tau, body_force=None, body_torque=None, mass_scale=None, com_off=None, foot_mat=None):
+        """Forward dynamics with a force / torque on every body (local frame, force at the centre of mass): t1.py:522-527."""
+        root, q, qd, tau = _f64(root), _f64(q), _f64(qd), _f64(tau)
+        body_force, body_torque, mass_scale, com_off, foot_mat = map(_f64, (body_force, body_torque, mass_scale, com_off, foot_mat))
+        qacc = np.zeros(18)
+        cf = np.zeros((NB, 3))
+        r = lib().ref_forward_bw(C.byref(self.model), C.byref(self.phys), C.byref(self.terrain), _p(mass_scale), _p(com_off), _p(foot_mat),
+                                 _p(root), _p(q), _p(qd), _p(tau), _p(body_force), _p(body_torque), _p(qacc), _p(cf))
+        if r:
+            raise RuntimeError("ref_forward_bw failed")
+        return qacc, cf
+
+    def step_bw(self, root, q, qd, tau, body_force=None, body_torque=None, mass_scale=None, com_off=None, foot_mat=None):
+        """One gym.simulate (t1.py:451) in place on float64 root[13], q[12], qd[12] with per-body applied forces. Returns contact forces."""
+        assert root.dtype == np.float64 and q.dtype == np.float64 and qd.dtype == np.float64
+        tau, body_force, body_torque, mass_scale, com_off, foot_mat = map(_f64, (tau, body_force, body_torque, mass_scale, com_off, foot_mat))
+        cf = np.zeros((NB, 3))
+        r = lib().ref_step_bw(C.byref(self.model), C.byref(self.phys), C.byref(self.terrain), _p(mass_scale), _p(com_off), _p(foot_mat),
+                              _p(root), _p(q), _p(qd), _p(tau), _p(body_force), _p(body_torque), _p(cf))
+        if r:
+            raise RuntimeError("ref_step_bw failed")
+        return cf
+
+    def body_states(self, root, q, qd):
+        """Rigid-body state rows [13,13] (t1.py:220): pos, quat xyzw (w >= 0), lin vel of the origin, ang vel, world frame."""
+        root, q, qd = _f64(root), _f64(q), _f64(qd)
+        out = np.zeros((NB, 13))
+        lib().ref_body_states(C.byref(self.model), _p(root), _p(q), _p(qd), _p(out))
+        return out
+
     def substeps_batch(self, decimation, mass_scale, com_off, foot_mat, kp, kd, fric, tau_limit, root, q, qd, targets, last_targets,
                        delay, base_wrench):
         """Decimation loop for n envs, in place on root[n,13], q[n,12], qd[n,12], last_targets[n,12] (float64)."""

@@ -455,9 +455,14 @@ class T1Ref:
         # ---- pre-physics + substeps (t1.py:439-456)
         self.actions = np.clip(np.asarray(actions, dtype=np.float64), -nz["clip_actions"], nz["clip_actions"])
         targets = self.default + cfg["control"]["action_scale"] * self.actions
+        # pushing force acts at the trunk's centre of mass, trunk frame (apply_rigid_body_force_tensors LOCAL_SPACE, t1.py:522-527):
+        # wrench about the trunk origin = (f, t + c x f)
+        com0 = np.array(self.dyn.model.com[0][:]) + self.p["com_off"].reshape(n, 13, 3)[:, 0]
+        wrench = self.push.copy()
+        wrench[:, 3:] += np.cross(com0, self.push[:, :3])
         tmean, cf = self.dyn.substeps_batch(dec, self.p["mass_scale"], self.p["com_off"].reshape(n, 39), self.p["foot_mat"].reshape(n, 6), self.p["kp"],
                                             self.p["kd"], self.p["fric"], self.limits["torque_limits"], self.root, self.q, self.qd, targets, self.last_tgt,
-                                            self.delay.astype(np.int32), self.push)
+                                            self.delay.astype(np.int32), wrench)
         # ---- post-physics (t1.py:460-478)
         quat = self.root[:, 3:7]
         base_lin, base_ang = quat_rotate_inverse(quat, self.root[:, 7:10]), quat_rotate_inverse(quat, self.root[:, 10:13])

@@ -1,0 +1,169 @@
+"""Lower seam of the drop-in boundary: the Isaac Gym tensor-API calls of envs/t1.py one at a time
+(bg_sim_* through booster_gym_amd.envs.gym_calls.GymCalls) against the double-precision oracle, and the reference's decimation
+loop (t1.py:443-456) re-typed on those calls against the fused env-step kernel.
+
+Tolerances: accelerations implied by one simulate() within 1e-4 relative (contact-free) / 5e-4 (stiff sole contacts) of the
+oracle, the same figures as tests/test_gpu_dynamics.py; body rows 2e-5 absolute.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_dynamics import _states  # noqa: E402
+
+
+def _make(n, terrain="plane", **over):
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.envs.gym_calls import GymCalls
+    from booster_gym_amd.utils.config import load_cfg
+
+    o = {"env.num_envs": n, "terrain.type": terrain}
+    o.update(over)
+    cfg = load_cfg("T1", o)
+    env = T1(cfg)
+    return cfg, env, GymCalls(env)
+
+
+@pytest.mark.parametrize("contact,tol", [(False, 1e-4), (True, 5e-4)])
+def test_simulate_matches_oracle_step(flat_model, contact, tol):
+    from oracle.dyn_ref import DynRef
+
+    n = 256
+    cfg, env, gym = _make(n)
+    ref = DynRef(flat_model, feet_edge_pos=cfg["asset"]["feet_edge_pos"])
+    dt = ref.phys.dt
+    rng = np.random.default_rng(11)
+    root, q, qd, tau, _ = _states(rng, flat_model, n, contact)
+    bf = rng.normal(size=(n, 13, 3)) * 10.0
+    bt = rng.normal(size=(n, 13, 3)) * 2.0
+    dev = env.device
+    f32 = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
+    root_t, dof_t = gym.acquire_actor_root_state_tensor(), gym.acquire_dof_state_tensor().view(n, 12, 2)
+    contact_t, body_t = gym.acquire_net_contact_force_tensor().view(n, 13, 3), gym.acquire_rigid_body_state_tensor().view(n, 13, 13)
+    root_t.copy_(f32(root)); dof_t[..., 0] = f32(q); dof_t[..., 1] = f32(qd)
+    gym.set_dof_actuation_force_tensor(f32(tau))
+    gym.apply_rigid_body_force_tensors(f32(bf), f32(bt), "LOCAL_SPACE")
+    gym.simulate()
+    got1 = (root_t.cpu().numpy().astype(np.float64), dof_t.cpu().numpy().astype(np.float64), contact_t.cpu().numpy().astype(np.float64),
+            body_t.cpu().numpy().astype(np.float64))
+    gym.simulate()  # applied forces were consumed by the first simulate; the actuation persists
+    got2 = (root_t.cpu().numpy().astype(np.float64), dof_t.cpu().numpy().astype(np.float64))
+
+    r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
+    worst = [0.0, 0.0]
+    ncontact = 0
+    for e in range(n):
+        par = dict(mass_scale=r32(env._mass_scale[e]), com_off=r32(env._com_off[e]), foot_mat=r32(env._foot_mat[e]).reshape(6))
+        r, qq, qv = r32(root[e]), r32(q[e]), r32(qd[e])
+        qa, _ = ref.forward_bw(r, qq, qv, r32(tau[e]), r32(bf[e]), r32(bt[e]), **par)
+        cf = ref.step_bw(r, qq, qv, r32(tau[e]), r32(bf[e]), r32(bt[e]), **par)
+        scale = max(1.0, np.abs(qa).max())
+        # velocities moved by dt * qacc: compare in acceleration units, allowing the fp32 rounding of the stored state itself
+        vel_g = np.concatenate([got1[0][e, 7:13], got1[1][e, :, 1]]); vel_r = np.concatenate([r[7:13], qv])
+        slack = 2e-7 * max(1.0, np.abs(vel_r).max()) / dt
+        worst[0] = max(worst[0], (np.abs(vel_g - vel_r).max() / dt - slack) / scale)
+        assert np.abs(got1[0][e, :7] - r[:7]).max() < 2e-6 * max(1.0, np.abs(r[:3]).max()) + dt * dt * tol * scale
+        assert np.abs(got1[1][e, :, 0] - qq).max() < 2e-6 + dt * dt * tol * scale
+        if np.abs(cf).max() > 0:
+            ncontact += 1
+            assert np.abs(got1[2][e] - cf).max() <= 2e-3 * max(1.0, np.abs(cf).max())
+        else:
+            assert np.abs(got1[2][e]).max() == 0.0
+        # rigid-body rows follow from the (GPU) post-step state
+        bs = ref.body_states(got1[0][e], got1[1][e, :, 0], got1[1][e, :, 1])
+        gb = got1[3][e]
+        assert np.abs(gb[:, :3] - bs[:, :3]).max() < 2e-5
+        assert np.minimum(np.abs(gb[:, 3:7] - bs[:, 3:7]).max(axis=1), np.abs(gb[:, 3:7] + bs[:, 3:7]).max(axis=1)).max() < 2e-5
+        assert np.abs(gb[:, 7:] - bs[:, 7:]).max() < 2e-5 * max(1.0, np.abs(bs[:, 7:]).max())
+        # second step: same torques, no applied forces
+        r2, q2, v2 = got1[0][e].copy(), got1[1][e, :, 0].copy(), got1[1][e, :, 1].copy()
+        qa2, _ = ref.forward_bw(r2, q2, v2, r32(tau[e]), None, None, **par)
+        ref.step_bw(r2, q2, v2, r32(tau[e]), None, None, **par)
+        vel_g = np.concatenate([got2[0][e, 7:13], got2[1][e, :, 1]]); vel_r = np.concatenate([r2[7:13], v2])
+        scale2 = max(1.0, np.abs(qa2).max())
+        worst[1] = max(worst[1], (np.abs(vel_g - vel_r).max() / dt - 2e-7 * max(1.0, np.abs(vel_r).max()) / dt) / scale2)
+    assert worst[0] < tol and worst[1] < tol, worst
+    if contact:
+        assert ncontact > n // 4
+
+
+def test_decimation_loop_on_gym_calls_equals_fused_step(flat_model):
+    """t1.py:439-456 written against the granular calls reproduces the state the fused kernel reaches in one launch."""
+    n = 512
+    cfg, env, gym = _make(n)
+    env.reset()
+    dev = env.device
+    g = torch.Generator(device="cpu").manual_seed(5)
+    for _ in range(15):  # settle onto the ground with a few random steps so that contacts are active
+        env.step((0.2 * torch.randn(n, 12, generator=g)).to(dev))
+    env.common_step_counter = 7  # not a kick / push step
+    push = torch.randn(n, 6, generator=g).to(dev) * torch.tensor([10, 10, 10, 2, 2, 2.0], device=dev)
+    env.set_field("pushing", push)
+    root0, q0, qd0 = env.root_states.clone(), env.dof_pos.clone(), env.dof_vel.clone()
+    kp, kd, fric = env.get_field("dof_stiffness"), env.get_field("dof_damping"), env.get_field("dof_friction")
+    delay = env.get_field("delay_steps").view(n, 1)
+    last_tgt = env.get_field("last_dof_targets").clone()
+    limit = torch.tensor(flat_model.dof_effort, dtype=torch.float32, device=dev)
+    default = env.default_dof_pos.view(1, 12)
+    actions = (0.5 * torch.randn(n, 12, generator=g)).to(dev)
+
+    # ---- granular: the reference's loop on gym calls
+    root_t, dof_t = gym.acquire_actor_root_state_tensor(), gym.acquire_dof_state_tensor().view(n, 12, 2)
+    root_t.copy_(root0); dof_t[..., 0] = q0; dof_t[..., 1] = qd0
+    clip = cfg["normalization"]["clip_actions"]
+    target = default + cfg["control"]["action_scale"] * torch.clip(actions, -clip, clip)
+    forces = torch.zeros(n, 13, 3, device=dev); torques = torch.zeros(n, 13, 3, device=dev)
+    forces[:, 0] = push[:, :3]; torques[:, 0] = push[:, 3:]
+    gym.apply_rigid_body_force_tensors(forces, torques, "LOCAL_SPACE")
+    tsum = torch.zeros(n, 12, device=dev)
+    for s in range(cfg["control"]["decimation"]):
+        last_tgt = torch.where(delay == s, target, last_tgt)
+        t = kp * (last_tgt - dof_t[..., 0]) - kd * dof_t[..., 1]
+        t = t - torch.minimum(fric, t.abs()) * torch.sign(t)
+        t = torch.clip(t, -limit, limit)
+        tsum += t
+        gym.set_dof_actuation_force_tensor(t)
+        gym.simulate()
+        gym.fetch_results(True)
+        gym.refresh_dof_state_tensor()
+    # ---- fused
+    _, _, done, _ = env.step(actions)
+    keep = ~done.bool()
+    assert keep.float().mean() > 0.7
+    r1, q1, v1 = env.root_states[keep], env.dof_pos[keep], env.dof_vel[keep]
+    assert torch.allclose(root_t[keep][:, :7], r1[:, :7], atol=2e-5)
+    assert torch.allclose(root_t[keep][:, 7:], r1[:, 7:], atol=2e-3)
+    assert torch.allclose(dof_t[keep][..., 0], q1, atol=2e-5)
+    assert torch.allclose(dof_t[keep][..., 1], v1, atol=5e-3)
+    assert torch.allclose(tsum[keep] / cfg["control"]["decimation"], env.get_field("torques")[keep], atol=2e-2)
+    # the state did move (the comparison is not vacuous)
+    assert (dof_t[..., 0] - q0).abs().max() > 1e-3
+
+
+def test_write_back_and_errors(flat_model):
+    from booster_gym_amd import _lib
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+
+    n = 64
+    env0 = T1(load_cfg("T1", {"env.num_envs": n, "terrain.type": "plane"}))
+    with pytest.raises(RuntimeError, match="bg_sim_bind_state"):
+        _lib.check(env0._lib.bg_sim_simulate(env0._env, None), "bg_sim_simulate")
+    cfg, env, gym = _make(n)
+    with pytest.raises(ValueError):
+        gym.apply_rigid_body_force_tensors(torch.zeros(n, 13, 3), None, "ENV_SPACE")
+    with pytest.raises(ValueError):
+        gym.set_dof_actuation_force_tensor(torch.zeros(n, 11))
+    root_t = gym.acquire_actor_root_state_tensor()
+    body_t = gym.acquire_rigid_body_state_tensor().view(n, 13, 13)
+    mine = root_t.clone()
+    mine[:, 0] = torch.arange(n, device=mine.device, dtype=torch.float32)
+    mine[:, 2] = 0.72
+    ids = torch.tensor([3, 10, 63], dtype=torch.int32, device=mine.device)
+    gym.set_actor_root_state_tensor_indexed(mine, ids, 3)
+    torch.cuda.synchronize()
+    assert root_t[3, 0] == 3 and root_t[10, 0] == 10 and root_t[63, 0] == 63 and root_t[4, 0] == 0
+    assert torch.equal(body_t[:, 0, :3], root_t[:, :3])  # trunk row re-derived
+    assert (body_t[10, 6, 2] - (0.72 - 0.1155 - 0.02 - 0.081854 - 0.134 - 0.28 - 0.012)).abs() < 1e-5  # left foot below the trunk at q = 0

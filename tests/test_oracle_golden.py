@@ -218,6 +218,42 @@ def test_aba_equals_inverse_dynamics(dyn, flat_model):
     assert worst < 1e-9
 
 
+def test_body_wrench_semantics(dyn, flat_model):
+    """Per-body applied forces (gym.apply_rigid_body_force_tensors LOCAL_SPACE, t1.py:522-527): (1) a force on the trunk row acts at the
+    trunk's centre of mass = base wrench (f, t + c x f); (2) m_i * (-g) on every body cancels gravity exactly; (3) the body-state rows
+    agree with the pose query and with the root state."""
+    from oracle.dyn_ref import DynRef
+
+    m, rng = flat_model, np.random.default_rng(2)
+    d0 = DynRef(m, phys={"g": (0.0, 0.0, 0.0)})
+    for _ in range(50):
+        root = np.zeros(13); root[2] = 5.0
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 1.0)
+        root[3:6], root[6] = ax * np.sin(ang / 2), np.cos(ang / 2)
+        root[7:13] = rng.normal(size=6)
+        q, qd = rng.uniform(m.dof_lower, m.dof_upper), rng.normal(size=12)
+        tau = rng.uniform(-m.dof_effort, m.dof_effort)
+        ms, co = rng.uniform(0.8, 1.2, 13), rng.uniform(-0.05, 0.05, (13, 3))
+        f, t = rng.normal(size=3) * 10, rng.normal(size=3) * 2
+        bf, bt = np.zeros((13, 3)), np.zeros((13, 3)); bf[0], bt[0] = f, t
+        a1, _ = dyn.forward_bw(root, q, qd, tau, bf, bt, mass_scale=ms, com_off=co)
+        a2, _ = dyn.forward(root, q, qd, tau, base_wrench=np.concatenate([f, t + np.cross(m.com[0] + co[0], f)]), mass_scale=ms, com_off=co)
+        assert np.abs(a1 - a2).max() < 1e-9
+        pos, R = dyn.body_poses(root, q)
+        anti = np.stack([R[b].T @ (m.mass[b] * ms[b] * np.array([0, 0, 9.81])) for b in range(13)])
+        a3, _ = dyn.forward_bw(root, q, qd, tau, anti, None, mass_scale=ms, com_off=co)
+        a4, _ = d0.forward(root, q, qd, tau, mass_scale=ms, com_off=co)
+        assert np.abs(a3 - a4).max() < 1e-8 * max(1.0, np.abs(a4).max())
+        bs = dyn.body_states(root, q, qd)
+        assert np.abs(bs[:, :3] - pos).max() < 1e-12 and np.abs(bs[0, 7:] - root[7:]).max() < 1e-12
+        assert np.abs(np.abs(bs[0, 3:7]) - np.abs(root[3:7])).max() < 1e-12 and (bs[:, 6] >= 0).all()
+    # a step with applied forces integrates exactly the accelerations of forward_bw
+    r, qq, v = root.copy(), q.copy(), qd.copy()
+    dyn.step_bw(r, qq, v, tau, bf, bt, mass_scale=ms, com_off=co)
+    lim = m.dof_velocity
+    assert np.allclose(r[7:], root[7:] + dyn.phys.dt * a1[:6], atol=1e-12) and np.allclose(v, np.clip(qd + dyn.phys.dt * a1[6:], -lim, lim), atol=1e-12)
+
+
 def test_free_fall(dyn):
     root = np.zeros(13); root[2], root[6] = 5.0, 1.0
     qacc, cf = dyn.forward(root, np.zeros(12), np.zeros(12), np.zeros(12))
