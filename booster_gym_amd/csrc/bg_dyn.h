@@ -60,16 +60,65 @@ struct BaseState {
     V3 vlin, vang;  // world frame (Isaac Gym root-state layout, t1.py:221-222)
 };
 
-struct LegWork {  // what the inward sweep leaves behind for the outward sweep
+// Where the sweeps keep what they hand to each other: the per-link vectors v (outward -> inward), cb (outward -> inward, accel) and
+// U = IA S (inward -> accel), and the per-env link constants.  RegStore: everything in registers (the fused env step: one wave per CU at
+// 4096 envs, latency is all that matters).  LdsLinkStore: link constants in LDS, lane-contiguous (slot k of lane l at p[64 k],
+// conflict-free), which is what lets two waves share a SIMD in forward_dynamics_kernel once the chip is full.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(3))) float lds_f32;  // explicit LDS pointers: volatile accesses are not address-space-inferred
+#else
+typedef float lds_f32;
+#endif
+struct RegStore {
+    SV v[LEG_LINKS], cb[LEG_LINKS], U[LEG_LINKS];
+    template <int I> BG_HD void put_v(SV x) { v[I] = x; }
+    template <int I> BG_HD SV get_v() const { return v[I]; }
+    template <int I> BG_HD void put_cb(SV x) { cb[I] = x; }
+    template <int I> BG_HD SV get_cb() const { return cb[I]; }
+    template <int I> BG_HD void put_U(SV x) { U[I] = x; }
+    template <int I> BG_HD SV get_U() const { return U[I]; }
+    template <int I, class LP> BG_HD V3 link_pos(const LP& lp) const { return lp.lk[I].pos; }
+    template <int I, class LP> BG_HD LinkConst link(const LP& lp) const { return lp.lk[I]; }
+};
+// v / cb / U in registers, the per-env link constants (13 floats per link, computed once per launch) in LDS
+struct LdsLinkStore : RegStore {
+    static constexpr int SLOTS = 13 * LEG_LINKS, STRIDE = 64;
+    lds_f32* p;
+    template <class LP> BG_HD void stash(const LP& lp) const {
+        for (int i = 0; i < LEG_LINKS; i++) {
+            const LinkConst& k = lp.lk[i];
+            const float f[13] = {k.pos.e[0], k.pos.e[1], k.pos.e[2], k.m, k.mc.e[0], k.mc.e[1], k.mc.e[2],
+                                 k.Io.e[0], k.Io.e[1], k.Io.e[2], k.Io.e[3], k.Io.e[4], k.Io.e[5]};
+            for (int j = 0; j < 13; j++) p[(13 * i + j) * STRIDE] = f[j];
+        }
+    }
+    // volatile reads: a plain load is forwarded from the stash stores above and the constants stay in registers after all
+    template <int I, class LP> BG_HD V3 link_pos(const LP&) const {
+        const volatile lds_f32* q = p;
+        return v3(q[(13 * I) * STRIDE], q[(13 * I + 1) * STRIDE], q[(13 * I + 2) * STRIDE]);
+    }
+    template <int I, class LP> BG_HD LinkConst link(const LP&) const {
+        const volatile lds_f32* q = p;
+        LinkConst k;
+        k.pos = v3(q[(13 * I) * STRIDE], q[(13 * I + 1) * STRIDE], q[(13 * I + 2) * STRIDE]);
+        k.m = q[(13 * I + 3) * STRIDE];
+        k.mc = v3(q[(13 * I + 4) * STRIDE], q[(13 * I + 5) * STRIDE], q[(13 * I + 6) * STRIDE]);
+        for (int j = 0; j < 6; j++) k.Io.e[j] = q[(13 * I + 7 + j) * STRIDE];
+        return k;
+    }
+};
+
+template <class Store>
+struct LegWorkT {  // what the inward sweep leaves behind for the outward sweep
     float c[LEG_LINKS], s[LEG_LINKS];
-    SV cb[LEG_LINKS];  // velocity-product accelerations
-    SV U[LEG_LINKS];
+    Store st;
     float dinv[LEG_LINKS], u[LEG_LINKS];
     M3 Rfoot;          // foot -> world
     SI Bc;             // contact impedance on the foot
     SV f0c;            // contact wrench at the current state (foot coords)
     bool contact;
 };
+using LegWork = LegWorkT<RegStore>;
 
 struct BaseContribution { SI I; SV p; };  // articulated inertia / bias force seen at the trunk
 
@@ -125,8 +174,8 @@ BG_HD float terrain_height(const TerrainDev& t, float x, float y) {
 }
 
 // ---------------------------------------------------------------- outward sweep, link I
-template <int I>
-BG_HD void leg_outward(const LegParams& lp, const LegState& ls, LegWork& w, SV vpar, M3 Rpar, V3 ppar, SV* vout, V3* pfoot) {
+template <int I, class W>
+BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M3 Rpar, V3 ppar, SV* vfoot, V3* pfoot) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
     float s, c;
     bg_sincos(ls.q[I], &s, &c);
@@ -134,15 +183,18 @@ BG_HD void leg_outward(const LegParams& lp, const LegState& ls, LegWork& w, SV v
     // v_i = X v_parent + S qd :  w' = E w ; v' = E (v + w x r)
     SV v;
     v.a = rotT<AX>(c, s, vpar.a);
-    v.l = rotT<AX>(c, s, vpar.l + cross(vpar.a, lp.lk[I].pos));
+    const V3 lpos = w.st.template link_pos<I>(lp);
+    v.l = rotT<AX>(c, s, vpar.l + cross(vpar.a, lpos));
     // c_i = v_i x (S qd)   (S = unit angular axis A)
     V3 sq = v3(0.f, 0.f, 0.f); sq.e[A] = ls.qd[I];
-    w.cb[I].a = cross(v.a, sq);
-    w.cb[I].l = cross(v.l, sq);
+    SV cb;
+    cb.a = cross(v.a, sq);
+    cb.l = cross(v.l, sq);
+    w.st.template put_cb<I>(cb);
     v.a.e[A] += ls.qd[I];
-    vout[I] = v;
+    w.st.template put_v<I>(v);
     // world pose of the link (needed for the foot only, carried down the chain)
-    V3 p = ppar + mul(Rpar, lp.lk[I].pos);
+    V3 p = ppar + mul(Rpar, lpos);
     M3 R;  // R_world_child = R_world_parent * R(axis,q): rotate the columns J,K
     {
         constexpr int J = Plane<AX>::J, K = Plane<AX>::K;
@@ -153,15 +205,17 @@ BG_HD void leg_outward(const LegParams& lp, const LegState& ls, LegWork& w, SV v
         }
     }
     if constexpr (I + 1 < LEG_LINKS) {
-        leg_outward<I + 1>(lp, ls, w, v, R, p, vout, pfoot);
+        leg_outward<I + 1>(lp, ls, w, v, R, p, vfoot, pfoot);
     } else {
         w.Rfoot = R;
         *pfoot = p;
+        *vfoot = v;
     }
 }
 
 // ---------------------------------------------------------------- foot contact (4 sole corners)
-BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& lp, LegWork& w, SV vfoot, V3 pfoot, V3* force_w0) {
+template <class W>
+BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& lp, W& w, SV vfoot, V3 pfoot, V3* force_w0) {
     SI B; B.A = s3_zero(); B.H = m3_zero(); B.M = s3_zero();
     SV f0 = sv_zero();
     V3 fw_sum = v3(0.f, 0.f, 0.f);
@@ -205,8 +259,8 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
 }
 
 // ---------------------------------------------------------------- inward sweep, link I (child -> parent)
-template <int I>
-BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, const float* tau, LegWork& w, const SV* v, SI IA, SV pA,
+template <int I, class W>
+BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, const float* tau, W& w, SI IA, SV pA,
                       BaseContribution* out, const SV* fext) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
     // joint limit spring/damper, implicit in the joint velocity: tau_lim = t0 - bl * qdd
@@ -221,18 +275,18 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
     float d = U.a.e[A] + bl;
     float dinv = bg_rcp(d);
     float u = tau[I] + t0 - pA.a.e[A];
-    w.U[I] = U; w.dinv[I] = dinv; w.u[I] = u;
+    w.dinv[I] = dinv; w.u[I] = u;
     // Ia = IA - U U^T / d ;  pa = pA + Ia c + U u / d
     V3 Uad = dinv * U.a, Uld = dinv * U.l;
     M3 A1 = Af - outer(Uad, U.a), H1 = IA.H - outer(Uad, U.l), M1 = Mf - outer(Uld, U.l);
-    SV cb = w.cb[I];
+    SV cb = w.st.template get_cb<I>();
     SV pa;
     pa.a = pA.a + mul(A1, cb.a) + mul(H1, cb.l) + u * Uad;
     pa.l = pA.l + mulT(H1, cb.a) + mul(M1, cb.l) + u * Uld;
     // to parent coordinates: rotate by R(axis,q) then shift the origin by r = pos
     float c = w.c[I], s = w.s[I];
     A1 = rot_conj<AX>(c, s, A1); H1 = rot_conj<AX>(c, s, H1); M1 = rot_conj<AX>(c, s, M1);
-    V3 r = lp.lk[I].pos;
+    V3 r = w.st.template link_pos<I>(lp);
     M3 H2 = H1 + cross_cols(r, M1);
     M3 A2 = A1 + cross_cols(r, transpose(H1)) - mul_skew(H2, r);
     SV pp;
@@ -240,14 +294,16 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
     pp.a = rot<AX>(c, s, pa.a) + cross(r, pp.l);
     if constexpr (I > 0) {
         // parent's own rigid inertia and velocity-dependent bias
-        const LinkConst& pk = lp.lk[I - 1];
+        const LinkConst pk = w.st.template link<I - 1>(lp);
         SI IP = rigid_inertia(pk);
-        SV vp = v[I - 1];
+        SV vp = w.st.template get_v<I - 1>();
+        w.st.template put_U<I>(U);
         SV pP = crf(vp, mul_rigid(pk, vp));
         if (fext) pP = pP - fext[I - 1];
         IP.A = IP.A + upper(A2); IP.H = IP.H + H2; IP.M = IP.M + upper(M1);
-        leg_inward<I - 1>(ph, lp, ls, tau, w, v, IP, pP + pp, out, fext);
+        leg_inward<I - 1>(ph, lp, ls, tau, w, IP, pP + pp, out, fext);
     } else {
+        w.st.template put_U<I>(U);
         out->I.A = upper(A2); out->I.H = H2; out->I.M = upper(M1);
         out->p = pp;
     }
@@ -256,15 +312,16 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
 // Everything a lane does before the pair exchange: kinematics, contact, inward sweep.
 // gb = gravity in base coordinates.  Returns this leg's contribution at the trunk.
 // fext (optional): applied wrench on each link about its own origin, link coordinates (a = torque, l = force).
+template <class W>
 BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
-                                  const BaseState& bs, M3 R0, SV v0, LegWork& w, V3* foot_force_w0, const SV* fext = nullptr) {
-    SV v[LEG_LINKS];
+                                  const BaseState& bs, M3 R0, SV v0, W& w, V3* foot_force_w0, const SV* fext = nullptr) {
+    SV vfoot;
     V3 pfoot;
-    leg_outward<0>(lp, ls, w, v0, R0, bs.pos, v, &pfoot);
-    foot_contact(ph, tr, lp, w, v[LEG_LINKS - 1], pfoot, foot_force_w0);
-    const LinkConst& fk = lp.lk[LEG_LINKS - 1];
+    leg_outward<0>(lp, ls, w, v0, R0, bs.pos, &vfoot, &pfoot);
+    foot_contact(ph, tr, lp, w, vfoot, pfoot, foot_force_w0);
+    const LinkConst fk = w.st.template link<LEG_LINKS - 1>(lp);
     SI IA = rigid_inertia(fk);
-    SV pA = crf(v[LEG_LINKS - 1], mul_rigid(fk, v[LEG_LINKS - 1]));
+    SV pA = crf(vfoot, mul_rigid(fk, vfoot));
     if (fext) pA = pA - fext[LEG_LINKS - 1];
     if (w.contact) {
         // f_ext = f0 - B a_true = (f0 - B ag) - B a'   with a' = a_true - ag  (gravity field in foot coords)
@@ -274,7 +331,7 @@ BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const Le
         pA = pA - (w.f0c - Bag);
     }
     BaseContribution out;
-    leg_inward<LEG_LINKS - 1>(ph, lp, ls, tau, w, v, IA, pA, &out, fext);
+    leg_inward<LEG_LINKS - 1>(ph, lp, ls, tau, w, IA, pA, &out, fext);
     return out;
 }
 
@@ -292,15 +349,15 @@ BG_HD SV base_solve(const SI& I, SV p) {
 }
 
 // ---------------------------------------------------------------- outward acceleration sweep + joint integration
-template <int I>
-BG_HD void leg_accel(const Phys& ph, const LegParams& lp, LegState& ls, const LegWork& w, SV apar, float* qdd, SV* afoot) {
+template <int I, class W>
+BG_HD void leg_accel(const Phys& ph, const LegParams& lp, LegState& ls, const W& w, SV apar, float* qdd, SV* afoot) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
     float c = w.c[I], s = w.s[I];
     SV a;
     a.a = rotT<AX>(c, s, apar.a);
-    a.l = rotT<AX>(c, s, apar.l + cross(apar.a, lp.lk[I].pos));
-    a = a + w.cb[I];
-    float qa = (w.u[I] - dot(w.U[I], a)) * w.dinv[I];
+    a.l = rotT<AX>(c, s, apar.l + cross(apar.a, w.st.template link_pos<I>(lp)));
+    a = a + w.st.template get_cb<I>();
+    float qa = (w.u[I] - dot(w.st.template get_U<I>(), a)) * w.dinv[I];
     a.a.e[A] += qa;
     qdd[I] = qa;
     if constexpr (I + 1 < LEG_LINKS) leg_accel<I + 1>(ph, lp, ls, w, a, qdd, afoot);
@@ -460,17 +517,22 @@ BG_HD LinkConst load_base_link(const ModelDev& m, int e, int n, const float* mas
 }
 
 // ---------------------------------------------------------------- one substep, split around the lane-pair exchange
-struct SubstepCtx { M3 R0; SV v0; LegWork w; };
+template <class W>
+struct SubstepCtxT { M3 R0; SV v0; W w; };
+using SubstepCtx = SubstepCtxT<LegWork>;
+using SubstepCtxLdsLink = SubstepCtxT<LegWorkT<LdsLinkStore>>;
 
+template <class Ctx>
 BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
-                                   const BaseState& bs, SubstepCtx& cx, const SV* fext = nullptr) {
+                                   const BaseState& bs, Ctx& cx, const SV* fext = nullptr) {
     cx.R0 = quat_to_mat(bs.quat);
     cx.v0 = base_body_velocity(cx.R0, bs);
     V3 unused;
     return leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused, fext);
 }
 // `both` = this leg's contribution + the partner leg's.  Returns accelerations; does not integrate.
-BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& lp, LegState& ls, const SubstepCtx& cx, const BaseContribution& both,
+template <class Ctx>
+BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& lp, LegState& ls, const Ctx& cx, const BaseContribution& both,
                          SV wrench, float* qdd, V3* lin_w, V3* ang_w, V3* foot_force_w) {
     BaseContribution own = base_own(bk, cx.v0, wrench);
     SI I; I.A = own.I.A + both.I.A; I.H = own.I.H + both.I.H; I.M = own.I.M + both.I.M;

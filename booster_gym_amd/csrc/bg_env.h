@@ -88,18 +88,18 @@ BG_HD float pymod(float x, float m) {  // python / torch `%` (floor mod) for m >
 BG_HD float wrap_pi(float x) { return pymod(x + 3.14159265358979f, 6.28318530717959f) - 3.14159265358979f; }
 
 // foot pose after the last substep (positions only)
-template <int I>
-BG_HD void leg_fk(const LegParams& lp, const LegState& ls, M3 Rpar, V3 ppar, M3* Rf, V3* pf) {
+template <int I, class St>
+BG_HD void leg_fk(const St& st, const LegParams& lp, const LegState& ls, M3 Rpar, V3 ppar, M3* Rf, V3* pf) {
     constexpr int AX = LEG_AXIS[I], J = Plane<AX>::J, K = Plane<AX>::K;
     float s, c;
     bg_sincos(ls.q[I], &s, &c);
-    V3 p = ppar + mul(Rpar, lp.lk[I].pos);
+    V3 p = ppar + mul(Rpar, st.template link_pos<I>(lp));
     M3 R = Rpar;
     for (int r = 0; r < 3; r++) {
         R.e[r][J] = c * Rpar.e[r][J] + s * Rpar.e[r][K];
         R.e[r][K] = -s * Rpar.e[r][J] + c * Rpar.e[r][K];
     }
-    if constexpr (I + 1 < LEG_LINKS) leg_fk<I + 1>(lp, ls, R, p, Rf, pf);
+    if constexpr (I + 1 < LEG_LINKS) leg_fk<I + 1>(st, lp, ls, R, p, Rf, pf);
     else { *Rf = R; *pf = p; }
 }
 
@@ -171,6 +171,8 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
     V3 foot_force = v3(0.f, 0.f, 0.f);
     for (int i = 0; i < LEG_LINKS; i++) { tmean[i] = 0.f; a6[i] = FLD(F_ACT, j0 + i); }
 
+    typename Sink::Ctx cx;  // sweep work space; the sink decides where the per-env link constants live (registers or LDS)
+    sink.bind(cx, lp);
     if (mode == 0) {
         // ------------------------------------------------------------ pre-physics (t1.py:439-440)
         float target[LEG_LINKS];
@@ -191,7 +193,6 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
                 tau[i] = pd_torque(kp[i], kd[i], fric[i], M.tau_lim[j0 + i], last_tgt[i], ls.q[i], ls.qd[i]);
                 tmean[i] += tau[i];
             }
-            SubstepCtx cx;
             BaseContribution mine = substep_pre(ph, E.terrain, lp, ls, tau, bs, cx);
             BaseContribution both;
             for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
@@ -237,7 +238,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
         filt_ang = C.filter_weight * base_ang + (1.0f - C.filter_weight) * filt_ang;
     }
     M3 Rf; V3 pf;
-    leg_fk<0>(lp, ls, R0, bs.pos, &Rf, &pf);
+    leg_fk<0>(cx.w.st, lp, ls, R0, bs.pos, &Rf, &pf);
     float roll = atan2f(Rf.e[2][1], Rf.e[2][2]), yaw = atan2f(Rf.e[1][0], Rf.e[0][0]);  // get_euler_xyz, wrapped to (-pi, pi]
     float fcontact = 0.f;
     for (int k = 0; k < 4; k++) {

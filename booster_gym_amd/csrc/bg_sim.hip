@@ -58,6 +58,10 @@ struct DppSwap {
 
 struct LdsSink {
     float* obs; float* priv; int el;
+    // sweep work space of the fused step: everything in registers.  (Staging the link constants in LDS as forward_dynamics_kernel does
+    // removes all spills here too, but the 10 substeps re-read them and the step got 3-5 % slower at every N: measured, not adopted.)
+    using Ctx = SubstepCtx;
+    __device__ __forceinline__ void bind(Ctx&, const LegParams&) const {}
     __device__ __forceinline__ void put_obs(int k, float v) { obs[el * BG_NUM_OBS + k] = v; }
     __device__ __forceinline__ void put_priv(int k, float v) { priv[el * BG_NUM_PRIV + k] = v; }
 };
@@ -85,7 +89,12 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __r
 }
 
 // ------------------------------------------------------------------ dynamics only: qacc for N independent states
-__global__ __launch_bounds__(64) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
+// One substep's accelerations per launch.  This is the kernel the ABA roofline is quoted on, and the regime that matters for it is a FULL
+// chip (>= 65k envs), where throughput = VALU issue slots: a wave64 fp32 instruction holds its SIMD for 4 cycles and the kernel is ~3,400 of
+// them per wave.  With everything in registers the kernel needs 282 and one wave fits per SIMD (77 % VALU-busy, the rest is exposed load
+// and dependency latency).  Keeping the per-env link constants (13 floats x 6 links per lane, computed once per launch) in LDS brings it to
+// 248 registers with no spill, two waves share a SIMD and cover each other's stalls: 88 % VALU-busy, +14 % throughput at 1M envs.
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
                                                               const float* __restrict__ qd, const float* __restrict__ tau,
                                                               const float* __restrict__ wrench, float* __restrict__ qacc) {
     const int lane = threadIdx.x, leg = lane & 1;
@@ -111,7 +120,10 @@ __global__ __launch_bounds__(64) void forward_dynamics_kernel(EnvDev E, const fl
     SV wr = sv_zero();
     if (wrench) { const float* w = wrench + (size_t)e * 6; wr.l = v3(w[0], w[1], w[2]); wr.a = v3(w[3], w[4], w[5]); }
     DppSwap x;
-    SubstepCtx cx;
+    __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
+    SubstepCtxLdsLink cx;
+    cx.w.st.p = (lds_f32*)(s_work + lane);
+    cx.w.st.stash(lp);
     BaseContribution mine = substep_pre(ph, E.terrain, lp, ls, t6, bs, cx), both;
     for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
