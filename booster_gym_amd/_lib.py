@@ -66,12 +66,15 @@ class EnvCfg(C.Structure):
 
 
 # every symbol include/booster_gym_amd.h declares (tests check that the .so exports all of them)
+HEAD_SCRATCH_FLOATS = 768 * 1720  # BG_HEAD_SCRATCH_FLOATS
+
 SYMBOLS = [
     "bg_model_create", "bg_model_get", "bg_model_destroy", "bg_env_create", "bg_env_destroy", "bg_env_set_heightfield",
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
     "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
     "bg_env_forward_dynamics", "bg_sim_bind_state", "bg_sim_set_actuation", "bg_sim_apply_body_wrench_local", "bg_sim_simulate",
     "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward",
+    "bg_critic_head_forward", "bg_actor_head", "bg_critic_head_backward",
     "bg_last_error", "bg_version",
 ]
 
@@ -128,6 +131,9 @@ def load():
         "bg_elu_backward_colsum": (i32, [i32, i32, vp, vp, vp, vp, vp]),
         "bg_mlp_layer_forward": (i32, [i32, i32, i32, vp, vp, vp, vp, i32, vp]),
         "bg_mlp_layer_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
+        "bg_critic_head_forward": (i32, [i32, vp, vp, vp, vp, vp]),
+        "bg_actor_head": (i32, [i32, i32] + [vp] * 10 + [f32, f32, f32] + [vp] * 9),
+        "bg_critic_head_backward": (i32, [i32] + [vp] * 11),
         "bg_last_error": (C.c_char_p, []),
         "bg_version": (C.c_char_p, []),
     }

@@ -1,0 +1,386 @@
+// Output ("head") layers of the two MLPs fused with the loss (gfx950 only).
+//
+// The 128 -> 12 (actor) and 128 -> 1 (critic) output layers of reference utils/model.py:9-26 are skinny: as library GEMMs + elementwise
+// kernels they cost 7 launches per network and mini-epoch, each re-reading the [B][128] hidden activations (50 MB at B = 98,304), for work
+// that is HBM-bound.  Here one launch per network reads the hidden activations once:
+//   bg_actor_head           mu = h W^T + b -> PPO actor loss forward + analytic backward (runner.py:145-174, bg_ppo_math.h) ->
+//                           dL/dz of the last hidden layer (g W * elu'(h)), weight / bias gradients of the output layer, bias gradient of the
+//                           hidden layer, log-std gradient and the loss statistics
+//   bg_critic_head_forward  values = h w + b for every row (the GAE scan between forward and backward needs all of them first)
+//   bg_critic_head_backward value loss (runner.py:148) backward through the output layer into the last hidden layer
+// Arithmetic is plain fp32 FMA on the vector ALU: 4.6 kflop per row against 1 KB of traffic is under the HBM ridge, so nothing here is
+// reshaped into an MFMA GEMM.  Reductions over rows are deterministic: every workgroup writes its partial sums, a second kernel adds them
+// in a fixed order (the loss statistics and the log-std gradient keep the float64 atomics of bg_ppo_loss).
+#include <hip/hip_runtime.h>
+
+#include "../../include/booster_gym_amd.h"
+#include "bg_ppo_math.h"
+
+extern int bg_set_error(int code, const char* msg);
+#define HIP_OK(expr)                                                          \
+    do {                                                                      \
+        hipError_t _e = (expr);                                               \
+        if (_e != hipSuccess) return bg_set_error(-2, hipGetErrorString(_e)); \
+    } while (0)
+
+namespace {
+
+constexpr int HK = 128;    // hidden width (both networks end in a 128-wide ELU layer)
+constexpr int HT = 64;     // rows per tile
+constexpr int HLD = 132;   // LDS row stride of the activation tile: 16-byte aligned, rows 4 banks apart
+constexpr int HA = BG_NUM_DOFS;
+constexpr int HEAD_MAX_GRID = 768;
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float elu_grad_from_output(float a) { return a > 0.f ? 1.0f : a + 1.0f; }
+
+// coalesced load of a [HT][HK] activation tile into LDS (rows past B read as zero)
+__device__ __forceinline__ void load_tile(const float* __restrict__ h, int row0, int B, float* s_h) {
+#pragma unroll
+    for (int i = 0; i < HT * HK / 4 / 256; i++) {
+        const int idx = threadIdx.x + 256 * i, r = idx >> 5, c4 = idx & 31;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < B) v = *reinterpret_cast<const float4*>(h + (size_t)(row0 + r) * HK + c4 * 4);
+        *reinterpret_cast<float4*>(s_h + r * HLD + c4 * 4) = v;
+    }
+}
+
+// Per-workgroup partial sums, added in a fixed order by head_finish_kernel.  scratch = [HEAD_MAX_GRID records of head_record<NO>() floats:
+// [NO][HK] output-layer weight gradient, [HK] hidden bias gradient, [NO] output bias gradient] followed by the float64 loss statistics,
+// statistic-major [HEAD_NSTAT][groups].  (Float64 atomics from every workgroup on the 17 shared addresses cost 45-60 us per launch.)
+constexpr int HEAD_NSTAT = HA + 5;
+template <int NO> constexpr int head_record() { return NO * HK + HK + 16; }
+template <int NO> constexpr size_t head_stat_base() { return (size_t)HEAD_MAX_GRID * head_record<NO>(); }  // even: float64 aligned
+
+__device__ __forceinline__ float quad_sum(float v) {  // sum over the 4 lanes of a quad (DPP quad_perm)
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // [1,0,3,2]
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // [2,3,0,1]
+    return v;
+}
+// sum over the 16 lanes of a wave that share (lane & 3); valid in lanes 0..3
+__device__ __forceinline__ double quadcol_sum(double v) {
+    for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+__device__ __forceinline__ float quadcol_sum(float v) {
+    for (int o = 32; o >= 4; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+// MODE 0: forward only (mu_out), MODE 1: forward + loss + backward.
+// Thread mappings: forward + loss: thread = (row t >> 2 of the tile, actions 3 (t & 3) .. + 2), the four threads of a row exchange their
+// partial log-prob / KL / bound sums with two DPP moves; backward: thread = (hidden column t & 127, row half t >> 7) with its column of W and
+// its accumulators in registers for the whole launch.
+template <int MODE>
+__global__ __launch_bounds__(256) void actor_head_kernel(int B, int tiles, const float* __restrict__ h, const float* __restrict__ W,
+                                                         const float* __restrict__ bias, const float* __restrict__ logstd,
+                                                         const float* __restrict__ actions, const float* __restrict__ old_mu,
+                                                         const float* __restrict__ old_logstd, const float* __restrict__ old_logp,
+                                                         const float* __restrict__ adv, const double* __restrict__ adv_stats, float e_clip,
+                                                         float bound_coef, float* __restrict__ mu_out, float* __restrict__ g_hidden,
+                                                         float* __restrict__ partial) {
+    constexpr int A = HA;
+    __shared__ __attribute__((aligned(16))) float s_h[HT * HLD];
+    __shared__ __attribute__((aligned(16))) float s_w[A * HK];
+    __shared__ __attribute__((aligned(16))) float s_g[HT * A];  // dL/dmu of the tile's rows
+    const int t = threadIdx.x;
+    for (int i = t; i < A * HK; i += 256) s_w[i] = W[i];
+    const int fr = t >> 2, fq = t & 3;
+    float fb[3];
+    for (int i = 0; i < 3; i++) fb[i] = bias[3 * fq + i];
+    const int kc = t & (HK - 1), half = t >> 7;
+    float wcol[A], dW[A], cs = 0.f;
+    for (int j = 0; j < A; j++) { wcol[j] = MODE == 1 ? W[j * HK + kc] : 0.f; dW[j] = 0.f; }
+    // loss constants of this thread's three actions (bg_ppo_math.h states the same formulas for a whole row)
+    float ls[3], ols[3], isig2[3], osig2[3], dbias[3] = {0.f, 0.f, 0.f};
+    float ent = 0.f, mean = 0.f, inv_std = 0.f, invB = 0.f, bscale = 0.f;
+    double acc_ls[3] = {0.0, 0.0, 0.0}, acc_st[4] = {0.0, 0.0, 0.0, 0.0};
+    if (MODE == 1) {
+        bg::ActorLossConsts<A> c;
+        bg::actor_loss_consts<A>(c, B, logstd, old_logstd, adv_stats, e_clip, bound_coef);
+        for (int i = 0; i < 3; i++) { ls[i] = logstd[3 * fq + i]; ols[i] = old_logstd[3 * fq + i]; }
+        for (int i = 0; i < 3; i++) { const float sg = expf(ls[i]), os = expf(ols[i]); isig2[i] = 1.0f / (sg * sg); osig2[i] = os * os; }
+        ent = c.ent; mean = c.mean; inv_std = c.inv_std; invB = c.invB; bscale = c.bscale;
+    }
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int row0 = tile * HT;
+        load_tile(h, row0, B, s_h);
+        __syncthreads();
+        {   // mu = h W^T + b
+            float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+            const float4* hr = reinterpret_cast<const float4*>(s_h + fr * HLD);
+            const float4* w0 = reinterpret_cast<const float4*>(s_w + (3 * fq) * HK);
+            const float4* w1 = reinterpret_cast<const float4*>(s_w + (3 * fq + 1) * HK);
+            const float4* w2 = reinterpret_cast<const float4*>(s_w + (3 * fq + 2) * HK);
+#pragma unroll 2
+            for (int k4 = 0; k4 < HK / 4; k4++) {
+                const float4 x = hr[k4], u = w0[k4], v = w1[k4], w = w2[k4];
+                a0 = fmaf(x.x, u.x, a0); a0 = fmaf(x.y, u.y, a0); a0 = fmaf(x.z, u.z, a0); a0 = fmaf(x.w, u.w, a0);
+                a1 = fmaf(x.x, v.x, a1); a1 = fmaf(x.y, v.y, a1); a1 = fmaf(x.z, v.z, a1); a1 = fmaf(x.w, v.w, a1);
+                a2 = fmaf(x.x, w.x, a2); a2 = fmaf(x.y, w.y, a2); a2 = fmaf(x.z, w.z, a2); a2 = fmaf(x.w, w.w, a2);
+            }
+            const float m[3] = {a0 + fb[0], a1 + fb[1], a2 + fb[2]};
+            const int b = row0 + fr;
+            const bool live = b < B;
+            const size_t o = (size_t)(live ? b : B - 1) * A + 3 * fq;
+            if (mu_out && live) for (int i = 0; i < 3; i++) mu_out[o + i] = m[i];
+            if (MODE == 1) {
+                float d[3], hl[3], lp = 0.f, kl = 0.f, bound = 0.f;
+                for (int i = 0; i < 3; i++) {
+                    d[i] = actions[o + i] - m[i];
+                    lp += -0.5f * d[i] * d[i] * isig2[i] - ls[i] - bg::kHalfLog2Pi;
+                    const float dm = m[i] - old_mu[o + i];
+                    kl += ls[i] - ols[i] + 0.5f * (osig2[i] + dm * dm) * isig2[i] - 0.5f;
+                    const float hi = fmaxf(m[i] - 1.0f, 0.f), lo = fminf(m[i] + 1.0f, 0.f);
+                    bound += hi * hi + lo * lo;
+                    hl[i] = hi + lo;
+                }
+                lp = quad_sum(lp); kl = quad_sum(kl); bound = quad_sum(bound);
+                const float An = (adv[live ? b : B - 1] - mean) * inv_std;
+                const float ratio = expf(lp - old_logp[live ? b : B - 1]);
+                const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
+                const float s1 = -An * ratio, s2 = -An * rc;
+                // d max(s1,s2)/d logp: through s1 when it wins or ties, through the clamp only inside the clip range
+                const bool inside = ratio >= 1.0f - e_clip && ratio <= 1.0f + e_clip;
+                const float dlogp = (live && (inside || s1 > s2)) ? -An * ratio * invB : 0.f;
+                for (int i = 0; i < 3; i++) {
+                    const float gm = live ? dlogp * d[i] * isig2[i] + bscale * hl[i] : 0.f;
+                    s_g[fr * A + 3 * fq + i] = gm;
+                    dbias[i] += gm;
+                    acc_ls[i] += (double)(dlogp * (d[i] * d[i] * isig2[i] - 1.0f));
+                }
+                if (live && fq == 0) {
+                    acc_st[0] += (double)fmaxf(s1, s2); acc_st[1] += (double)bound; acc_st[2] += (double)ent; acc_st[3] += (double)kl;
+                }
+            }
+        }
+        __syncthreads();
+        if (MODE == 1) {
+            // g_hidden = (dL/dmu W) * elu'(h), dW += dL/dmu^T h, hidden bias gradient = column sums of g_hidden
+            for (int rr = 0; rr < HT / 2; rr++) {
+                const int r = half * (HT / 2) + rr;
+                const float hv = s_h[r * HLD + kc];
+                const float4* gp = reinterpret_cast<const float4*>(s_g + r * A);
+                const float4 g0 = gp[0], g1 = gp[1], g2 = gp[2];
+                const float g[A] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w, g2.x, g2.y, g2.z, g2.w};
+                float sa = 0.f, sb = 0.f;
+#pragma unroll
+                for (int j = 0; j < A; j += 2) {
+                    sa = fmaf(g[j], wcol[j], sa); sb = fmaf(g[j + 1], wcol[j + 1], sb);
+                    dW[j] = fmaf(g[j], hv, dW[j]); dW[j + 1] = fmaf(g[j + 1], hv, dW[j + 1]);
+                }
+                const float gz = (sa + sb) * elu_grad_from_output(hv);
+                cs += gz;
+                if (row0 + r < B) g_hidden[(size_t)(row0 + r) * HK + kc] = gz;
+            }
+            __syncthreads();
+        }
+    }
+    if (MODE == 0) return;
+    // ---- this workgroup's partial sums: the two row halves of the column-mapped sums meet in LDS
+    float* red = s_h;  // [2][A + 1][HK]
+    for (int j = 0; j < A; j++) red[(half * (A + 1) + j) * HK + kc] = dW[j];
+    red[(half * (A + 1) + A) * HK + kc] = cs;
+    __syncthreads();
+    float* rec = partial + (size_t)blockIdx.x * head_record<A>();
+    for (int i = t; i < (A + 1) * HK; i += 256) rec[i] = red[i] + red[(A + 1) * HK + i];
+    // per-action sums: lanes sharing (lane & 3) within a wave, then the four waves through LDS.  slot = 3 fq + i; slots 12..15 = loss terms.
+    const int wave = t >> 6, lane = t & 63;
+    __syncthreads();
+    float* redf = s_h;          // [4 waves][16]
+    double* redd = reinterpret_cast<double*>(s_h + 64);  // [4 waves][16]
+    for (int i = 0; i < 3; i++) {
+        const float v = quadcol_sum(dbias[i]);
+        const double w = quadcol_sum(acc_ls[i]);
+        if (lane < 4) { redf[wave * 16 + 3 * lane + i] = v; redd[wave * 16 + 3 * lane + i] = w; }
+    }
+    for (int i = 0; i < 4; i++) {
+        const double w = quadcol_sum(acc_st[i]);  // only fq == 0 lanes carry values
+        if (lane == 0) redd[wave * 16 + 12 + i] = w;
+    }
+    __syncthreads();
+    if (t < 16) {
+        double* srec = reinterpret_cast<double*>(partial + head_stat_base<A>());
+        const double w = redd[t] + redd[16 + t] + redd[32 + t] + redd[48 + t];
+        // statistic index: [0, A) dL/dlogstd, A unused (the value error is the critic head's), A+1.. = surrogate, bound, entropy, kl
+        const int k = t < A ? t : t + 1;
+        srec[(size_t)k * gridDim.x + blockIdx.x] = w;
+        if (t < A) rec[(A + 1) * HK + t] = redf[t] + redf[16 + t] + redf[32 + t] + redf[48 + t];
+    }
+}
+
+__global__ __launch_bounds__(256) void critic_head_backward_kernel(int B, int tiles, const float* __restrict__ h, const float* __restrict__ w,
+                                                                   const float* __restrict__ values, const float* __restrict__ returns,
+                                                                   float* __restrict__ g_hidden, float* __restrict__ partial) {
+    __shared__ __attribute__((aligned(16))) float s_h[HT * HLD];
+    __shared__ float s_g[HT];
+    const int t = threadIdx.x, kc = t & (HK - 1), half = t >> 7;
+    const float wk = w[kc], invB = 1.0f / (float)B;
+    float dW = 0.f, cs = 0.f, db = 0.f;
+    double verr2 = 0.0;
+    for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
+        const int row0 = tile * HT;
+        load_tile(h, row0, B, s_h);
+        if (t < HT) {
+            const int b = row0 + t;
+            float g = 0.f;
+            if (b < B) {
+                const float verr = values[b] - returns[b];
+                g = 2.0f * verr * invB;  // d mean((v - ret)^2) / dv, runner.py:148
+                verr2 += (double)(verr * verr);
+                db += g;
+            }
+            s_g[t] = g;
+        }
+        __syncthreads();
+        for (int rr = 0; rr < HT / 2; rr++) {
+            const int r = half * (HT / 2) + rr;
+            const float hv = s_h[r * HLD + kc], g = s_g[r];
+            dW = fmaf(g, hv, dW);
+            const float gz = g * wk * elu_grad_from_output(hv);
+            cs += gz;
+            if (row0 + r < B) g_hidden[(size_t)(row0 + r) * HK + kc] = gz;
+        }
+        __syncthreads();
+    }
+    float* red = s_h;  // [2][2][HK]
+    red[(half * 2) * HK + kc] = dW;
+    red[(half * 2 + 1) * HK + kc] = cs;
+    __syncthreads();
+    float* rec = partial + (size_t)blockIdx.x * head_record<1>();
+    for (int i = t; i < 2 * HK; i += 256) rec[i] = red[i] + red[2 * HK + i];
+    if (t < 64) {
+        float v = db;
+        for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+        const double s = wave_sum_d(verr2);
+        if (t == 0) { rec[2 * HK] = v; reinterpret_cast<double*>(partial + head_stat_base<1>())[blockIdx.x] = s; }
+    }
+}
+
+// fixed-order sum of the workgroups' records: out[i] = sum_g partial[g][i]; 16 outputs x 16 record slices per workgroup.  The LAST workgroup
+// adds up the float64 statistics (stat-major [n_stat][groups] at stat_base) and issues one atomic per statistic: k < n_ls goes to
+// grad_logstd[k] (+ entropy_coef: d(entropy.mean())/dlogstd = 1), the rest to stats[k - n_ls]; statistics whose stat_skip bit is set are skipped.
+__global__ __launch_bounds__(256) void head_finish_kernel(int groups, int record, int n_out, const float* __restrict__ partial, float* __restrict__ grad_w,
+                                                          int n_w, float* __restrict__ grad_b_hidden, float* __restrict__ grad_b, size_t stat_base,
+                                                          int n_stat, int n_ls, unsigned stat_skip, double entropy_coef,
+                                                          double* __restrict__ grad_logstd, double* __restrict__ stats) {
+    if (blockIdx.x == gridDim.x - 1) {
+        __shared__ double sd[4];
+        const double* sp = reinterpret_cast<const double*>(partial + stat_base);
+        for (int k = 0; k < n_stat; k++) {
+            if ((stat_skip >> k) & 1u) continue;
+            double s = 0.0;
+            for (int g = threadIdx.x; g < groups; g += 256) s += sp[(size_t)k * groups + g];
+            s = wave_sum_d(s);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const double v = sd[0] + sd[1] + sd[2] + sd[3];
+                if (k < n_ls) atomicAdd(&grad_logstd[k], v + entropy_coef);
+                else atomicAdd(&stats[k - n_ls], v);
+            }
+        }
+        return;
+    }
+    __shared__ float sm[16][17];
+    const int o = threadIdx.x & 15, gs = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
+    float s = 0.f;
+    if (i < n_out)
+        for (int g = gs; g < groups; g += 16) s += partial[(size_t)g * record + i];
+    sm[gs][o] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && i < n_out) {
+        float v = 0.f;
+        for (int k = 0; k < 16; k++) v += sm[k][o];
+        if (i < n_w) grad_w[i] = v;
+        else if (i < n_w + HK) grad_b_hidden[i - n_w] = v;
+        else grad_b[i - n_w - HK] = v;
+    }
+}
+
+// values = h w + b: half a wave per row (32 lanes x 16 bytes = one 512-byte row), 4 rows in flight per half-wave
+__global__ __launch_bounds__(256) void critic_head_forward_kernel(int rows, const float* __restrict__ h, const float* __restrict__ w,
+                                                                  const float* __restrict__ b, float* __restrict__ values) {
+    const int lane = threadIdx.x & 31;
+    const int hw = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, nhw = (gridDim.x * blockDim.x) >> 5;
+    const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4);
+    const float bias = b[0];
+    for (int r0 = hw * 4; r0 < rows; r0 += nhw * 4) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int r = r0 + u < rows ? r0 + u : rows - 1;
+            x[u] = *reinterpret_cast<const float4*>(h + (size_t)r * HK + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float s = x[u].x * wv.x;
+            s = fmaf(x[u].y, wv.y, s); s = fmaf(x[u].z, wv.z, s); s = fmaf(x[u].w, wv.w, s);
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0 && r0 + u < rows) values[r0 + u] = s + bias;
+        }
+    }
+}
+
+int head_grid(int tiles) { return tiles < HEAD_MAX_GRID ? tiles : HEAD_MAX_GRID; }
+bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
+
+}  // namespace
+
+extern "C" int bg_critic_head_forward(int32_t rows, const float* h, const float* w, const float* b, float* values, void* stream) {
+    if (rows <= 0 || !h || !w || !b || !values) return bg_set_error(-1, "bg_critic_head_forward: bad argument");
+    if (!aligned16(h) || !aligned16(w)) return bg_set_error(-1, "bg_critic_head_forward: h and w must be 16-byte aligned");
+    int blocks = (rows + 31) / 32;  // 8 half-waves x 4 rows per 256-thread workgroup and pass
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(critic_head_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, h, w, b, values);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_actor_head(int32_t B, int32_t mode, const float* h, const float* W, const float* bias, const float* logstd, const float* actions,
+                             const float* old_mu, const float* old_logstd, const float* old_logp, const float* adv, const double* adv_stats,
+                             float e_clip, float bound_coef, float entropy_coef, float* mu_out, float* g_hidden, float* grad_W, float* grad_b,
+                             float* grad_b_hidden, double* grad_logstd, double* stats, float* scratch, void* stream) {
+    if (B <= 0 || !h || !W || !bias) return bg_set_error(-1, "bg_actor_head: bad argument");
+    if (!aligned16(h)) return bg_set_error(-1, "bg_actor_head: h must be 16-byte aligned");
+    const int tiles = (B + HT - 1) / HT, grid = head_grid(tiles);
+    hipStream_t st = (hipStream_t)stream;
+    if (mode == 0) {
+        if (!mu_out) return bg_set_error(-1, "bg_actor_head: mode 0 needs mu_out");
+        hipLaunchKernelGGL(actor_head_kernel<0>, dim3(grid), dim3(256), 0, st, B, tiles, h, W, bias, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr,
+                           nullptr, 0.f, 0.f, mu_out, nullptr, nullptr);
+        HIP_OK(hipGetLastError());
+        return 0;
+    }
+    if (mode != 1) return bg_set_error(-1, "bg_actor_head: mode must be 0 (forward) or 1 (forward + loss + backward)");
+    if (!logstd || !actions || !old_mu || !old_logstd || !old_logp || !adv || !adv_stats || !g_hidden || !grad_W || !grad_b || !grad_b_hidden ||
+        !grad_logstd || !stats || !scratch)
+        return bg_set_error(-1, "bg_actor_head: bad argument");
+    hipLaunchKernelGGL(actor_head_kernel<1>, dim3(grid), dim3(256), 0, st, B, tiles, h, W, bias, logstd, actions, old_mu, old_logstd, old_logp, adv,
+                       adv_stats, e_clip, bound_coef, mu_out, g_hidden, scratch);
+    constexpr int n_out = HA * HK + HK + HA;
+    hipLaunchKernelGGL(head_finish_kernel, dim3((n_out + 15) / 16 + 1), dim3(256), 0, st, grid, head_record<HA>(), n_out, scratch, grad_W, HA * HK,
+                       grad_b_hidden, grad_b, head_stat_base<HA>(), HEAD_NSTAT, HA, 1u << HA, (double)entropy_coef, grad_logstd, stats);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_critic_head_backward(int32_t B, const float* h, const float* w, const float* values, const float* returns, float* g_hidden,
+                                       float* grad_w, float* grad_b, float* grad_b_hidden, double* stats, float* scratch, void* stream) {
+    if (B <= 0 || !h || !w || !values || !returns || !g_hidden || !grad_w || !grad_b || !grad_b_hidden || !stats || !scratch)
+        return bg_set_error(-1, "bg_critic_head_backward: bad argument");
+    if (!aligned16(h)) return bg_set_error(-1, "bg_critic_head_backward: h must be 16-byte aligned");
+    const int tiles = (B + HT - 1) / HT, grid = head_grid(tiles);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(critic_head_backward_kernel, dim3(grid), dim3(256), 0, st, B, tiles, h, w, values, returns, g_hidden, scratch);
+    constexpr int n_out = HK + HK + 1;
+    hipLaunchKernelGGL(head_finish_kernel, dim3((n_out + 15) / 16 + 1), dim3(256), 0, st, grid, head_record<1>(), n_out, scratch, grad_w, HK, grad_b_hidden,
+                       grad_b, head_stat_base<1>(), 1, 0, 0u, 0.0, (double*)nullptr, stats);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

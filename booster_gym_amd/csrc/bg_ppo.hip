@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/booster_gym_amd.h"
+#include "bg_ppo_math.h"
 #include "bg_rng.h"
 
 extern int bg_set_error(int code, const char* msg);
@@ -68,7 +69,7 @@ __global__ __launch_bounds__(256) void gae_kernel(int T, int N, float* __restric
 }
 
 // ------------------------------------------------------------------ PPO loss forward + backward, one lane per sample
-constexpr float kHalfLog2Pi = 0.9189385332046727f;
+using bg::kHalfLog2Pi;
 
 template <int A>
 __global__ __launch_bounds__(256) void ppo_loss_kernel(int B, const float* __restrict__ mu, const float* __restrict__ logstd,
@@ -81,54 +82,18 @@ __global__ __launch_bounds__(256) void ppo_loss_kernel(int B, const float* __res
                                                        double* __restrict__ stats) {
     __shared__ double sm[(A + 5) * 4];
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
-    // advantage normalisation: (adv - mean) / (std + 1e-8), torch.std is the unbiased estimator (runner.py:145)
-    const double cnt = adv_stats[2], mean_d = adv_stats[0] / cnt;
-    double var_d = (adv_stats[1] - cnt * mean_d * mean_d) / (cnt - 1.0);
-    if (var_d < 0.0) var_d = 0.0;
-    const float mean = (float)mean_d, inv_std = 1.0f / ((float)sqrt(var_d) + 1e-8f);
-    const float invB = 1.0f / (float)B;
-    float sig[A], isig2[A], osig[A];
-    float ent = 0.f;
-    for (int a = 0; a < A; a++) {
-        sig[a] = expf(logstd[a]); isig2[a] = 1.0f / (sig[a] * sig[a]); osig[a] = expf(old_logstd[a]);
-        ent += 0.5f + kHalfLog2Pi + logstd[a];
-    }
+    bg::ActorLossConsts<A> c;
+    bg::actor_loss_consts<A>(c, B, logstd, old_logstd, adv_stats, e_clip, bound_coef);
     double acc[A + 5];
     for (int k = 0; k < A + 5; k++) acc[k] = 0.0;
     if (b < B) {
-        float m[A], d[A];
-        float logp = 0.f, kl = 0.f, bound = 0.f;
-        for (int a = 0; a < A; a++) {
-            m[a] = mu[(size_t)b * A + a];
-            d[a] = actions[(size_t)b * A + a] - m[a];
-            logp += -0.5f * d[a] * d[a] * isig2[a] - logstd[a] - kHalfLog2Pi;
-            const float dm = m[a] - old_mu[(size_t)b * A + a];
-            kl += logstd[a] - old_logstd[a] + 0.5f * (osig[a] * osig[a] + dm * dm) * isig2[a] - 0.5f;
-            const float hi = fmaxf(m[a] - 1.0f, 0.f), lo = fminf(m[a] + 1.0f, 0.f);
-            bound += hi * hi + lo * lo;
-        }
-        const float An = (adv[b] - mean) * inv_std;
-        const float ratio = expf(logp - old_logp[b]);
-        const float rc = fminf(fmaxf(ratio, 1.0f - e_clip), 1.0f + e_clip);
-        const float s1 = -An * ratio, s2 = -An * rc;
-        const float actor = fmaxf(s1, s2);
-        // d max(s1,s2)/d logp: through s1 when it wins or ties, through the clamp only inside the clip range
-        const bool inside = ratio >= 1.0f - e_clip && ratio <= 1.0f + e_clip;
-        const float dlogp = (inside || s1 > s2) ? -An * ratio * invB : 0.f;
-        const float v = values[b], rt = returns[b];
-        const float verr = v - rt;
-        grad_values[b] = 2.0f * verr * invB;
-        const float bscale = bound_coef * 2.0f * invB / (float)A;
-        for (int a = 0; a < A; a++) {
-            const float hi = fmaxf(m[a] - 1.0f, 0.f), lo = fminf(m[a] + 1.0f, 0.f);
-            grad_mu[(size_t)b * A + a] = dlogp * d[a] * isig2[a] + bscale * (hi + lo);
-            acc[a] = (double)(dlogp * (d[a] * d[a] * isig2[a] - 1.0f));
-        }
+        float m[A], act[A], om[A], gmu[A];
+        for (int a = 0; a < A; a++) { m[a] = mu[(size_t)b * A + a]; act[a] = actions[(size_t)b * A + a]; om[a] = old_mu[(size_t)b * A + a]; }
+        bg::actor_loss_row<A>(c, m, act, om, old_logp[b], adv[b], gmu, acc);
+        for (int a = 0; a < A; a++) grad_mu[(size_t)b * A + a] = gmu[a];
+        const float verr = values[b] - returns[b];
+        grad_values[b] = 2.0f * verr * c.invB;
         acc[A + 0] = (double)(verr * verr);
-        acc[A + 1] = (double)actor;
-        acc[A + 2] = (double)bound;
-        acc[A + 3] = (double)ent;
-        acc[A + 4] = (double)kl;
     }
     // reduce: grad_logstd[A] and stats[5]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, waves = (blockDim.x + 63) >> 6;

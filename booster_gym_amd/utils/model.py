@@ -70,7 +70,12 @@ class MLPTrainer:
         self.w0pad = torch.zeros(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if k_in != l0.weight.shape[1] else None
         self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
 
-    def forward(self, x, train_rows=None):
+    def forward_hidden(self, x, train_rows=None):
+        """All layers but the output layer: returns the activations of the last hidden (ELU) layer [rows, width].  The output layer then runs
+        fused with the loss (bg_actor_head / bg_critic_head_*), and `backward_hidden` takes over from the gradient those kernels produce."""
+        return self.forward(x, train_rows, _stop_before_output=True)
+
+    def forward(self, x, train_rows=None, _stop_before_output=False):
         """x [rows, in (possibly zero-padded)].  The first `train_rows` rows (default: all) are the batch the backward pass differentiates."""
         B = x.shape[0] if train_rows is None else train_rows
         if self._B != B or self._rows != x.shape[0] or self._kin != x.shape[1]:
@@ -79,6 +84,8 @@ class MLPTrainer:
         last = len(self.layers) - 1
         lib, stream = _lib.load(), _lib.current_stream_ptr()
         for i, l in enumerate(self.layers):
+            if i == last and _stop_before_output:
+                break
             n_out, k_in = l.weight.shape
             w = l.weight
             if i == 0 and self.w0pad is not None:
@@ -109,12 +116,25 @@ class MLPTrainer:
         g always holds dL/dz of layer i (z = pre-activation).  For the linear output layer that is grad_out itself; going down, the fused
         kernel bg_mlp_layer_backward produces dL/dz of layer i-1 = (g W_i) * elu'(a_{i-1}) together with layer i-1's bias gradient in one
         pass; the skinny output layers (12 / 1 columns) use torch.mm + the fused ELU-backward/column-sum kernel instead."""
-        lib = _lib.load()
-        g, B, S = grad_out, self._B, self._S
-        stream = _lib.current_stream_ptr()
         last = len(self.layers) - 1
-        torch.sum(g, dim=0, out=self.layers[last].bias.grad)  # linear output layer: plain column sum
-        for i in range(last, -1, -1):
+        torch.sum(grad_out, dim=0, out=self.layers[last].bias.grad)  # linear output layer: plain column sum
+        self._backward_from(last, grad_out)
+
+    @property
+    def hidden_grad(self):
+        """[B, width] buffer the fused head kernels write dL/dz of the last hidden layer into (input of `backward_hidden`)."""
+        return self.gin[len(self.layers) - 1]
+
+    def backward_hidden(self, g=None):
+        """Backward from the last hidden layer down.  g = dL/dz of that layer (default: `hidden_grad`); its bias gradient and the output
+        layer's weight / bias gradients have already been written by the fused head kernel."""
+        self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g)
+
+    def _backward_from(self, start, g):
+        lib = _lib.load()
+        B, S = self._B, self._S
+        stream = _lib.current_stream_ptr()
+        for i in range(start, -1, -1):
             l = self.layers[i]
             a_in = (self.acts[i - 1] if i > 0 else self.x)[:B]
             C_out, C_in = l.weight.shape

@@ -34,7 +34,8 @@ from .config import load_cfg
 from .model import ActorCritic, MLPTrainer
 from .parallel import DataParallel
 from .recorder import Recorder
-from .utils import gae, gaussian_logp, ppo_loss_fused
+from .utils import (actor_head_forward, actor_head_loss_backward, critic_head_backward, critic_head_forward, gae, gaussian_logp, head_scratch,
+                    ppo_loss_fused)
 
 
 class FlatAdam:
@@ -165,6 +166,13 @@ class Runner:
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
         self._actor_tr, self._critic_tr = MLPTrainer(self.model.actor), MLPTrainer(self.model.critic)
         self._side_stream = torch.cuda.Stream(device=self.device)
+        # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
+        # library GEMMs + bg_ppo_loss for these layers (A/B comparisons).
+        self._fused_head = (os.environ.get("BG_FUSED_HEAD", "1") == "1" and A == 12
+                            and self.model.actor[-1].in_features == 128 and self.model.critic[-1].in_features == 128)
+        self._old_mu = torch.zeros(B, A, device=dev)
+        self._values_all = torch.zeros(B + N, device=dev)
+        self._head_scratch_a, self._head_scratch_c = head_scratch(dev), head_scratch(dev)
         self._act_counter = 0
         self.timers = {"rollout": 0.0, "update": 0.0}
 
@@ -254,8 +262,15 @@ class Runner:
         else:
             obs_flat = buf["obses"][:T].reshape(B, -1)
         critic_all = self._critic_in.reshape((T + 1) * N, -1)  # rows [B, B+N) = the observation after the last step (last_values)
+        fused_head = self._fused_head
+        logstd_flat = self.model.logstd.reshape(-1)
+        a_out, c_out = self._actor_tr.layers[-1], self._critic_tr.layers[-1]
         with torch.no_grad():
-            old_mu = self._actor_tr.forward(obs_flat).clone()  # same kernels as the mini-epochs: the first ratio is exactly 1
+            # old mu through the same kernels as the mini-epochs: the first ratio is exactly 1
+            if fused_head:
+                old_mu = actor_head_forward(self._actor_tr.forward_hidden(obs_flat), a_out.weight, a_out.bias, self._old_mu)
+            else:
+                old_mu = self._actor_tr.forward(obs_flat).clone()
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
             gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
         self._stats_acc.zero_()
@@ -266,22 +281,51 @@ class Runner:
         with torch.no_grad():
             for _ in range(cfg["runner"]["mini_epochs"]):
                 side.wait_stream(main)  # parameters updated by the previous optimiser step
+                if fused_head:  # both heads accumulate into these; zeroed before either can run
+                    self._stats.zero_()
+                    self._grad_logstd.zero_()
+                    zeroed = main.record_event()
                 with torch.cuda.stream(side):
-                    v_all = self._critic_tr.forward(critic_all, train_rows=B).squeeze(-1)
+                    if fused_head:
+                        hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
+                        v_all = critic_head_forward(hc, c_out.weight, c_out.bias, self._values_all)
+                    else:
+                        v_all = self._critic_tr.forward(critic_all, train_rows=B).squeeze(-1)
                     values, last_values = v_all[:B], v_all[B:]
                     gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
                         advantages=self._adv, returns=self._ret, sums=self._adv_sums)
                     self.dp.sum_(self._adv_sums)  # exchange (1), on the side stream: hidden under the actor forward
-                mu = self._actor_tr.forward(obs_flat)
-                main.wait_stream(side)
-                ppo_loss_fused(mu, self.model.logstd.reshape(-1), act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
-                               values, self._ret.view(B), 0.2, alg["bound_coef"], alg["entropy_coef"], self._grad_mu, self._grad_val,
-                               self._grad_logstd, self._stats)
-                side.wait_stream(main)
-                with torch.cuda.stream(side):
-                    self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
-                    self._critic_tr.backward(self._grad_val.view(B, 1))
-                self._actor_tr.backward(self._grad_mu)
+                    gae_done = side.record_event()
+                if fused_head:
+                    # Output layers fused with the loss (bg_head.hip): per network ONE pass over the [B][128] hidden activations gives the
+                    # output, the loss terms, dL/dz of the hidden layer and the output layer's gradients.  Both heads add into _stats.
+                    ha = self._actor_tr.forward_hidden(obs_flat)
+                    with torch.cuda.stream(side):
+                        side.wait_event(zeroed)
+                        critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,
+                                             c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c)
+                        self._critic_tr.backward_hidden()
+                    main.wait_event(gae_done)  # advantages and their moments
+                    actor_head_loss_backward(ha, a_out.weight, a_out.bias, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp,
+                                             self._adv.view(B), self._adv_sums, 0.2, alg["bound_coef"], alg["entropy_coef"],
+                                             self._actor_tr.hidden_grad, a_out.weight.grad, a_out.bias.grad, self._actor_tr.layers[-2].bias.grad,
+                                             self._grad_logstd, self._stats, self._head_scratch_a)
+                    if self.dp.active:
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
+                    self._actor_tr.backward_hidden()
+                else:
+                    mu = self._actor_tr.forward(obs_flat)
+                    main.wait_stream(side)
+                    ppo_loss_fused(mu, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
+                                   values, self._ret.view(B), 0.2, alg["bound_coef"], alg["entropy_coef"], self._grad_mu, self._grad_val,
+                                   self._grad_logstd, self._stats)
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
+                        self._critic_tr.backward(self._grad_val.view(B, 1))
+                    self._actor_tr.backward(self._grad_mu)
                 self._logstd_grad_view.copy_(self._grad_logstd)
                 main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path

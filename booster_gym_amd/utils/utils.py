@@ -108,6 +108,49 @@ def ppo_loss_fused(mu, logstd, actions, old_mu, old_logstd, old_logp, adv, adv_s
                                        _lib.current_stream_ptr()), "bg_ppo_loss")
 
 
+def head_scratch(device):
+    """Workspace of one fused head call (per-workgroup partial sums); calls that may run concurrently need their own."""
+    return torch.empty(_lib.HEAD_SCRATCH_FLOATS, dtype=torch.float32, device=device)
+
+
+def critic_head_forward(h, weight, bias, values_out):
+    """values = h @ weight.T + bias for the 128 -> 1 output layer (model.py:21), one pass over h [rows, 128]."""
+    _need_cuda(h, weight, bias, values_out)
+    _lib.check(_lib.load().bg_critic_head_forward(h.shape[0], _lib.ptr(h), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(values_out),
+                                                  _lib.current_stream_ptr()), "bg_critic_head_forward")
+    return values_out
+
+
+def actor_head_forward(h, weight, bias, mu_out):
+    """mu = h @ weight.T + bias for the 128 -> 12 output layer (model.py:13) with the arithmetic of the fused loss kernel."""
+    _need_cuda(h, weight, bias, mu_out)
+    z = None
+    _lib.check(_lib.load().bg_actor_head(h.shape[0], 0, _lib.ptr(h), _lib.ptr(weight), _lib.ptr(bias), z, z, z, z, z, z, z, 0.0, 0.0, 0.0,
+                                         _lib.ptr(mu_out), z, z, z, z, z, z, z, _lib.current_stream_ptr()), "bg_actor_head")
+    return mu_out
+
+
+def actor_head_loss_backward(h, weight, bias, logstd, actions, old_mu, old_logstd, old_logp, adv, adv_stats, e_clip, bound_coef, entropy_coef,
+                             g_hidden, grad_weight, grad_bias, grad_bias_hidden, grad_logstd, stats, scratch, mu_out=None):
+    """Output layer + PPO actor loss (runner.py:145-174) + output-layer backward in one pass over h [B, 128].  grad_logstd float64[12] and
+    stats float64[5] (entries 1..4) are ACCUMULATED with atomics: the caller zeroes them (the critic head adds entry 0 concurrently)."""
+    _need_cuda(h, weight, bias, logstd, actions, old_mu, old_logstd, old_logp, adv, adv_stats, g_hidden, grad_weight, grad_bias, grad_bias_hidden,
+               grad_logstd, stats, scratch)
+    _lib.check(_lib.load().bg_actor_head(h.shape[0], 1, _lib.ptr(h), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(logstd), _lib.ptr(actions),
+                                         _lib.ptr(old_mu), _lib.ptr(old_logstd), _lib.ptr(old_logp), _lib.ptr(adv), _lib.ptr(adv_stats), e_clip,
+                                         bound_coef, entropy_coef, _lib.ptr(mu_out), _lib.ptr(g_hidden), _lib.ptr(grad_weight), _lib.ptr(grad_bias),
+                                         _lib.ptr(grad_bias_hidden), _lib.ptr(grad_logstd), _lib.ptr(stats), _lib.ptr(scratch),
+                                         _lib.current_stream_ptr()), "bg_actor_head")
+
+
+def critic_head_backward(h, weight, values, returns, g_hidden, grad_weight, grad_bias, grad_bias_hidden, stats, scratch):
+    """Backward of mean((values - returns)^2) (runner.py:148) through the 128 -> 1 output layer; stats[0] += sum of squared errors."""
+    _need_cuda(h, weight, values, returns, g_hidden, grad_weight, grad_bias, grad_bias_hidden, stats, scratch)
+    _lib.check(_lib.load().bg_critic_head_backward(h.shape[0], _lib.ptr(h), _lib.ptr(weight), _lib.ptr(values), _lib.ptr(returns), _lib.ptr(g_hidden),
+                                                   _lib.ptr(grad_weight), _lib.ptr(grad_bias), _lib.ptr(grad_bias_hidden), _lib.ptr(stats),
+                                                   _lib.ptr(scratch), _lib.current_stream_ptr()), "bg_critic_head_backward")
+
+
 def surrogate_loss(old_actions_log_prob, actions_log_prob, advantages, e_clip=0.2):
     """Reference utils/utils.py:47-52, kept for API parity (plain torch ops on the caller's device; the
     training loop uses ppo_loss_fused instead)."""

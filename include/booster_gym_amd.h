@@ -224,6 +224,27 @@ int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const 
 int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const float* G, const float* Wt, const float* act_below, float* Gout,
                           float* bias_grad_below, float* scratch, void* stream);
 
+/* ---- output ("head") layers fused with the loss: the 128 -> 12 / 128 -> 1 Linear layers of utils/model.py:13,21 together with
+ * runner.py:145-174.  h [rows][128] = activations of the last hidden (ELU) layer, 16-byte aligned.  One launch reads h once instead of
+ * the seven library GEMM / elementwise passes these skinny layers otherwise take per network and mini-epoch.
+ * scratch: BG_HEAD_SCRATCH_FLOATS floats of device memory per concurrent call (per-workgroup partial sums, added in a fixed order). */
+#define BG_HEAD_SCRATCH_FLOATS (768 * 1720)
+/* critic.6 forward: values [rows] = h w + b   (w [128], b [1]) */
+int bg_critic_head_forward(int32_t rows, const float* h, const float* w, const float* b, float* values, void* stream);
+/* actor.6 forward (mode 0: mu_out [B][12] = h W^T + b, nothing else is touched) or forward + PPO actor loss + backward (mode 1), with the
+ * argument meaning of bg_ppo_loss: out g_hidden [B][128] = dL/dz of the last hidden layer, grad_W [12][128], grad_b [12],
+ * grad_b_hidden [128] (bias gradient of the last hidden layer = column sums of g_hidden), grad_logstd [12] float64 and
+ * stats[1..4] float64 (surrogate, bound penalty, entropy, kl sums; atomic, caller zeroes; stats[0] is left to the critic head).
+ * mu_out may be NULL in mode 1. */
+int bg_actor_head(int32_t B, int32_t mode, const float* h, const float* W, const float* bias, const float* logstd, const float* actions,
+                  const float* old_mu, const float* old_logstd, const float* old_logp, const float* adv, const double* adv_stats, float e_clip,
+                  float bound_coef, float entropy_coef, float* mu_out, float* g_hidden, float* grad_W, float* grad_b, float* grad_b_hidden,
+                  double* grad_logstd, double* stats, float* scratch, void* stream);
+/* critic.6 backward of the value loss mean((v - ret)^2) (runner.py:148): g_hidden [B][128], grad_w [128], grad_b [1], grad_b_hidden [128],
+ * stats[0] += sum of squared value errors (float64, atomic) */
+int bg_critic_head_backward(int32_t B, const float* h, const float* w, const float* values, const float* returns, float* g_hidden, float* grad_w,
+                            float* grad_b, float* grad_b_hidden, double* stats, float* scratch, void* stream);
+
 const char* bg_last_error(void);
 const char* bg_version(void);
 
