@@ -46,6 +46,46 @@ def gemm_flops_per_iteration(n_envs, horizon, mini_epochs):
     return train + nograd
 
 
+ABA_BYTES = 4 * (13 + 12 + 12 + 12 + 6 + 18 + 6 + 58)  # forward_dynamics_kernel, per env and substep
+
+
+from booster_gym_amd import _lib  # noqa: E402  (raw ABI calls for the kernel-level timings)
+
+
+def aba_roofline(n=1 << 20, launches=30):
+    """HBM roofline of the ABA kernel on a FULL chip: forward_dynamics_kernel (one substep's accelerations per launch) on n synthetic states
+    (joints around the default pose, unit-normal joint velocities, torques within the effort limits), HIP events on the
+    launch stream.  At the training size (4096 envs = 128 waves on 1024 SIMDs) no kernel can approach a bandwidth roof."""
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+
+    env = T1(load_cfg("T1", {"env.num_envs": n, "terrain.type": "plane"}))
+    dev = env.device
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    root = torch.zeros(n, 13); root[:, 2] = 0.66; root[:, 6] = 1.0; root[:, 7:13] = torch.randn(n, 6, generator=g) * 0.3
+    q = torch.tensor([-0.2, 0, 0, 0.4, -0.25, 0] * 2).repeat(n, 1) + torch.randn(n, 12, generator=g) * 0.1
+    qd = torch.randn(n, 12, generator=g)
+    tau = (torch.rand(n, 12, generator=g) * 2 - 1) * 20
+    root, q, qd, tau = (t.to(dev).contiguous() for t in (root, q, qd, tau))
+    qacc = torch.empty(n, 18, device=dev)
+    lib = _lib.load()
+    call = lambda: _lib.check(lib.bg_env_forward_dynamics(env._env, _lib.ptr(root), _lib.ptr(q), _lib.ptr(qd), _lib.ptr(tau), None, _lib.ptr(qacc),
+                                                          _lib.current_stream_ptr()), "bg_env_forward_dynamics")
+    for _ in range(3):
+        call()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(launches):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    us = e0.elapsed_time(e1) / launches * 1e3
+    gbs = n * ABA_BYTES / us / 1e3
+    return {"kernel": "forward_dynamics_kernel (hand-written HIP: one ABA substep with contact and limits, per-step joint accelerations)",
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
+            "avg_launch_us": us, "num_envs": n, "algorithmic_bytes_per_launch": n * ABA_BYTES,
+            "note": "VALU-issue bound: 88% of the issue slots at 1M envs (profiles/r01_d_aba_pmc.json); curve over N in profiles/r01_d_aba_roofline_curve.json"}
+
+
 def cpu_baseline(n_sample=2048):
     """CPU restatement baseline ("port"), timed in a child process that never touches the GPU (oracle/cpu_baseline.py)."""
     import subprocess
@@ -64,6 +104,8 @@ def main():
     ap.add_argument("--num_envs", type=int, default=4096)
     ap.add_argument("--terrain", type=str, default="plane")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the measurements after the timed region (kernel alone on the GPU, ABA roofline): "
+                    "used under rocprofv3 so that the per-kernel averages of the summary are those of the timed region")
     args = ap.parse_args()
 
     t_start = time.perf_counter()
@@ -141,7 +183,24 @@ def main():
         if ev:
             gemm_us = sum(a.elapsed_time(b) for a, b, *_ in ev) / len(ev) * 1e3
             rows_g, kg, ng = ev[0][2], ev[0][3], ev[0][4]
-            gemm_name = f"mlp_fwd_kernel<256,1>: fused Linear+bias+ELU, critic layer 2, [{rows_g}x{kg}]x[{kg}x{ng}] fp32 MFMA 32x32x2 (hand-written HIP, bg_mlp.hip)"
+            gemm_name = f"mlp_fwd_kernel<256,1,2>: fused Linear+bias+ELU, critic layer 2, [{rows_g}x{kg}]x[{kg}x{ng}] fp32 MFMA 32x32x2 (hand-written HIP, bg_mlp.hip)"
+            # the same launch with nothing else on the GPU (in the loop the actor's kernels run beside it on the second stream)
+            tr = runner._critic_tr
+            xg, lg, og = tr.acts[0], tr.layers[1], tr.acts[1]
+            lib = _lib.load()
+            solo = lambda: _lib.check(lib.bg_mlp_layer_forward(rows_g, kg, ng, _lib.ptr(xg), _lib.ptr(lg.weight), _lib.ptr(lg.bias), _lib.ptr(og), 1,
+                                                               _lib.current_stream_ptr()), "bg_mlp_layer_forward")
+            torch.cuda.synchronize()
+            solo_us = float("nan")
+            if not args.no_extra:
+                for _ in range(3):
+                    solo()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                for _ in range(30):
+                    solo()
+                g1.record(); torch.cuda.synchronize()
+                solo_us = g0.elapsed_time(g1) / 30 * 1e3
         else:  # BG_FUSED_MLP=0: the library GEMM of the same layer
             tr = runner._critic_tr
             xg, lg, og = tr.acts[0], tr.layers[1], torch.empty_like(tr.acts[1])
@@ -156,10 +215,11 @@ def main():
             gemm_us = g0.elapsed_time(g1) / 50 * 1e3
             rows_g, kg, ng = xg.shape[0], lg.weight.shape[1], lg.weight.shape[0]
             gemm_name = f"critic layer-2 forward GEMM [{rows_g}x{kg}]x[{kg}x{ng}] fp32 (hipBLASLt via torch.addmm)"
+            solo_us = gemm_us
         gemm_flop = 2.0 * rows_g * kg * ng
         gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_c_env_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_d_env_pmc.json")
         if N == 4096 and os.path.isfile(pmc):  # PMC counters are collected offline by tools/profile.sh (separate rocprofv3 passes)
             k = json.load(open(pmc))["kernels"]["env_step_kernel"]
             traffic = (k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
@@ -173,7 +233,9 @@ def main():
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms},
             "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF, "traffic": None,
-                         "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop},
+                         "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop,
+                         "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,
+                                              "frac": gemm_flop / (solo_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}},
             "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",
                                   "achieved": sim_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS, "traffic": traffic,
                                   "avg_launch_us": step_ms * 1e3, "algorithmic_bytes_per_launch": env_bytes,
@@ -183,6 +245,14 @@ def main():
                                 "note": "all actor+critic GEMM flops of the update phase / update-phase wall time (which also holds GAE, loss, ELU, Adam)"},
             "nonfinite_resets": stats[-1],
         }
+        if args.no_extra:
+            out["roofline"].pop("alone_on_the_gpu", None)
+        if world == 1 and not args.no_extra:
+            try:
+                del runner.env
+                out["roofline_aba"] = aba_roofline()
+            except Exception as ex:
+                out["roofline_aba"] = {"error": repr(ex)}
         if not args.no_cpu_baseline and world == 1:
             try:
                 log("cpu baseline ...")

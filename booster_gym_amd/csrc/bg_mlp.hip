@@ -70,7 +70,9 @@ __device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, 
 // EPI 2: Y = (X W^T) * elu'(aux), aux = the layer's OUTPUT activations (1 if aux > 0 else aux + 1), plus per-workgroup column sums of Y
 //        written to colpart[blockIdx.x][ldy]  (backward: X = dL/dz of the layer above, W = its transposed weight, Y = dL/dz of this layer,
 //        column sums = this layer's bias gradient)
-template <int K, int EPI>
+// NB = number of 128-column blocks of the layer (1, 2; 0 = any): it only gives every layer shape its own kernel symbol, so that a profiler's
+// per-kernel average is the average of ONE shape (bench.py's roofline line is checked against the rocprofv3 summary in profiles/).
+template <int K, int EPI, int NB>
 __global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(int M, int ldy, const float* __restrict__ X, const float* __restrict__ Wfull,
                                                          const float* __restrict__ biasfull, float* __restrict__ Yfull,
                                                          const float* __restrict__ auxfull, float* __restrict__ colpart) {
@@ -184,8 +186,10 @@ extern "C" int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float
     hipStream_t st = (hipStream_t)stream;
 #define BG_FWD(KK)                                                                                                      \
     if (K == KK) {                                                                                                      \
-        if (elu) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 1>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr); \
-        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, 0>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr);    \
+        if (elu && N == 128) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 1, 1>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr);      \
+        else if (elu && N == 256) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 1, 2>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr); \
+        else if (elu) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 1, 0>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr);             \
+        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, 0, 0>), grid, block, 0, st, M, N, X, W, bias, Y, nullptr, nullptr);                      \
         HIP_OK(hipGetLastError());                                                                                      \
         return 0;                                                                                                       \
     }
@@ -207,7 +211,9 @@ extern "C" int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const floa
     hipStream_t st = (hipStream_t)stream;
 #define BG_BWD(KK)                                                                                                                \
     if (K == KK) {                                                                                                                \
-        hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch);           \
+        if (N == 128) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2, 1>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch);      \
+        else if (N == 256) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2, 2>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch); \
+        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2, 0>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch);               \
         hipLaunchKernelGGL(mlp_colsum_finish_kernel, dim3(N), dim3(256), 0, st, nb, N, scratch, bias_grad_below);                  \
         HIP_OK(hipGetLastError());                                                                                                \
         return 0;                                                                                                                 \
