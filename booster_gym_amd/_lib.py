@@ -62,6 +62,7 @@ class EnvCfg(C.Structure):
         ("soft_dof_vel_limit", C.c_float), ("soft_torque_limit", C.c_float), ("swing_period", C.c_float), ("feet_distance_ref", C.c_float),
         ("max_episode_length", C.c_int32), ("terminate_height", C.c_float), ("terminate_vel", C.c_float),
         ("terrain_type", C.c_int32), ("terrain_env_width", C.c_float), ("terrain_env_length", C.c_float), ("terrain_border", C.c_float),
+        ("state_fp16", C.c_int32),
     ]
 
 

@@ -54,8 +54,23 @@ enum { I_EP_LEN = 0, I_CMD_TIME = 1, I_DELAY = 2, I_EP_STEPS = 3, I_CURR_LIN = 4
 // global statistics accumulator: [0] finished episodes, [1] sum of their lengths, [2] sum reward, [3..28] sum of terms, [29] non-finite resets
 constexpr int STATS_COUNT = 4 + BG_NUM_REWARD_TERMS;  // last entry: resets caused by a non-finite state
 
+// Optional fp16 STORAGE of the per-env dynamic state (BASELINE.json configs[4]: "16384 envs/GPU, fp16 state"; cfg.state_fp16).  Arithmetic
+// stays fp32: values are widened on load at the start of the env step and rounded on store at its end, nothing is rounded between substeps.
+// Stored as fp16: orientation, linear / angular velocity, joint positions and velocities, targets, actions and their histories, commands,
+// gait state, velocity filters, push wrench (105 of the 120 state floats).  Kept fp32: the root POSITION (robots walk tens of metres from
+// their origin and fp16 resolves 16 mm at 30 m), last_feet_pos (world positions, same reason), contact forces, all per-env parameters and
+// the derived / statistics fields.
+typedef uint16_t bg_half_bits;
+constexpr int FP16_SLAB_FIELDS = 120;  // [0, F_CONTACT + 6)
+BG_HD constexpr bool fp16_state_field(int idx) { return (idx >= 3 && idx < 102) || (idx >= 108 && idx < 114); }
+#if defined(__HIPCC__)
+BG_HD float half_bits_to_float(bg_half_bits b) { _Float16 h; __builtin_memcpy(&h, &b, 2); return (float)h; }
+BG_HD bg_half_bits float_to_half_bits(float v) { _Float16 h = (_Float16)v; bg_half_bits b; __builtin_memcpy(&b, &h, 2); return b; }  // round to nearest even
+#endif
+
 struct EnvDev {
     float* f;
+    bg_half_bits* h;  // fp16 slab [FP16_SLAB_FIELDS][n], or null
     int32_t* i;
     float* stats;  // [STATS_COUNT], atomics
     float* curr;   // curriculum_prob running sums [(2L+1)*(2A+1)], atomics
@@ -128,15 +143,36 @@ struct GlobalSink {
 };
 
 // mode: 0 = step, 1 = reset-all (T1.reset(), t1.py:294-299: no physics, every env reset + resampled + observed)
-template <class X, class Sink>
+// one per-env field: fp32 slab, or the fp16 slab when the env stores its state in fp16 and the field is part of it
+template <bool H16>
+struct FieldRef {
+    float* pf;
+    bg_half_bits* ph;
+    BG_HD operator float() const {
+        if constexpr (H16) { if (ph) return half_bits_to_float(*ph); }
+        return *pf;
+    }
+    BG_HD void operator=(float v) const {
+        if constexpr (H16) { if (ph) { *ph = float_to_half_bits(v); return; } }
+        *pf = v;
+    }
+};
+template <bool H16>
+BG_HD FieldRef<H16> field_ref(float* F, bg_half_bits* H, int idx, int n, int e) {
+    const size_t o = (size_t)idx * n + e;
+    return FieldRef<H16>{F + o, (H16 && fp16_state_field(idx)) ? H + o : nullptr};
+}
+
+template <class X, class Sink, bool H16>
 BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool valid, const float* act, uint32_t step, int mode,
                          const StepOut& out) {
     const bg_env_cfg& C = E.cfg;
     const int n = E.n;
     const ModelDev& M = *E.model;
     float* const F = E.f;
+    bg_half_bits* const HS = E.h;
     int32_t* const II = E.i;
-#define FLD(off, comp) F[(size_t)((off) + (comp)) * n + e]
+#define FLD(off, comp) field_ref<H16>(F, HS, (off) + (comp), n, e)
     const int j0 = leg * LEG_LINKS;
     const float dt_env = C.sim_dt * (float)C.decimation;
     Phys ph = make_phys(C);

@@ -32,6 +32,7 @@ struct bg_env {
     bg_model_desc model;
     int n;
     float* f = nullptr;
+    bg_half_bits* h = nullptr;  // fp16 slab of the dynamic state (cfg.state_fp16), else null
     int32_t* i = nullptr;
     float* stats = nullptr;
     float* curr = nullptr;
@@ -68,6 +69,7 @@ struct LdsSink {
 
 constexpr int ENVS_PER_BLOCK = 32;
 
+template <bool H16>
 __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __restrict__ act, uint32_t step, int mode, StepOut out) {
     __shared__ float s_obs[ENVS_PER_BLOCK * BG_NUM_OBS];
     __shared__ float s_priv[ENVS_PER_BLOCK * BG_NUM_PRIV];
@@ -78,7 +80,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __r
     if (!valid) e = E.n - 1;
     DppSwap x;
     LdsSink sink{s_obs, s_priv, lane >> 1};
-    env_step_lane(E, x, sink, e, lane & 1, valid, act, step, mode, out);
+    env_step_lane<DppSwap, LdsSink, H16>(E, x, sink, e, lane & 1, valid, act, step, mode, out);
     __syncthreads();
     // coalesced copy-out of the block's 32 observation rows (contiguous in the [N][47] / [N][14] outputs)
     const int rows = min(ENVS_PER_BLOCK, E.n - e0);
@@ -236,26 +238,38 @@ __global__ __launch_bounds__(64) void sim_body_state_kernel(EnvDev E, const floa
 }
 
 // ------------------------------------------------------------------ layout conversion helpers
-__global__ void soa_to_aos_kernel(const float* __restrict__ soa, float* __restrict__ aos, int n, int comps) {
-    int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * comps) return;
-    int e = idx / comps, c = idx % comps;
-    aos[idx] = soa[(size_t)c * n + e];
+// per-env float field `field` (+ component c) of env e, wherever it is stored (fp32 slab, or the fp16 slab of a state_fp16 env)
+__device__ __forceinline__ float ld_field(const EnvDev& E, int field, int e) {
+    const size_t o = (size_t)field * E.n + e;
+    return (E.h && field < FP16_SLAB_FIELDS && fp16_state_field(field)) ? half_bits_to_float(E.h[o]) : E.f[o];
 }
-__global__ void aos_to_soa_kernel(const float* __restrict__ aos, float* __restrict__ soa, int n, int comps) {
+__device__ __forceinline__ void st_field(const EnvDev& E, int field, int e, float v) {
+    const size_t o = (size_t)field * E.n + e;
+    if (E.h && field < FP16_SLAB_FIELDS && fp16_state_field(field)) E.h[o] = float_to_half_bits(v);
+    else E.f[o] = v;
+}
+__global__ void soa_to_aos_kernel(EnvDev E, int field, int is_int, float* __restrict__ aos, int comps) {
     int idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n * comps) return;
+    if (idx >= E.n * comps) return;
     int e = idx / comps, c = idx % comps;
-    soa[(size_t)c * n + e] = aos[idx];
+    if (is_int) reinterpret_cast<int32_t*>(aos)[idx] = E.i[(size_t)(field + c) * E.n + e];
+    else aos[idx] = ld_field(E, field + c, e);
+}
+__global__ void aos_to_soa_kernel(EnvDev E, int field, int is_int, const float* __restrict__ aos, int comps) {
+    int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= E.n * comps) return;
+    int e = idx / comps, c = idx % comps;
+    if (is_int) E.i[(size_t)(field + c) * E.n + e] = reinterpret_cast<const int32_t*>(aos)[idx];
+    else st_field(E, field + c, e, aos[idx]);
 }
 __global__ void get_state_kernel(EnvDev E, float* root, float* dof, float* contact) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E.n) return;
     const int n = E.n;
-    if (root) for (int c = 0; c < 13; c++) root[(size_t)e * 13 + c] = E.f[(size_t)(F_ROOT + c) * n + e];
+    if (root) for (int c = 0; c < 13; c++) root[(size_t)e * 13 + c] = ld_field(E, F_ROOT + c, e);
     if (dof) for (int j = 0; j < 12; j++) {
-        dof[((size_t)e * 12 + j) * 2] = E.f[(size_t)(F_Q + j) * n + e];
-        dof[((size_t)e * 12 + j) * 2 + 1] = E.f[(size_t)(F_QD + j) * n + e];
+        dof[((size_t)e * 12 + j) * 2] = ld_field(E, F_Q + j, e);
+        dof[((size_t)e * 12 + j) * 2 + 1] = ld_field(E, F_QD + j, e);
     }
     if (contact) {
         for (int c = 0; c < 39; c++) contact[(size_t)e * 39 + c] = 0.f;
@@ -268,11 +282,10 @@ __global__ void get_state_kernel(EnvDev E, float* root, float* dof, float* conta
 __global__ void set_state_kernel(EnvDev E, const float* root, const float* dof) {
     int e = blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= E.n) return;
-    const int n = E.n;
-    if (root) for (int c = 0; c < 13; c++) E.f[(size_t)(F_ROOT + c) * n + e] = root[(size_t)e * 13 + c];
+    if (root) for (int c = 0; c < 13; c++) st_field(E, F_ROOT + c, e, root[(size_t)e * 13 + c]);
     if (dof) for (int j = 0; j < 12; j++) {
-        E.f[(size_t)(F_Q + j) * n + e] = dof[((size_t)e * 12 + j) * 2];
-        E.f[(size_t)(F_QD + j) * n + e] = dof[((size_t)e * 12 + j) * 2 + 1];
+        st_field(E, F_Q + j, e, dof[((size_t)e * 12 + j) * 2]);
+        st_field(E, F_QD + j, e, dof[((size_t)e * 12 + j) * 2 + 1]);
     }
 }
 
@@ -308,7 +321,7 @@ extern "C" void bg_model_destroy(bg_model* m) { delete m; }
 // ------------------------------------------------------------------ ABI: env
 static EnvDev env_dev(const bg_env* e) {
     EnvDev E;
-    E.f = e->f; E.i = e->i; E.stats = e->stats; E.curr = e->curr; E.curr_read = e->curr_read; E.model = e->model_dev; E.terrain = e->terrain; E.cfg = e->cfg; E.n = e->n;
+    E.f = e->f; E.h = e->h; E.i = e->i; E.stats = e->stats; E.curr = e->curr; E.curr_read = e->curr_read; E.model = e->model_dev; E.terrain = e->terrain; E.cfg = e->cfg; E.n = e->n;
     return E;
 }
 
@@ -365,6 +378,12 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
         for (int f = 0; f < 2; f++) { host[(size_t)(F_FOOT_MAT + 3 * f) * n + k] = 1.f; host[(size_t)(F_FOOT_MAT + 3 * f + 1) * n + k] = 1.f; }
     }
     HIP_OK(hipMemcpy(e->f, host.data(), sizeof(float) * n * F_COUNT, hipMemcpyHostToDevice));
+    if (cfg->state_fp16) {  // fp16 slab of the dynamic state: zeros, identity orientation
+        HIP_OK(hipMalloc(&e->h, sizeof(bg_half_bits) * n * FP16_SLAB_FIELDS));
+        std::vector<bg_half_bits> hh(n * FP16_SLAB_FIELDS, 0);
+        for (size_t k = 0; k < n; k++) hh[(size_t)(F_ROOT + 6) * n + k] = 0x3C00;  // 1.0
+        HIP_OK(hipMemcpy(e->h, hh.data(), sizeof(bg_half_bits) * hh.size(), hipMemcpyHostToDevice));
+    }
     *out = e;
     return 0;
 }
@@ -372,7 +391,7 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
 extern "C" void bg_env_destroy(bg_env* e) {
     if (!e) return;
     (void)hipFree(e->sim_tau); (void)hipFree(e->sim_bforce); (void)hipFree(e->sim_btorque);
-    (void)hipFree(e->f); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
+    (void)hipFree(e->f); (void)hipFree(e->h); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
     delete e;
 }
 
@@ -421,7 +440,8 @@ extern "C" int bg_env_bind_outputs(bg_env* e, float* obs, float* priv, float* re
 static int launch_step(bg_env* e, const float* actions, int mode, const StepOut& out, void* stream) {
     if (!out.obs || !out.priv || !out.rew || !out.done || !out.tout) return fail(-1, "bg_env_step: outputs are not bound");
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
-    hipLaunchKernelGGL(env_step_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), actions, (uint32_t)e->step_count, mode, out);
+    if (e->h) hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), actions, (uint32_t)e->step_count, mode, out);
+    else hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), actions, (uint32_t)e->step_count, mode, out);
     HIP_OK(hipGetLastError());
     if (e->cfg.curriculum && mode == 0)  // publish this step's curriculum increments to the next step's samplers
         HIP_OK(hipMemcpyAsync(e->curr_read, e->curr, sizeof(float) * e->curr_cells, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -494,9 +514,8 @@ extern "C" int bg_env_get_field(bg_env* e, const char* name, void* dst, void* st
     }
     const FieldInfo* f = name ? find_field(name) : nullptr;
     if (!f) return fail(-1, std::string("unknown field: ") + (name ? name : "(null)"));
-    const float* src = f->is_int ? (const float*)(e->i + (size_t)f->off * e->n) : e->f + (size_t)f->off * e->n;
     int total = e->n * f->comps;
-    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, src, (float*)dst, e->n, f->comps);
+    hipLaunchKernelGGL(soa_to_aos_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_dev(e), f->off, f->is_int, (float*)dst, f->comps);
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -508,9 +527,8 @@ extern "C" int bg_env_set_field(bg_env* e, const char* name, const void* src, vo
     }
     const FieldInfo* f = name ? find_field(name) : nullptr;
     if (!f) return fail(-1, std::string("unknown field: ") + (name ? name : "(null)"));
-    float* dst = f->is_int ? (float*)(e->i + (size_t)f->off * e->n) : e->f + (size_t)f->off * e->n;
     int total = e->n * f->comps;
-    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)src, dst, e->n, f->comps);
+    hipLaunchKernelGGL(aos_to_soa_kernel, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, env_dev(e), f->off, f->is_int, (const float*)src, f->comps);
     HIP_OK(hipGetLastError());
     return 0;
 }

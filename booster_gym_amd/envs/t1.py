@@ -250,6 +250,10 @@ class T1(BaseTask):
         else:
             c.terrain_type = 1
             c.terrain_env_width, c.terrain_env_length, c.terrain_border = self.terrain.env_width, self.terrain.env_length, self.terrain.border_size
+        sd = str(cfg["sim"].get("state_dtype", "fp32")).lower()
+        if sd not in ("fp32", "float32", "fp16", "float16", "half"):
+            raise ValueError(f"sim.state_dtype must be fp32 or fp16, got {sd!r}")
+        c.state_fp16 = int(sd in ("fp16", "float16", "half"))
         return c
 
     def _model_struct(self):

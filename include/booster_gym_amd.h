@@ -98,6 +98,10 @@ typedef struct {
     /* terrain extents for the teleport wrap (t1.py:343-360); plane => teleport off */
     int32_t terrain_type; /* 0 plane, 1 heightfield ("trimesh" in the yaml) */
     float terrain_env_width, terrain_env_length, terrain_border;
+    /* 1 = keep the per-env dynamic state in fp16 between env steps (BASELINE.json configs[4]; T1.yaml sim.state_dtype: fp16): orientation,
+     * velocities, joint state, targets / actions and their histories, commands, gait, filters, push wrench.  Arithmetic stays fp32; root position,
+     * last feet positions, parameters and outputs stay fp32.  bg_env_get/set_state / get/set_field convert transparently. */
+    int32_t state_fp16;
 } bg_env_cfg;
 
 /* ---- model (replaces gym.load_asset and the asset queries, t1.py:54-108) */

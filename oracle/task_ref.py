@@ -327,6 +327,14 @@ class T1Ref:
         self.curr_prob_read = self.curr_prob.copy()  # samplers see the grid as of the start of the step (bg_env.h)
         self.curr_levels = np.zeros((n, 2), dtype=np.int64)
 
+    def quantize_state_fp16(self):
+        """The product's optional fp16 state storage (bg_env_cfg.state_fp16, BASELINE configs[4]): everything the env keeps between steps except
+        the root position, last_feet_pos and the per-env parameters is rounded to fp16 (nearest even) when it is stored at the end of a step."""
+        h = lambda a: np.asarray(a, dtype=np.float64).astype(np.float16).astype(np.float64)
+        self.root[:, 3:] = h(self.root[:, 3:])
+        for k in ("q", "qd", "last_tgt", "actions", "last_actions", "last_qd", "last_rootvel", "cmd", "gait_f", "gait_p", "filt_lin", "filt_ang", "push"):
+            setattr(self, k, h(getattr(self, k)))
+
     # -- helpers
     def _feet(self):
         pos, quat = np.zeros((self.n, 2, 3)), np.zeros((self.n, 2, 4))

@@ -120,6 +120,46 @@ def test_step_matches_oracle(terrain, start_count):
     assert st[0] >= 6  # the forced time-outs were counted as finished episodes
 
 
+FP16_FIELDS = ["dof_pos", "dof_vel", "last_dof_targets", "actions", "last_actions", "last_dof_vel", "last_root_vel", "commands", "gait_frequency",
+               "gait_process", "filtered_lin_vel", "filtered_ang_vel", "pushing"]
+
+
+def test_fp16_state_step_matches_oracle():
+    """sim.state_dtype: fp16 (BASELINE configs[4]): the state the env keeps between steps is fp16-representable (root position and feet
+    positions stay fp32), one env step from identical (fp16) inputs matches the float64 oracle whose stored state is rounded the same way,
+    observations (computed before the state is rounded for storage) keep the fp32 tolerance."""
+    n = 96
+    cfg, env, ref = _make("trimesh", n, {"sim.state_dtype": "fp16"})
+    env.reset()
+    rng = np.random.default_rng(5)
+    for _ in range(15):
+        env.step(torch.tensor(rng.uniform(-0.3, 0.3, (n, 12)), dtype=torch.float32, device=env.device))
+    env.common_step_counter = 246  # push drawn inside the window
+    is_h = lambda a: np.array_equal(a, a.astype(np.float16).astype(np.float32))
+    for s in range(6):
+        _sync_oracle(env, ref)
+        for k in FP16_FIELDS:
+            assert is_h(env.get_field(k).cpu().numpy()), k
+        root = env.root_states.cpu().numpy()
+        assert is_h(root[:, 3:]) and not is_h(root[:, :3])
+        assert not is_h(env.get_field("last_feet_pos").cpu().numpy()) and not is_h(env.get_field("dof_stiffness").cpu().numpy())
+        act = rng.uniform(-0.6, 0.6, (n, 12)).astype(np.float32)
+        obs, rew, done, extras = env.step(torch.tensor(act, device=env.device))
+        o_ref, p_ref, r_ref, d_ref, t_ref, terms_ref, derived = ref.step(act.astype(np.float64))
+        ref.quantize_state_fp16()
+        keep = done.cpu().numpy() == d_ref
+        assert keep.mean() > 0.95
+        # stored state: dynamics tolerance + one fp16 ulp (2^-10 relative) where the two sides round a near-tie differently
+        _close(env.root_states.cpu().numpy()[keep], ref.root[keep], 3e-3, frac=0.97, what=f"step {s} root")
+        _close(env.dof_pos.cpu().numpy()[keep], ref.q[keep], 3e-3, frac=0.97, what=f"step {s} dof_pos")
+        _close(env.dof_vel.cpu().numpy()[keep], ref.qd[keep], 1e-2, frac=0.95, what=f"step {s} dof_vel")
+        _close(env.get_field("last_dof_targets").cpu().numpy()[keep], ref.last_tgt[keep], 2e-3, frac=1.0, what=f"step {s} targets")
+        _close(env.get_field("pushing").cpu().numpy(), ref.push, 2e-3, frac=1.0, what=f"step {s} push")
+        _close(obs.cpu().numpy()[keep], o_ref[keep], 5e-3, frac=0.95, what=f"step {s} obs")
+        _close(rew.cpu().numpy()[keep], r_ref[keep], 5e-3, frac=0.93, what=f"step {s} reward")
+    assert env.episode_stats(reset=False).cpu().numpy()[-1] == 0
+
+
 def test_command_curriculum_matches_oracle():
     """commands.curriculum = true (t1.py:391-435): grid update on successful episodes, multinomial resampling, level bookkeeping."""
     n = 96

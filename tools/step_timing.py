@@ -6,8 +6,9 @@ from booster_gym_amd.utils.config import load_cfg
 from booster_gym_amd.envs import T1
 
 def main():
-    for n, terrain in [(4096, "plane"), (4096, "trimesh"), (16384, "plane"), (65536, "plane"), (262144, "plane")]:
-        env = T1(load_cfg("T1", {"env.num_envs": n, "terrain.type": terrain}))
+    dtype = sys.argv[1] if len(sys.argv) > 1 else "fp32"
+    for n, terrain in [(4096, "plane"), (4096, "trimesh"), (16384, "plane"), (16384, "trimesh"), (65536, "plane"), (262144, "plane")]:
+        env = T1(load_cfg("T1", {"env.num_envs": n, "terrain.type": terrain, "sim.state_dtype": dtype}))
         env.reset()
         act = torch.zeros(n, 12, device=env.device)
         for _ in range(20): env.step(act)   # settle onto the ground

@@ -6,7 +6,15 @@ from booster_gym_amd.utils.config import load_cfg
 from booster_gym_amd.utils.runner import Runner
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 terrain = sys.argv[2] if len(sys.argv) > 2 else "trimesh"
-cfg = load_cfg("T1", {"terrain.type": terrain, "basic.max_iterations": iters})
+over = {"terrain.type": terrain, "basic.max_iterations": iters}
+for kv in sys.argv[3:]:  # extra overrides, e.g. env.num_envs=16384 sim.state_dtype=fp16
+    k, v = kv.split("=", 1)
+    try:
+        v = json.loads(v)
+    except ValueError:
+        pass
+    over[k] = v
+cfg = load_cfg("T1", over)
 r = Runner(cfg=cfg)
 obs, infos = r.env.reset()
 r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
