@@ -20,6 +20,9 @@ REWARD_NAMES = [
 ]
 
 
+MAX_BODY_SPHERES = 16
+
+
 class ModelDesc(C.Structure):
     _fields_ = [
         ("num_bodies", C.c_int32), ("num_dofs", C.c_int32),
@@ -29,6 +32,8 @@ class ModelDesc(C.Structure):
         ("dof_lower", C.c_float * NUM_DOFS), ("dof_upper", C.c_float * NUM_DOFS), ("dof_velocity", C.c_float * NUM_DOFS),
         ("dof_effort", C.c_float * NUM_DOFS),
         ("feet_edge_pos", C.c_float * 3 * 4),
+        ("num_body_spheres", C.c_int32), ("sphere_body", C.c_int32 * MAX_BODY_SPHERES), ("sphere_pos", C.c_float * 3 * MAX_BODY_SPHERES),
+        ("sphere_radius", C.c_float * MAX_BODY_SPHERES),
     ]
 
 
@@ -63,6 +68,7 @@ class EnvCfg(C.Structure):
         ("max_episode_length", C.c_int32), ("terminate_height", C.c_float), ("terminate_vel", C.c_float),
         ("terrain_type", C.c_int32), ("terrain_env_width", C.c_float), ("terrain_env_length", C.c_float), ("terrain_border", C.c_float),
         ("state_fp16", C.c_int32),
+        ("body_gate_height", C.c_float), ("penalized_body_mask", C.c_int32), ("terminate_body_mask", C.c_int32),
     ]
 
 

@@ -36,6 +36,8 @@ struct Phys {
     V3 g;
     float contact_ramp, friction_visc, limit_k, limit_d;
     int clamp_qd;
+    // non-foot body contacts (explicit penalty on the contact spheres of the trunk box / hip-yaw and shank cylinders)
+    float body_gate, body_kn, body_dn, body_mu;
 };
 
 struct TerrainDev {
@@ -43,6 +45,19 @@ struct TerrainDev {
     int rows, cols, border_px;
     float inv_hscale, vscale;
     const int16_t* hf;
+};
+
+struct ModelDev {  // nominal (un-randomised) model, shared by all envs; filled by bg_model_create
+    float pos[13][3];
+    float mass[13];
+    float com[13][3];
+    float inertia[13][6];  // about the centre of mass: xx yy zz xy xz yz
+    float q_lo[12], q_hi[12], qd_max[12], tau_lim[12];
+    float corner[4][3];
+    // contact spheres of the non-foot collision shapes, sorted by body: body b owns sph_first[b] .. + sph_cnt[b]
+    int sph_n;
+    int sph_first[13], sph_cnt[13];
+    float sph_pos[16][3], sph_r[16];
 };
 
 struct LegParams {
@@ -171,6 +186,72 @@ BG_HD float terrain_height(const TerrainDev& t, float x, float y) {
     float h; V3 n;
     terrain_query(t, x, y, &h, &n);
     return h;
+}
+
+// ---------------------------------------------------------------- non-foot body contacts (trunk box, hip-yaw / shank cylinders)
+// Explicit penalty contact of a body's contact spheres against the terrain: same normal / friction law as the sole corners, evaluated at
+// the current state only (these links are heavy enough for an explicit force at dt = 2 ms), default material averaged with the terrain's.
+// R, p = body pose in the world, v = body velocity in body coordinates.  sel < 0: all spheres of body b; sel = 0 / 1: those whose index has
+// that parity (the two lanes of an env share the trunk's spheres).  Returns the wrench about the body origin in body coordinates
+// (a = torque, l = force) and adds the world-frame force to *fw.
+BG_HD SV body_contact_wrench(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int b, int sel, const M3& R, V3 p, SV v, V3* fw) {
+    SV w = sv_zero();
+    const int first = M.sph_first[b], cnt = M.sph_cnt[b];
+    for (int k = first; k < first + cnt; k++) {
+        if (sel >= 0 && (k & 1) != sel) continue;
+        const V3 c = v3(M.sph_pos[k][0], M.sph_pos[k][1], M.sph_pos[k][2]);
+        const float r = M.sph_r[k];
+        const V3 xw = p + mul(R, c);
+        float h; V3 n;
+        terrain_query(tr, xw.e[0], xw.e[1], &h, &n);
+        const float pen = (h - xw.e[2]) * n.e[2] + r;
+        if (!(pen > 0.f)) continue;
+        const V3 nb = mulT(R, n);
+        const V3 rc = c - r * nb;  // contact point = sphere centre - r n
+        const V3 vw = mul(R, v.l + cross(v.a, rc));
+        const float vn = dot(vw, n);
+        const float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
+        const float fn0 = ph.body_kn * pen - ph.body_dn * ramp * vn;
+        if (!(fn0 > 0.f)) continue;
+        const V3 vt = vw - vn * n;
+        const float c_t = fminf(ph.friction_visc, ph.body_mu * fn0 * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
+        const V3 f_w = fn0 * n - c_t * vt;
+        const V3 fb = mulT(R, f_w);
+        w.l = w.l + fb;
+        w.a = w.a + cross(rc, fb);
+        *fw = *fw + f_w;
+    }
+    return w;
+}
+// Kinematics-only walk down one leg that evaluates the contact spheres of its links: run BEFORE the sweeps, and only while the trunk is low
+// (substep_pre), so that the sweeps themselves exist once and carry no contact code for these bodies.  fext[I] += contact wrench of link I
+// about its origin (link coordinates), fw[I] = its world-frame force.
+template <int I, class St>
+BG_HD void leg_contact_prepass(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int body0, const St& st, const LegParams& lp, const LegState& ls,
+                               SV vpar, M3 Rpar, V3 ppar, SV* fext, V3* fw) {
+    constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    float s, c;
+    bg_sincos(ls.q[I], &s, &c);
+    const V3 lpos = st.template link_pos<I>(lp);
+    SV v;
+    v.a = rotT<AX>(c, s, vpar.a);
+    v.l = rotT<AX>(c, s, vpar.l + cross(vpar.a, lpos));
+    v.a.e[A] += ls.qd[I];
+    const V3 p = ppar + mul(Rpar, lpos);
+    M3 R = Rpar;
+    {
+        constexpr int J = Plane<AX>::J, K = Plane<AX>::K;
+        for (int r = 0; r < 3; r++) {
+            R.e[r][J] = c * Rpar.e[r][J] + s * Rpar.e[r][K];
+            R.e[r][K] = -s * Rpar.e[r][J] + c * Rpar.e[r][K];
+        }
+    }
+    if (M.sph_cnt[body0 + I] > 0) {
+        V3 f = v3(0.f, 0.f, 0.f);
+        fext[I] = fext[I] + body_contact_wrench(ph, tr, M, body0 + I, -1, R, p, v, &f);
+        fw[I] = f;
+    }
+    if constexpr (I + 1 < LEG_LINKS - 1) leg_contact_prepass<I + 1>(ph, tr, M, body0, st, lp, ls, v, R, p, fext, fw);  // the foot has its own contacts
 }
 
 // ---------------------------------------------------------------- outward sweep, link I
@@ -468,14 +549,6 @@ BG_HD void leg_body_states(const LegParams& lp, const LegState& ls, SV vpar, M3 
 }
 
 // ---------------------------------------------------------------- model constants and per-env parameters
-struct ModelDev {  // nominal (un-randomised) model, shared by all envs; filled by bg_model_create
-    float pos[13][3];
-    float mass[13];
-    float com[13][3];
-    float inertia[13][6];  // about the centre of mass: xx yy zz xy xz yz
-    float q_lo[12], q_hi[12], qd_max[12], tau_lim[12];
-    float corner[4][3];
-};
 
 // nominal body + per-env randomisation (mass scale, com offset; inertia scales with the mass as
 // Isaac Gym's recomputeInertia=True does, reference t1.py:129-131) -> constants about the body origin
@@ -522,13 +595,48 @@ struct SubstepCtxT { M3 R0; SV v0; W w; };
 using SubstepCtx = SubstepCtxT<LegWork>;
 using SubstepCtxLdsLink = SubstepCtxT<LegWorkT<LdsLinkStore>>;
 
-template <class Ctx>
-BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
-                                   const BaseState& bs, Ctx& cx, const SV* fext = nullptr) {
+// World-frame contact forces of the non-foot bodies of one lane's half of the env (net_contact_force rows; reward `collision`, t1.py:627-629)
+struct BodyContactOut {
+    bool active;          // the trunk was low enough for the spheres to be evaluated
+    V3 trunk;             // this lane's share of the trunk's force (sum the two lanes)
+    V3 link[LEG_LINKS];   // this leg's links
+};
+
+// Are the non-foot body contacts evaluated for this env?  Only while the trunk origin is less than ph.body_gate above the terrain: from a
+// standing or walking posture those shapes cannot reach the ground.  The callers test this ONCE per launch and per env (the fused env step:
+// at the start of the env step) and run one of two complete instantiations of their lane code, so that the common path carries no trace of
+// the body-contact code (a runtime branch around it inside the substep loop cost 30 % of the env step in register pressure: measured).
+BG_HD bool body_contacts_active(const Phys& ph, const TerrainDev& tr, const ModelDev& M, const V3& base_pos) {
+    return M.sph_n > 0 && base_pos.e[2] - terrain_height(tr, base_pos.e[0], base_pos.e[1]) < ph.body_gate;
+}
+
+// fext (optional): applied wrench on each link about its own origin, link coordinates.  BODY: also evaluate the contact spheres of the
+// non-foot bodies (M / leg: model constants and which leg this lane owns); their wrenches join `fext`, the trunk's share is subtracted from
+// this lane's contribution at the trunk.
+template <bool BODY, class Ctx>
+BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int leg, const LegParams& lp, const LegState& ls,
+                                   const float* tau, const BaseState& bs, Ctx& cx, const SV* fext = nullptr, BodyContactOut* bo = nullptr) {
     cx.R0 = quat_to_mat(bs.quat);
     cx.v0 = base_body_velocity(cx.R0, bs);
     V3 unused;
-    return leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused, fext);
+    if (bo) bo->active = BODY;
+    if constexpr (!BODY) {
+        return leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused, fext);
+    } else {
+        SV fx[LEG_LINKS];
+        V3 fw[LEG_LINKS];
+        for (int i = 0; i < LEG_LINKS; i++) { fx[i] = fext ? fext[i] : sv_zero(); fw[i] = v3(0.f, 0.f, 0.f); }
+        leg_contact_prepass<0>(ph, tr, M, 1 + leg * LEG_LINKS, cx.w.st, lp, ls, cx.v0, cx.R0, bs.pos, fx, fw);
+        V3 ft = v3(0.f, 0.f, 0.f);
+        const SV wt = body_contact_wrench(ph, tr, M, 0, leg, cx.R0, bs.pos, cx.v0, &ft);
+        if (bo) {
+            bo->trunk = ft;
+            for (int i = 0; i < LEG_LINKS; i++) bo->link[i] = fw[i];
+        }
+        BaseContribution out = leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused, fx);
+        out.p = out.p - wt;
+        return out;
+    }
 }
 // `both` = this leg's contribution + the partner leg's.  Returns accelerations; does not integrate.
 template <class Ctx>

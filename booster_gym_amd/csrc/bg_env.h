@@ -122,6 +122,9 @@ BG_HD Phys make_phys(const bg_env_cfg& c) {
     Phys ph;
     ph.dt = c.sim_dt; ph.g = v3(c.gravity[0], c.gravity[1], c.gravity[2]);
     ph.contact_ramp = c.contact_ramp; ph.friction_visc = c.friction_visc; ph.limit_k = c.limit_k; ph.limit_d = c.limit_d; ph.clamp_qd = c.clamp_qd;
+    // non-foot shapes: default material (friction 1, restitution 0) averaged with the terrain's, nominal stiffness / damping
+    ph.body_gate = c.body_gate_height; ph.body_kn = c.contact_k; ph.body_dn = c.contact_d * (1.0f - 0.5f * c.terrain_restitution);
+    ph.body_mu = 0.5f * (1.0f + c.terrain_mu);
     return ph;
 }
 BG_HD ContactCfg make_contact_cfg(const bg_env_cfg& c) {
@@ -163,7 +166,8 @@ BG_HD FieldRef<H16> field_ref(float* F, bg_half_bits* H, int idx, int n, int e) 
     return FieldRef<H16>{F + o, (H16 && fp16_state_field(idx)) ? H + o : nullptr};
 }
 
-template <class X, class Sink, bool H16>
+// BODY: this env step evaluates the non-foot body contacts (decided by the caller from the trunk height at the START of the env step)
+template <class X, class Sink, bool H16, bool BODY>
 BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool valid, const float* act, uint32_t step, int mode,
                          const StepOut& out) {
     const bg_env_cfg& C = E.cfg;
@@ -204,6 +208,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
     for (int a = 0; a < 6; a++) last_rootvel[a] = FLD(F_LAST_ROOTVEL, a);
 
     float tmean[LEG_LINKS];
+    float body_pen = 0.f, body_term = 0.f;  // penalised / terminating non-foot bodies of this leg in contact (last substep)
     V3 foot_force = v3(0.f, 0.f, 0.f);
     for (int i = 0; i < LEG_LINKS; i++) { tmean[i] = 0.f; a6[i] = FLD(F_ACT, j0 + i); }
 
@@ -229,7 +234,24 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
                 tau[i] = pd_torque(kp[i], kd[i], fric[i], M.tau_lim[j0 + i], last_tgt[i], ls.q[i], ls.qd[i]);
                 tmean[i] += tau[i];
             }
-            BaseContribution mine = substep_pre(ph, E.terrain, lp, ls, tau, bs, cx);
+            BodyContactOut bo;
+            BaseContribution mine = substep_pre<BODY>(ph, E.terrain, M, leg, lp, ls, tau, bs, cx, (const SV*)nullptr, &bo);
+            // contact forces of the LAST substep are the ones the task logic sees (contact_collection: last substep, T1.yaml:56): how many
+            // penalised / terminating non-foot bodies of this leg carry more than 1 N (t1.py:553,629); the trunk is counted once (leg 0)
+            body_pen = 0.f; body_term = 0.f;
+            if constexpr (BODY) {
+                V3 tf = bo.trunk;
+                for (int a = 0; a < 3; a++) tf.e[a] += x.swap(tf.e[a]);
+                const float trunk_hit = (leg == 0 && dot(tf, tf) > 1.0f) ? 1.f : 0.f;
+                body_pen = (C.penalized_body_mask & 1) ? trunk_hit : 0.f;
+                body_term = (C.terminate_body_mask & 1) ? trunk_hit : 0.f;
+                for (int i = 0; i < LEG_LINKS - 1; i++) {
+                    const float hit = dot(bo.link[i], bo.link[i]) > 1.0f ? 1.f : 0.f;
+                    const int bit = 1 << (1 + j0 + i);
+                    if (C.penalized_body_mask & bit) body_pen += hit;
+                    if (C.terminate_body_mask & bit) body_term += hit;
+                }
+            }
             BaseContribution both;
             for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
             for (int r = 0; r < 3; r++) for (int c2 = 0; c2 < 3; c2++) both.I.H.e[r][c2] = mine.I.H.e[r][c2] + x.swap(mine.I.H.e[r][c2]);
@@ -349,7 +371,15 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
         float h_base = terrain_height(E.terrain, bs.pos.e[0], bs.pos.e[1]);
         float v2 = dot(bs.vlin, bs.vlin) + dot(bs.vang, bs.vang);
         bool to = ep_len > C.max_episode_length;
-        bool rs = (v2 > C.terminate_vel) || (bs.pos.e[2] - h_base < C.terminate_height) || to;
+        {   // the feet rows of the contact tensor (this leg's foot, last substep)
+            const float hit = dot(foot_force, foot_force) > 1.0f ? 1.f : 0.f;
+            const int bit = 1 << (1 + j0 + LEG_LINKS - 1);
+            if (C.penalized_body_mask & bit) body_pen += hit;
+            if (C.terminate_body_mask & bit) body_term += hit;
+        }
+        body_pen += x.swap(body_pen);
+        body_term += x.swap(body_term);
+        bool rs = (body_term > 0.f) || (v2 > C.terminate_vel) || (bs.pos.e[2] - h_base < C.terminate_height) || to;
         to = to || (ep_len == cmd_time);
         if (bad != 0.f) rs = true;
         reset_flag = rs ? 1 : 0; tout_flag = to ? 1 : 0;
@@ -386,7 +416,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
         term[BG_REW_DOF_POS_LIMITS] = s_poslim;
         term[BG_REW_DOF_VEL_LIMITS] = s_vellim;
         term[BG_REW_TORQUE_LIMITS] = s_taulim;
-        term[BG_REW_COLLISION] = 0.f;  // only the soles collide in this build
+        term[BG_REW_COLLISION] = body_pen;  // number of penalised bodies with |contact force| > 1 N (t1.py:627-629)
         term[BG_REW_FEET_SLIP] = slip * (ep_len > 1 ? 1.f : 0.f);
         term[BG_REW_FEET_VEL_Z] = velz;
         term[BG_REW_FEET_YAW_DIFF] = ydiff * ydiff;

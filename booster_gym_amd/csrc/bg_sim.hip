@@ -33,6 +33,7 @@ struct bg_env {
     int n;
     float* f = nullptr;
     bg_half_bits* h = nullptr;  // fp16 slab of the dynamic state (cfg.state_fp16), else null
+    unsigned* lowmask = nullptr;  // [blocks of 32 envs] envs left to the body-contact kernel (two-kernel scheme), null = no body spheres
     int32_t* i = nullptr;
     float* stats = nullptr;
     float* curr = nullptr;
@@ -68,26 +69,79 @@ struct LdsSink {
 };
 
 constexpr int ENVS_PER_BLOCK = 32;
+constexpr int BODY_GRID = 512;  // persistent grid of the body-contact kernels (they walk the per-block masks)
+
+// Non-foot body contacts and the two-kernel scheme.  The contact spheres of the trunk box / hip-yaw / shank cylinders matter only while a robot
+// is collapsing (trunk lower than cfg.body_gate_height), and ANY trace of their code inside the main kernel costs the common path dearly (a
+// runtime branch in the substep loop +30 %, two instantiations of the lane code in one kernel +100 %: register allocation of a 256 + 256
+// register kernel does not survive it).  So the work is split by LAUNCH: kernel A (BODY = false, one 32-env block per workgroup) steps every
+// env whose trunk is high at the start of the step and records the others in a 32-bit mask per block; kernel B (BODY = true, a small
+// persistent grid) walks the masks and steps exactly the recorded envs with the body contacts evaluated.  B normally finds nothing.
+__device__ __forceinline__ void copy_out_rows(const StepOut& out, int e0, int rows, unsigned mask, const float* s_obs, const float* s_priv) {
+    const int lane = threadIdx.x;
+    for (int r = 0; r < rows; r++) {
+        if (!((mask >> r) & 1u)) continue;
+        if (lane < BG_NUM_OBS) out.obs[(size_t)(e0 + r) * BG_NUM_OBS + lane] = s_obs[r * BG_NUM_OBS + lane];
+        if (lane < BG_NUM_PRIV) out.priv[(size_t)(e0 + r) * BG_NUM_PRIV + lane] = s_priv[r * BG_NUM_PRIV + lane];
+    }
+}
 
 template <bool H16>
-__global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __restrict__ act, uint32_t step, int mode, StepOut out) {
+__global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __restrict__ act, uint32_t step, int mode, StepOut out,
+                                                      unsigned* __restrict__ lowmask) {
     __shared__ float s_obs[ENVS_PER_BLOCK * BG_NUM_OBS];
     __shared__ float s_priv[ENVS_PER_BLOCK * BG_NUM_PRIV];
+    __shared__ unsigned s_low;
     const int lane = threadIdx.x;
     const int e0 = blockIdx.x * ENVS_PER_BLOCK;
     int e = e0 + (lane >> 1);
     const bool valid = e < E.n;
     if (!valid) e = E.n - 1;
+    if (lane == 0) s_low = 0u;
+    __syncthreads();
     DppSwap x;
     LdsSink sink{s_obs, s_priv, lane >> 1};
-    env_step_lane<DppSwap, LdsSink, H16>(E, x, sink, e, lane & 1, valid, act, step, mode, out);
+    // decided once per env step from the trunk height at its start; both lanes of an env agree
+    const V3 p0 = v3(E.f[(size_t)(F_ROOT + 0) * E.n + e], E.f[(size_t)(F_ROOT + 1) * E.n + e], E.f[(size_t)(F_ROOT + 2) * E.n + e]);
+    const bool low = mode == 0 && lowmask && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, p0);
+    if (low) { if (valid && !(lane & 1)) atomicOr(&s_low, 1u << (lane >> 1)); }
+    else env_step_lane<DppSwap, LdsSink, H16, false>(E, x, sink, e, lane & 1, valid, act, step, mode, out);
     __syncthreads();
-    // coalesced copy-out of the block's 32 observation rows (contiguous in the [N][47] / [N][14] outputs)
     const int rows = min(ENVS_PER_BLOCK, E.n - e0);
-    float* go = out.obs + (size_t)e0 * BG_NUM_OBS;
-    for (int k = lane; k < rows * BG_NUM_OBS; k += 64) go[k] = s_obs[k];
-    float* gp = out.priv + (size_t)e0 * BG_NUM_PRIV;
-    for (int k = lane; k < rows * BG_NUM_PRIV; k += 64) gp[k] = s_priv[k];
+    const unsigned lowm = s_low;
+    if (lowm == 0u) {
+        // coalesced copy-out of the block's 32 observation rows (contiguous in the [N][47] / [N][14] outputs)
+        float* go = out.obs + (size_t)e0 * BG_NUM_OBS;
+        for (int k = lane; k < rows * BG_NUM_OBS; k += 64) go[k] = s_obs[k];
+        float* gp = out.priv + (size_t)e0 * BG_NUM_PRIV;
+        for (int k = lane; k < rows * BG_NUM_PRIV; k += 64) gp[k] = s_priv[k];
+    } else {
+        copy_out_rows(out, e0, rows, ~lowm, s_obs, s_priv);
+    }
+    if (lowmask && lane == 0) lowmask[blockIdx.x] = lowm;
+}
+
+// kernel B: the envs kernel A left out (trunk low at the start of the step), with the non-foot body contacts
+template <bool H16>
+__global__ __launch_bounds__(64) void env_step_body_kernel(EnvDev E, const float* __restrict__ act, uint32_t step, StepOut out,
+                                                           const unsigned* __restrict__ lowmask, int nblocks) {
+    __shared__ float s_obs[ENVS_PER_BLOCK * BG_NUM_OBS];
+    __shared__ float s_priv[ENVS_PER_BLOCK * BG_NUM_PRIV];
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const unsigned lowm = lowmask[b];
+        if (lowm == 0u) continue;
+        const int e0 = b * ENVS_PER_BLOCK;
+        int e = e0 + (lane >> 1);
+        const bool valid = e < E.n;
+        if (!valid) e = E.n - 1;
+        DppSwap x;
+        LdsSink sink{s_obs, s_priv, lane >> 1};
+        if ((lowm >> (lane >> 1)) & 1u) env_step_lane<DppSwap, LdsSink, H16, true>(E, x, sink, e, lane & 1, valid, act, step, 0, out);
+        __syncthreads();
+        copy_out_rows(out, e0, min(ENVS_PER_BLOCK, E.n - e0), lowm, s_obs, s_priv);
+        __syncthreads();
+    }
 }
 
 // ------------------------------------------------------------------ dynamics only: qacc for N independent states
@@ -96,13 +150,11 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __r
 // them per wave.  With everything in registers the kernel needs 282 and one wave fits per SIMD (77 % VALU-busy, the rest is exposed load
 // and dependency latency).  Keeping the per-env link constants (13 floats x 6 links per lane, computed once per launch) in LDS brings it to
 // 248 registers with no spill, two waves share a SIMD and cover each other's stalls: 88 % VALU-busy, +14 % throughput at 1M envs.
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
-                                                              const float* __restrict__ qd, const float* __restrict__ tau,
-                                                              const float* __restrict__ wrench, float* __restrict__ qacc) {
+template <bool BODY>
+__device__ __forceinline__ void forward_dynamics_lane(const EnvDev& E, int e, bool valid, float* s_work, const float* __restrict__ root,
+                                                      const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ tau,
+                                                      const float* __restrict__ wrench, float* __restrict__ qacc) {
     const int lane = threadIdx.x, leg = lane & 1;
-    int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
-    const bool valid = e < E.n;
-    if (!valid) e = E.n - 1;
     const int n = E.n;
     Phys ph = make_phys(E.cfg);
     ContactCfg cc = make_contact_cfg(E.cfg);
@@ -122,11 +174,10 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     SV wr = sv_zero();
     if (wrench) { const float* w = wrench + (size_t)e * 6; wr.l = v3(w[0], w[1], w[2]); wr.a = v3(w[3], w[4], w[5]); }
     DppSwap x;
-    __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
     SubstepCtxLdsLink cx;
     cx.w.st.p = (lds_f32*)(s_work + lane);
     cx.w.st.stash(lp);
-    BaseContribution mine = substep_pre(ph, E.terrain, lp, ls, t6, bs, cx), both;
+    BaseContribution mine = substep_pre<BODY>(ph, E.terrain, *E.model, leg, lp, ls, t6, bs, cx), both;
     for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
     for (int k = 0; k < 3; k++) { both.p.a.e[k] = mine.p.a.e[k] + x.swap(mine.p.a.e[k]); both.p.l.e[k] = mine.p.l.e[k] + x.swap(mine.p.l.e[k]); }
@@ -138,6 +189,45 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
     if (leg == 0) for (int a = 0; a < 3; a++) { o[a] = lin_w.e[a]; o[3 + a] = ang_w.e[a]; }
     for (int i = 0; i < LEG_LINKS; i++) o[6 + leg * 6 + i] = qdd[i];
     for (int a = 0; a < 3; a++) E.f[(size_t)(F_CONTACT + 3 * leg + a) * n + e] = fw.e[a];
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
+                                                              const float* __restrict__ qd, const float* __restrict__ tau,
+                                                              const float* __restrict__ wrench, float* __restrict__ qacc,
+                                                              unsigned* __restrict__ lowmask) {
+    __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
+    __shared__ unsigned s_low;
+    const int lane = threadIdx.x;
+    int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
+    const bool valid = e < E.n;
+    if (!valid) e = E.n - 1;
+    if (lowmask) {
+        if (lane == 0) s_low = 0u;
+        __syncthreads();
+    }
+    const float* r = root + (size_t)e * 13;
+    const bool low = lowmask && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]));
+    if (low) { if (valid && !(lane & 1)) atomicOr(&s_low, 1u << (lane >> 1)); }
+    else forward_dynamics_lane<false>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+    if (lowmask) {
+        __syncthreads();
+        if (lane == 0) lowmask[blockIdx.x] = s_low;
+    }
+}
+// kernel B of the two-kernel scheme (see env_step_kernel): the envs whose trunk is low, with the non-foot body contacts
+__global__ __launch_bounds__(64) void forward_dynamics_body_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
+                                                                   const float* __restrict__ qd, const float* __restrict__ tau,
+                                                                   const float* __restrict__ wrench, float* __restrict__ qacc,
+                                                                   const unsigned* __restrict__ lowmask, int nblocks) {
+    __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const unsigned lowm = lowmask[b];
+        if (lowm == 0u) continue;
+        int e = b * ENVS_PER_BLOCK + (lane >> 1);
+        const bool valid = e < E.n;
+        if (!valid) e = E.n - 1;
+        if ((lowm >> (lane >> 1)) & 1u) forward_dynamics_lane<true>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+    }
 }
 
 // ------------------------------------------------------------------ granular simulator calls on caller-owned Isaac-layout tensors
@@ -174,13 +264,11 @@ __device__ __forceinline__ void sim_write_body(const SimLane& L, int e, int leg,
 }
 
 // one gym.simulate (t1.py:451): a sim.dt step of every env, in place on root [N][13] / dof [N][12][2]
-__global__ __launch_bounds__(64) void sim_substep_kernel(EnvDev E, float* __restrict__ root, float* __restrict__ dof, const float* __restrict__ tau,
-                                                         const float* __restrict__ bforce, const float* __restrict__ btorque,
-                                                         float* __restrict__ contact, float* __restrict__ body) {
+template <bool BODY>
+__device__ __forceinline__ void sim_substep_lane(const EnvDev& E, int e, bool valid, float* __restrict__ root, float* __restrict__ dof,
+                                                 const float* __restrict__ tau, const float* __restrict__ bforce, const float* __restrict__ btorque,
+                                                 float* __restrict__ contact, float* __restrict__ body) {
     const int lane = threadIdx.x, leg = lane & 1;
-    int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
-    const bool valid = e < E.n;
-    if (!valid) e = E.n - 1;
     Phys ph = make_phys(E.cfg);
     SimLane L;
     sim_load(E, e, leg, root, dof, L);
@@ -200,7 +288,8 @@ __global__ __launch_bounds__(64) void sim_substep_kernel(EnvDev E, float* __rest
     }
     DppSwap x;
     SubstepCtx cx;
-    BaseContribution mine = substep_pre(ph, E.terrain, L.lp, L.ls, t6, L.bs, cx, has_w ? fext : nullptr), both;
+    BodyContactOut bo;
+    BaseContribution mine = substep_pre<BODY>(ph, E.terrain, *E.model, leg, L.lp, L.ls, t6, L.bs, cx, has_w ? fext : nullptr, &bo), both;
     for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
     for (int k = 0; k < 3; k++) { both.p.a.e[k] = mine.p.a.e[k] + x.swap(mine.p.a.e[k]); both.p.l.e[k] = mine.p.l.e[k] + x.swap(mine.p.l.e[k]); }
@@ -218,13 +307,51 @@ __global__ __launch_bounds__(64) void sim_substep_kernel(EnvDev E, float* __rest
         float* d = dof + ((size_t)e * 12 + leg * 6 + i) * 2;
         d[0] = L.ls.q[i]; d[1] = L.ls.qd[i];
     }
-    if (contact) {  // net contact force per body, world frame (t1.py:219); only the feet carry collision geometry in this build
+    if (contact) {  // net contact force per body, world frame (t1.py:219): sole corners of the feet + contact spheres of the other shapes
         float* c = contact + (size_t)e * 39;
-        if (leg == 0) c[0] = c[1] = c[2] = 0.f;
-        for (int i = 0; i < LEG_LINKS - 1; i++) for (int a = 0; a < 3; a++) c[3 * (1 + leg * LEG_LINKS + i) + a] = 0.f;
+        V3 tf = bo.active ? bo.trunk : v3(0.f, 0.f, 0.f);
+        for (int a = 0; a < 3; a++) tf.e[a] += x.swap(tf.e[a]);
+        if (leg == 0) for (int a = 0; a < 3; a++) c[a] = tf.e[a];
+        for (int i = 0; i < LEG_LINKS - 1; i++)
+            for (int a = 0; a < 3; a++) c[3 * (1 + leg * LEG_LINKS + i) + a] = bo.active ? bo.link[i].e[a] : 0.f;
         for (int a = 0; a < 3; a++) c[3 * (LEG_LINKS + leg * LEG_LINKS) + a] = fw.e[a];
     }
     if (body) sim_write_body(L, e, leg, body);
+}
+__global__ __launch_bounds__(64) void sim_substep_kernel(EnvDev E, float* __restrict__ root, float* __restrict__ dof, const float* __restrict__ tau,
+                                                         const float* __restrict__ bforce, const float* __restrict__ btorque,
+                                                         float* __restrict__ contact, float* __restrict__ body, unsigned* __restrict__ lowmask) {
+    __shared__ unsigned s_low;
+    const int lane = threadIdx.x;
+    int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
+    const bool valid = e < E.n;
+    if (!valid) e = E.n - 1;
+    if (lowmask) {
+        if (lane == 0) s_low = 0u;
+        __syncthreads();
+    }
+    const float* r = root + (size_t)e * 13;
+    const bool low = lowmask && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]));
+    if (low) { if (valid && !(lane & 1)) atomicOr(&s_low, 1u << (lane >> 1)); }
+    else sim_substep_lane<false>(E, e, valid, root, dof, tau, bforce, btorque, contact, body);
+    if (lowmask) {
+        __syncthreads();
+        if (lane == 0) lowmask[blockIdx.x] = s_low;
+    }
+}
+__global__ __launch_bounds__(64) void sim_substep_body_kernel(EnvDev E, float* __restrict__ root, float* __restrict__ dof, const float* __restrict__ tau,
+                                                              const float* __restrict__ bforce, const float* __restrict__ btorque,
+                                                              float* __restrict__ contact, float* __restrict__ body,
+                                                              const unsigned* __restrict__ lowmask, int nblocks) {
+    const int lane = threadIdx.x;
+    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+        const unsigned lowm = lowmask[b];
+        if (lowm == 0u) continue;
+        int e = b * ENVS_PER_BLOCK + (lane >> 1);
+        const bool valid = e < E.n;
+        if (!valid) e = E.n - 1;
+        if ((lowm >> (lane >> 1)) & 1u) sim_substep_lane<true>(E, e, valid, root, dof, tau, bforce, btorque, contact, body);
+    }
 }
 
 // gym.refresh_rigid_body_state_tensor (t1.py:462): body rows from the current root / dof tensors, no dynamics
@@ -306,6 +433,13 @@ extern "C" int bg_model_create(const bg_model_desc* d, bg_model** out) {
     if (d->parent[0] != -1 || d->joint_axis[0] != 0) return fail(-1, "bg_model_create: body 0 must be the floating base");
     for (int b = 0; b < BG_NUM_BODIES; b++)
         if (!(d->mass[b] > 0.f)) return fail(-1, "bg_model_create: non-positive mass on body " + std::to_string(b));
+    if (d->num_body_spheres < 0 || d->num_body_spheres > BG_MAX_BODY_SPHERES) return fail(-1, "bg_model_create: num_body_spheres out of range");
+    for (int k = 0; k < d->num_body_spheres; k++) {
+        const int b = d->sphere_body[k];
+        if (b < 0 || b >= BG_NUM_BODIES || b == 6 || b == 12) return fail(-1, "bg_model_create: contact spheres belong to the trunk or a non-foot leg link");
+        if (k > 0 && b < d->sphere_body[k - 1]) return fail(-1, "bg_model_create: contact spheres must be sorted by body");
+        if (!(d->sphere_radius[k] >= 0.f)) return fail(-1, "bg_model_create: negative sphere radius");
+    }
     bg_model* m = new bg_model;
     m->desc = *d;
     *out = m;
@@ -367,6 +501,13 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
         md.qd_max[j] = model->desc.dof_velocity[j]; md.tau_lim[j] = model->desc.dof_effort[j];
     }
     for (int k = 0; k < 4; k++) for (int a = 0; a < 3; a++) md.corner[k][a] = model->desc.feet_edge_pos[k][a];
+    md.sph_n = model->desc.num_body_spheres;
+    for (int k = 0; k < md.sph_n; k++) {
+        const int b = model->desc.sphere_body[k];
+        if (md.sph_cnt[b]++ == 0) md.sph_first[b] = k;
+        md.sph_r[k] = model->desc.sphere_radius[k];
+        for (int a = 0; a < 3; a++) md.sph_pos[k][a] = model->desc.sphere_pos[k][a];
+    }
     HIP_OK(hipMemcpy(e->model_dev, &md, sizeof(md), hipMemcpyHostToDevice));
     e->terrain.type = 0; e->terrain.rows = e->terrain.cols = e->terrain.border_px = 0; e->terrain.inv_hscale = 1.f; e->terrain.vscale = 0.f; e->terrain.hf = nullptr;
     memset(&e->bound, 0, sizeof(e->bound));
@@ -378,6 +519,14 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
         for (int f = 0; f < 2; f++) { host[(size_t)(F_FOOT_MAT + 3 * f) * n + k] = 1.f; host[(size_t)(F_FOOT_MAT + 3 * f + 1) * n + k] = 1.f; }
     }
     HIP_OK(hipMemcpy(e->f, host.data(), sizeof(float) * n * F_COUNT, hipMemcpyHostToDevice));
+    // Non-foot body contacts are evaluated for envs whose trunk starts a step below body_gate_height.  When the task resets every env that ends
+    // a step below terminate_height >= body_gate_height (the shipped T1.yaml: 0.45 / 0.45) no env can ever start a step that low, and the whole
+    // two-kernel scheme (mask bookkeeping + the second launch) is left out: the launch sequence is then exactly that of a model without spheres.
+    if (model->desc.num_body_spheres > 0 && cfg->body_gate_height > cfg->terminate_height) {
+        const size_t nb = (n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+        HIP_OK(hipMalloc(&e->lowmask, sizeof(unsigned) * nb));
+        HIP_OK(hipMemset(e->lowmask, 0, sizeof(unsigned) * nb));
+    }
     if (cfg->state_fp16) {  // fp16 slab of the dynamic state: zeros, identity orientation
         HIP_OK(hipMalloc(&e->h, sizeof(bg_half_bits) * n * FP16_SLAB_FIELDS));
         std::vector<bg_half_bits> hh(n * FP16_SLAB_FIELDS, 0);
@@ -391,7 +540,7 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
 extern "C" void bg_env_destroy(bg_env* e) {
     if (!e) return;
     (void)hipFree(e->sim_tau); (void)hipFree(e->sim_bforce); (void)hipFree(e->sim_btorque);
-    (void)hipFree(e->f); (void)hipFree(e->h); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
+    (void)hipFree(e->f); (void)hipFree(e->h); (void)hipFree(e->lowmask); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
     delete e;
 }
 
@@ -440,8 +589,16 @@ extern "C" int bg_env_bind_outputs(bg_env* e, float* obs, float* priv, float* re
 static int launch_step(bg_env* e, const float* actions, int mode, const StepOut& out, void* stream) {
     if (!out.obs || !out.priv || !out.rew || !out.done || !out.tout) return fail(-1, "bg_env_step: outputs are not bound");
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
-    if (e->h) hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), actions, (uint32_t)e->step_count, mode, out);
-    else hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), actions, (uint32_t)e->step_count, mode, out);
+    hipStream_t st = (hipStream_t)stream;
+    const uint32_t cnt = (uint32_t)e->step_count;
+    if (e->h) hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
+    else hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
+    if (e->lowmask && mode == 0) {  // kernel B: the envs whose trunk was low at the start of the step (usually none)
+        const int nb = (int)grid.x;
+        dim3 gb(nb < BODY_GRID ? nb : BODY_GRID);
+        if (e->h) hipLaunchKernelGGL(env_step_body_kernel<true>, gb, block, 0, st, env_dev(e), actions, cnt, out, (const unsigned*)e->lowmask, nb);
+        else hipLaunchKernelGGL(env_step_body_kernel<false>, gb, block, 0, st, env_dev(e), actions, cnt, out, (const unsigned*)e->lowmask, nb);
+    }
     HIP_OK(hipGetLastError());
     if (e->cfg.curriculum && mode == 0)  // publish this step's curriculum increments to the next step's samplers
         HIP_OK(hipMemcpyAsync(e->curr_read, e->curr, sizeof(float) * e->curr_cells, hipMemcpyDeviceToDevice, (hipStream_t)stream));
@@ -559,7 +716,12 @@ extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float
                                        float* qacc, void* stream) {
     if (!e || !root || !q || !qd || !tau || !qacc) return fail(-1, "bg_env_forward_dynamics: null argument");
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
-    hipLaunchKernelGGL(forward_dynamics_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc);
+    hipLaunchKernelGGL(forward_dynamics_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->lowmask);
+    if (e->lowmask) {
+        const int nb = (int)grid.x;
+        hipLaunchKernelGGL(forward_dynamics_body_kernel, dim3(nb < BODY_GRID ? nb : BODY_GRID), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
+                           wrench, qacc, (const unsigned*)e->lowmask, nb);
+    }
     HIP_OK(hipGetLastError());
     return 0;
 }
@@ -603,7 +765,13 @@ extern "C" int bg_sim_simulate(bg_env* e, void* stream) {
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
     const bool w = e->sim_wrench_pending;
     hipLaunchKernelGGL(sim_substep_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), e->sim_root, e->sim_dof, (const float*)e->sim_tau,
-                       w ? (const float*)e->sim_bforce : nullptr, w ? (const float*)e->sim_btorque : nullptr, e->sim_contact, e->sim_body);
+                       w ? (const float*)e->sim_bforce : nullptr, w ? (const float*)e->sim_btorque : nullptr, e->sim_contact, e->sim_body, e->lowmask);
+    if (e->lowmask) {
+        const int nb = (int)grid.x;
+        hipLaunchKernelGGL(sim_substep_body_kernel, dim3(nb < BODY_GRID ? nb : BODY_GRID), block, 0, (hipStream_t)stream, env_dev(e), e->sim_root, e->sim_dof,
+                           (const float*)e->sim_tau, w ? (const float*)e->sim_bforce : nullptr, w ? (const float*)e->sim_btorque : nullptr, e->sim_contact,
+                           e->sim_body, (const unsigned*)e->lowmask, nb);
+    }
     HIP_OK(hipGetLastError());
     e->sim_wrench_pending = false;  // applied forces last for one simulate
     return 0;

@@ -254,6 +254,9 @@ class T1(BaseTask):
         if sd not in ("fp32", "float32", "fp16", "float16", "half"):
             raise ValueError(f"sim.state_dtype must be fp32 or fp16, got {sd!r}")
         c.state_fp16 = int(sd in ("fp16", "float16", "half"))
+        c.body_gate_height = float(cfg.get("contact", {}).get("body_gate_height", 0.45))
+        c.penalized_body_mask = sum(1 << int(b) for b in set(self.penalized_contact_indices.tolist()))
+        c.terminate_body_mask = sum(1 << int(b) for b in set(self.termination_contact_indices.tolist()))
         return c
 
     def _model_struct(self):
@@ -275,6 +278,15 @@ class T1(BaseTask):
         for k in range(4):
             for a in range(3):
                 d.feet_edge_pos[k][a] = float(fe[k][a])
+        # non-foot collision shapes (URDF <collision>) as contact spheres; contact.body_contacts: false switches them off
+        sph = m.contact_spheres(exclude_bodies=self.feet_indices.tolist()) if self.cfg.get("contact", {}).get("body_contacts", True) else []
+        if len(sph) > _lib.MAX_BODY_SPHERES:
+            raise ValueError(f"{len(sph)} body contact spheres, the library holds {_lib.MAX_BODY_SPHERES}")
+        d.num_body_spheres = len(sph)
+        for k, (b, c, r) in enumerate(sph):
+            d.sphere_body[k], d.sphere_radius[k] = b, r
+            for a in range(3):
+                d.sphere_pos[k][a] = c[a]
         return d
 
     def _create_native(self):

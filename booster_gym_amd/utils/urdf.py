@@ -107,6 +107,24 @@ class FlatModel:
     def find_body(self, name):
         return self.body_names.index(name)
 
+    def contact_spheres(self, exclude_bodies=()):
+        """Contact spheres (body, centre, radius) standing in for the collision primitives of the bodies NOT in `exclude_bodies` (the feet have
+        their own sole-corner contacts): a box gives its 8 corners with radius 0, a z-axis cylinder two spheres of its radius inscribed in
+        its ends.  Sorted by body index."""
+        out = []
+        for sh in self.shapes:
+            b = int(sh["body"])
+            if b in exclude_bodies:
+                continue
+            px, py, pz = (float(v) for v in sh["pos"])
+            if sh["type"] == "box":
+                hx, hy, hz = (0.5 * float(v) for v in sh["size"])
+                out += [(b, (px + i * hx, py + j * hy, pz + k * hz), 0.0) for i in (-1, 1) for j in (-1, 1) for k in (-1, 1)]
+            elif sh["type"] == "cylinder":
+                r, half = float(sh["size"][0]), 0.5 * float(sh["size"][1])
+                out += [(b, (px, py, pz + sgn * max(half - r, 0.0)), r) for sgn in (-1.0, 1.0)]
+        return sorted(out, key=lambda t: t[0])
+
     def to_json(self):
         return {
             "format": "booster_gym_amd.flat_model.v1",

@@ -25,6 +25,7 @@ extern "C" {
 #define BG_NUM_OBS 47
 #define BG_NUM_PRIV 14
 #define BG_NUM_REWARD_TERMS 26
+#define BG_MAX_BODY_SPHERES 16
 
 typedef struct bg_model bg_model;
 typedef struct bg_env bg_env;
@@ -41,6 +42,12 @@ typedef struct {
     float inertia[BG_NUM_BODIES][6]; /* about com: xx yy zz xy xz yz */
     float dof_lower[BG_NUM_DOFS], dof_upper[BG_NUM_DOFS], dof_velocity[BG_NUM_DOFS], dof_effort[BG_NUM_DOFS];
     float feet_edge_pos[4][3]; /* cfg asset.feet_edge_pos, envs/T1.yaml:79-82 */
+    /* contact spheres of the NON-foot collision shapes of the asset (URDF <collision>: box corners with radius 0, two spheres inscribed in the
+     * ends of a cylinder), sorted by body; bodies are the trunk or leg links.  num_body_spheres = 0 switches these contacts off. */
+    int32_t num_body_spheres;
+    int32_t sphere_body[BG_MAX_BODY_SPHERES];
+    float sphere_pos[BG_MAX_BODY_SPHERES][3];
+    float sphere_radius[BG_MAX_BODY_SPHERES];
 } bg_model_desc;
 
 /* randomisation / noise entry (utils/utils.py:5-30): mode 0 none, 1 gaussian additive,
@@ -102,6 +109,13 @@ typedef struct {
      * velocities, joint state, targets / actions and their histories, commands, gait, filters, push wrench.  Arithmetic stays fp32; root position,
      * last feet positions, parameters and outputs stay fp32.  bg_env_get/set_state / get/set_field convert transparently. */
     int32_t state_fp16;
+    /* non-foot body contacts: evaluated for envs whose trunk origin starts the step lower than body_gate_height above
+     * the terrain, and only if body_gate_height > terminate_height (otherwise every such env has been reset before its next step and the
+     * second launch that handles them is left out altogether).
+     * Bit b of the masks = body b: rewards.penalize_contacts_on / terminate_contacts_on resolved against the body names (t1.py:85-100);
+     * a body counts when its net contact force exceeds 1 N (t1.py:553,629). */
+    float body_gate_height;
+    int32_t penalized_body_mask, terminate_body_mask;
 } bg_env_cfg;
 
 /* ---- model (replaces gym.load_asset and the asset queries, t1.py:54-108) */

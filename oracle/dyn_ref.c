@@ -45,6 +45,11 @@ typedef struct {
     double q_lower[ND], q_upper[ND], qd_limit[ND];
     int32_t foot_body[2];
     double foot_corner[4][3];
+    /* contact spheres of the non-foot collision shapes (URDF <collision>: trunk box corners with radius 0, cylinder end caps) */
+    int32_t n_sph;
+    int32_t sph_body[16];
+    double sph_pos[16][3];
+    double sph_r[16];
 } ref_model_t;
 
 typedef struct {
@@ -58,6 +63,7 @@ typedef struct {
     double terrain_mu, terrain_restitution;
     int32_t clamp_qd;
     int32_t pad;
+    double body_gate_height; /* m: the spheres above are evaluated only while the trunk origin is lower than this above the terrain */
 } ref_phys_t;
 
 typedef struct {
@@ -314,6 +320,56 @@ static void contacts(const ref_model_t *m, const ref_phys_t *p, const ref_terrai
     }
 }
 
+/* Non-foot bodies (trunk box, hip-yaw and shank cylinders): explicit penalty contact of their spheres, same normal / friction law as the
+ * sole corners but evaluated at the current state only (no implicit term: these links are heavy enough for dt = 2 ms), default material
+ * (friction 1, restitution 0) averaged with the terrain's.  Evaluated only while the trunk is low (body_gate_height): the spheres cannot
+ * reach the ground from a standing or walking posture.  wrench[b] = [torque about the body origin; force] in body coords, fw[b] = world force. */
+/* -1: the gate is evaluated on the state at hand (single-substep entry points); 0 / 1: decided by the caller for a whole env step
+ * (ref_substeps: from the trunk height at the START of the env step, as the fused HIP env step does) */
+static __thread int g_body_gate = -1;
+static int body_gate_low(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *root) {
+    return m->n_sph > 0 && root[2] - ref_terrain_height(t, root[0], root[1]) < p->body_gate_height;
+}
+static void body_contacts(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t *t, const double *root, const kin_t *k,
+                          double wrench[NB][6], double fw_body[NB][3]) {
+    memset(wrench, 0, sizeof(double) * NB * 6);
+    memset(fw_body, 0, sizeof(double) * NB * 3);
+    if (!(g_body_gate >= 0 ? g_body_gate : body_gate_low(m, p, t, root))) return;
+    const double mu = 0.5 * (1.0 + p->terrain_mu), kn = p->contact_k, dn = p->contact_d * (1.0 - 0.5 * p->terrain_restitution);
+    for (int s = 0; s < m->n_sph; s++) {
+        const int b = m->sph_body[s];
+        const double *c = m->sph_pos[s], r = m->sph_r[s];
+        double cw[3], xw[3], h, n[3];
+        m3_vec(k->Rw[b], c, cw);
+        for (int a = 0; a < 3; a++) xw[a] = k->pw[b][a] + cw[a];
+        terrain_query(t, xw[0], xw[1], &h, n);
+        const double pen = (h - xw[2]) * n[2] + r;
+        if (pen <= 0) continue;
+        /* contact point = sphere centre - r n, in body coords rc = c - r R^T n */
+        double nb[3], rc[3], t1[3], vb[3], vw[3];
+        m3t_vec(k->Rw[b], n, nb);
+        for (int a = 0; a < 3; a++) rc[a] = c[a] - r * nb[a];
+        cross(k->v[b], rc, t1);
+        for (int a = 0; a < 3; a++) vb[a] = k->v[b][3 + a] + t1[a];
+        m3_vec(k->Rw[b], vb, vw);
+        const double vn = vw[0] * n[0] + vw[1] * n[1] + vw[2] * n[2];
+        const double ramp = pen < p->contact_ramp ? pen / p->contact_ramp : 1.0;
+        const double fn0 = kn * pen - dn * ramp * vn;
+        if (fn0 <= 0) continue;
+        double vt[3];
+        for (int a = 0; a < 3; a++) vt[a] = vw[a] - vn * n[a];
+        const double vtn = sqrt(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]);
+        double c_t = p->friction_visc;
+        const double cap = mu * fn0 / (vtn + 1e-6);
+        if (cap < c_t) c_t = cap;
+        double f_w[3], fb[3], tq[3];
+        for (int a = 0; a < 3; a++) f_w[a] = fn0 * n[a] - c_t * vt[a];
+        m3t_vec(k->Rw[b], f_w, fb);
+        cross(rc, fb, tq);
+        for (int a = 0; a < 3; a++) { wrench[b][a] += tq[a]; wrench[b][3 + a] += fb[a]; fw_body[b][a] += f_w[a]; }
+    }
+}
+
 /* joint-limit spring/damper, implicit in the joint velocity:  tau = t0 - bl * qdd */
 static void joint_limits(const ref_model_t *m, const ref_phys_t *p, const double *q, const double *qd, double *t0, double *bl) {
     for (int j = 0; j < ND; j++) {
@@ -391,6 +447,9 @@ static int forward_core(const ref_model_t *m, const ref_phys_t *p, const ref_ter
             for (int a = 0; a < 3; a++) { pA[i][a] -= tq[a] + cxf[a]; pA[i][3 + a] -= f[a]; }
         }
     }
+    static __thread double bw[NB][6], bfw[NB][3];
+    body_contacts(m, p, t, root, &k, bw, bfw);
+    for (int i = 0; i < m->nb; i++) for (int a = 0; a < 6; a++) pA[i][a] -= bw[i][a];
     for (int f = 0; f < 2; f++) {
         int b = m->foot_body[f];
         double Bag[6];
@@ -451,7 +510,7 @@ static int forward_core(const ref_model_t *m, const ref_phys_t *p, const ref_ter
     if (a_body)
         for (int i = 0; i < m->nb; i++) for (int a = 0; a < 6; a++) a_body[6 * i + a] = ap[i][a] + k.ag[i][a];
     if (contact_force_w) {
-        memset(contact_force_w, 0, NB * 3 * sizeof(double));
+        memcpy(contact_force_w, bfw, NB * 3 * sizeof(double)); /* explicit body contacts; the feet rows are overwritten below */
         for (int f = 0; f < 2; f++) {
             /* report the force that actually acted over the step: f0 - B a, rotated to world */
             int b = m->foot_body[f];
@@ -619,7 +678,9 @@ int ref_substeps(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t 
                  const double *tau_limit, double *root, double *q, double *qd, const double *targets, double *last_targets,
                  int delay, const double *base_wrench_local, double *torques_mean, double *contact_force_w) {
     for (int j = 0; j < ND; j++) torques_mean[j] = 0;
-    for (int s = 0; s < decimation; s++) {
+    g_body_gate = body_gate_low(m, p, t, root);
+    int rc = 0;
+    for (int s = 0; s < decimation && !rc; s++) {
         double tau[ND];
         if (delay == s) for (int j = 0; j < ND; j++) last_targets[j] = targets[j];
         for (int j = 0; j < ND; j++) {
@@ -631,10 +692,11 @@ int ref_substeps(const ref_model_t *m, const ref_phys_t *p, const ref_terrain_t 
             tau[j] = tq;
             torques_mean[j] += tq;
         }
-        if (ref_step(m, p, t, mass_scale, com_off, foot_mat, root, q, qd, tau, s == 0 ? base_wrench_local : 0, contact_force_w)) return -1;
+        if (ref_step(m, p, t, mass_scale, com_off, foot_mat, root, q, qd, tau, s == 0 ? base_wrench_local : 0, contact_force_w)) rc = -1;
     }
+    g_body_gate = -1;
     for (int j = 0; j < ND; j++) torques_mean[j] /= decimation;
-    return 0;
+    return rc;
 }
 
 /* batch driver used by the CPU baseline (OpenMP over environments) */

@@ -26,6 +26,10 @@ class RefModel(C.Structure):
         ("qd_limit", C.c_double * ND),
         ("foot_body", C.c_int32 * 2),
         ("foot_corner", C.c_double * 3 * 4),
+        ("n_sph", C.c_int32),
+        ("sph_body", C.c_int32 * 16),
+        ("sph_pos", C.c_double * 3 * 16),
+        ("sph_r", C.c_double * 16),
     ]
 
 
@@ -43,6 +47,7 @@ class RefPhys(C.Structure):
         ("terrain_restitution", C.c_double),
         ("clamp_qd", C.c_int32),
         ("pad", C.c_int32),
+        ("body_gate_height", C.c_double),
     ]
 
 
@@ -89,14 +94,34 @@ def _f64(a):
 # default physics constants of this build; product defaults must match
 DEFAULT_PHYS = dict(
     dt=0.002, g=(0.0, 0.0, -9.81), contact_k=4.0e4, contact_d=600.0, contact_ramp=1.0e-3, friction_visc=1.0e4,
-    limit_k=2000.0, limit_d=20.0, terrain_mu=1.0, terrain_restitution=0.0, clamp_qd=1,
+    limit_k=2000.0, limit_d=20.0, terrain_mu=1.0, terrain_restitution=0.0, clamp_qd=1, body_gate_height=0.45,
 )
+
+
+def contact_spheres(flat_model, foot_bodies):
+    """Contact spheres of the non-foot collision shapes (URDF <collision>, resources/T1/T1_locomotion.xml:42,66,71,99,104): the 8 corners of a
+    box with radius 0, two spheres inscribed in the ends of a cylinder (axis z).  Returns [(body, (x, y, z), radius)]."""
+    out = []
+    for sh in flat_model.shapes:
+        b, pos, size = int(sh["body"]), [float(v) for v in sh["pos"]], [float(v) for v in sh["size"]]
+        if b in foot_bodies:
+            continue
+        if sh["type"] == "box":
+            for sx in (-0.5, 0.5):
+                for sy in (-0.5, 0.5):
+                    for sz in (-0.5, 0.5):
+                        out.append((b, (pos[0] + sx * size[0], pos[1] + sy * size[1], pos[2] + sz * size[2]), 0.0))
+        elif sh["type"] == "cylinder":
+            r, length = size[0], size[1]
+            for sz in (-1.0, 1.0):
+                out.append((b, (pos[0], pos[1], pos[2] + sz * max(0.5 * length - r, 0.0)), r))
+    return out
 
 
 class DynRef:
     """Holds model/physics/terrain structs and exposes the oracle entry points on numpy arrays."""
 
-    def __init__(self, flat_model, foot_names=("left_foot_link", "right_foot_link"), feet_edge_pos=None, phys=None, terrain=None):
+    def __init__(self, flat_model, foot_names=("left_foot_link", "right_foot_link"), feet_edge_pos=None, phys=None, terrain=None, body_contacts=True):
         m = RefModel()
         m.nb = flat_model.num_bodies
         assert m.nb == NB and flat_model.num_dofs == ND
@@ -120,6 +145,14 @@ class DynRef:
         for c in range(4):
             for a in range(3):
                 m.foot_corner[c][a] = float(feet_edge_pos[c][a])
+        sph = contact_spheres(flat_model, [m.foot_body[0], m.foot_body[1]]) if body_contacts else []
+        assert len(sph) <= 16
+        m.n_sph = len(sph)
+        for k, (b, c, r) in enumerate(sph):
+            m.sph_body[k] = b
+            m.sph_r[k] = r
+            for a in range(3):
+                m.sph_pos[k][a] = c[a]
         self.model = m
         ph = dict(DEFAULT_PHYS)
         ph.update(phys or {})
@@ -130,6 +163,7 @@ class DynRef:
         for k in ("contact_k", "contact_d", "contact_ramp", "friction_visc", "limit_k", "limit_d", "terrain_mu", "terrain_restitution"):
             setattr(p, k, float(ph[k]))
         p.clamp_qd = int(ph["clamp_qd"])
+        p.body_gate_height = float(ph["body_gate_height"])
         self.phys = p
         self.set_terrain(terrain)
 

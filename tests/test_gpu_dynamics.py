@@ -11,11 +11,13 @@ pytestmark = pytest.mark.gpu
 
 
 def _states(rng, m, n, contact):
+    """contact: False = airborne, True = standing height (sole contacts), "low" = trunk 0.15-0.5 m above the ground in any orientation (the
+    trunk box and the hip-yaw / shank cylinders touch as well)."""
     root = np.zeros((n, 13))
-    root[:, 2] = rng.uniform(0.55, 0.72, n) if contact else 5.0
+    root[:, 2] = (rng.uniform(0.15, 0.5, n) if contact == "low" else rng.uniform(0.55, 0.72, n)) if contact else 5.0
     root[:, :2] = rng.uniform(-1, 1, (n, 2))
     ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
-    ang = rng.uniform(0, 0.3 if contact else 1.0, n)
+    ang = rng.uniform(0, (3.0 if contact == "low" else 0.3) if contact else 1.0, n)
     root[:, 3:6] = ax * np.sin(ang / 2)[:, None]; root[:, 6] = np.cos(ang / 2)
     root[:, 7:13] = rng.normal(size=(n, 6)) * (0.3 if contact else 1.0)
     if contact:
@@ -28,14 +30,16 @@ def _states(rng, m, n, contact):
     return root, q, qd, tau, w
 
 
-@pytest.mark.parametrize("terrain,contact,tol", [("plane", False, 1e-4), ("plane", True, 5e-4), ("trimesh", True, 5e-4)])
+@pytest.mark.parametrize("terrain,contact,tol", [("plane", False, 1e-4), ("plane", True, 5e-4), ("trimesh", True, 5e-4), ("plane", "low", 1e-3),
+                                                 ("trimesh", "low", 1e-3)])
 def test_forward_dynamics_matches_oracle(flat_model, terrain, contact, tol):
     from booster_gym_amd.envs import T1
     from booster_gym_amd.utils.config import load_cfg
     from oracle.dyn_ref import DynRef
 
     n = 256
-    cfg = load_cfg("T1", {"env.num_envs": n, "terrain.type": terrain})
+    # rewards.terminate_height below the body-contact gate height switches the non-foot body contacts on (bg_env_cfg.body_gate_height)
+    cfg = load_cfg("T1", {"env.num_envs": n, "terrain.type": terrain, "rewards.terminate_height": 0.05})
     env = T1(cfg)
     tdict = None
     if terrain != "plane":

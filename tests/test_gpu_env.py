@@ -120,6 +120,42 @@ def test_step_matches_oracle(terrain, start_count):
     assert st[0] >= 6  # the forced time-outs were counted as finished episodes
 
 
+def test_body_contacts_collision_reward_and_contact_termination_match_oracle():
+    """Non-foot collision shapes (trunk box, hip-yaw / shank cylinders): robots are dropped lying at random orientations with the height
+    termination switched off, so that those shapes carry the load.  The `collision` reward term (number of penalised bodies with more than
+    1 N, t1.py:627-629) and termination on contact (`terminate_contacts_on: [Trunk]`, t1.py:553) must agree with the oracle."""
+    n = 128
+    cfg, env, ref = _make("plane", n, {"rewards.terminate_height": -1.0, "rewards.terminate_contacts_on": ["Trunk"], "rewards.terminate_vel": 1.0e9})
+    env.reset()
+    rng = np.random.default_rng(21)
+    root = env.root_states.cpu().numpy().astype(np.float64)
+    ax = rng.normal(size=(n, 3)); ax /= np.linalg.norm(ax, axis=1, keepdims=True)
+    ang = rng.uniform(0.5, 3.0, n)
+    root[:, 2] = rng.uniform(0.08, 0.35, n)
+    root[:, 3:6], root[:, 6] = ax * np.sin(ang / 2)[:, None], np.cos(ang / 2)
+    root[:, 7:] = 0.0
+    env.set_field("root_states", torch.tensor(root, dtype=torch.float32))
+    env.common_step_counter = 7
+    coll_seen, term_seen, flags_bad = 0, 0, 0
+    for s in range(4):
+        _sync_oracle(env, ref)
+        act = rng.uniform(-0.3, 0.3, (n, 12)).astype(np.float32)
+        obs, rew, done, extras = env.step(torch.tensor(act, device=env.device))
+        o_ref, p_ref, r_ref, d_ref, t_ref, terms_ref, derived = ref.step(act.astype(np.float64))
+        d_gpu = done.cpu().numpy()
+        flags_bad += int((d_gpu != d_ref).sum())
+        keep = d_gpu == d_ref
+        coll_gpu, coll_ref = extras["rew_terms"]["collision"].cpu().numpy(), terms_ref["collision"]
+        # a body whose force sits at the 1 N threshold may count on one side only: allow a few envs to differ by one body
+        diff = np.abs(coll_gpu - coll_ref)[keep]
+        assert (diff > 1e-6).mean() < 0.05, f"step {s}: collision term differs in {(diff > 1e-6).mean():.3f} of envs"
+        coll_seen += int((coll_ref < 0).sum()); term_seen += int(d_ref.sum())
+        _close(env.root_states.cpu().numpy()[keep], ref.root[keep], 5e-3, frac=0.9, what=f"step {s} root")
+    assert coll_seen > n // 4 and term_seen > n // 10, (coll_seen, term_seen)  # the shapes were exercised
+    assert flags_bad <= n * 4 * 3 // 100, flags_bad
+    assert env.episode_stats(reset=False).cpu().numpy()[-1] == 0
+
+
 FP16_FIELDS = ["dof_pos", "dof_vel", "last_dof_targets", "actions", "last_actions", "last_dof_vel", "last_root_vel", "commands", "gait_frequency",
                "gait_process", "filtered_lin_vel", "filtered_ang_vel", "pushing"]
 

@@ -19,14 +19,14 @@ def _make(n, terrain="plane", **over):
     from booster_gym_amd.envs.gym_calls import GymCalls
     from booster_gym_amd.utils.config import load_cfg
 
-    o = {"env.num_envs": n, "terrain.type": terrain}
+    o = {"env.num_envs": n, "terrain.type": terrain, "rewards.terminate_height": 0.05}  # below the body-contact gate: those contacts are on
     o.update(over)
     cfg = load_cfg("T1", o)
     env = T1(cfg)
     return cfg, env, GymCalls(env)
 
 
-@pytest.mark.parametrize("contact,tol", [(False, 1e-4), (True, 5e-4)])
+@pytest.mark.parametrize("contact,tol", [(False, 1e-4), (True, 5e-4), ("low", 1e-3)])
 def test_simulate_matches_oracle_step(flat_model, contact, tol):
     from oracle.dyn_ref import DynRef
 
@@ -87,6 +87,8 @@ def test_simulate_matches_oracle_step(flat_model, contact, tol):
     assert worst[0] < tol and worst[1] < tol, worst
     if contact:
         assert ncontact > n // 4
+    if contact == "low":  # the non-foot rows of the contact tensor (trunk, hip-yaw, shank) were exercised
+        assert (np.abs(got1[2][:, [0, 3, 4, 9, 10]]).max(axis=(1, 2)) > 1.0).mean() > 0.3
 
 
 def test_decimation_loop_on_gym_calls_equals_fused_step(flat_model):

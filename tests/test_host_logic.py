@@ -258,11 +258,12 @@ def test_product_dynamics_header_matches_oracle(harness, flat_model):
 
     class ModelDev(C.Structure):
         _fields_ = [("pos", C.c_float * 3 * 13), ("mass", C.c_float * 13), ("com", C.c_float * 3 * 13), ("inertia", C.c_float * 6 * 13), ("q_lo", C.c_float * 12),
-                    ("q_hi", C.c_float * 12), ("qd_max", C.c_float * 12), ("tau_lim", C.c_float * 12), ("corner", C.c_float * 3 * 4)]
+                    ("q_hi", C.c_float * 12), ("qd_max", C.c_float * 12), ("tau_lim", C.c_float * 12), ("corner", C.c_float * 3 * 4),
+                    ("sph_n", C.c_int), ("sph_first", C.c_int * 13), ("sph_cnt", C.c_int * 13), ("sph_pos", C.c_float * 3 * 16), ("sph_r", C.c_float * 16)]
 
     class Cfg(C.Structure):
         _fields_ = [("dt", C.c_float), ("g", C.c_float * 3)] + [(k, C.c_float) for k in ("contact_k", "contact_d", "contact_ramp", "friction_visc", "limit_k", "limit_d",
-                                                                                      "terrain_mu", "terrain_restitution")] + [("clamp_qd", C.c_int)]
+                                                                                      "terrain_mu", "terrain_restitution")] + [("clamp_qd", C.c_int), ("body_gate", C.c_float)]
 
     class Terr(C.Structure):
         _fields_ = [("type", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("border_px", C.c_int), ("inv_hscale", C.c_float), ("vscale", C.c_float), ("hf", C.c_void_p)]
@@ -280,23 +281,36 @@ def test_product_dynamics_header_matches_oracle(harness, flat_model):
     for k in range(4):
         for a in range(3):
             md.corner[k][a] = corners[k][a]
-    cfg = Cfg(); cfg.dt = DEFAULT_PHYS["dt"]; cfg.clamp_qd = 1
+    sph = m.contact_spheres(exclude_bodies=[6, 12])  # the product's own derivation of the contact spheres (utils/urdf.py)
+    md.sph_n = len(sph)
+    for k, (b, c, r) in enumerate(sph):
+        if md.sph_cnt[b] == 0:
+            md.sph_first[b] = k
+        md.sph_cnt[b] += 1
+        md.sph_r[k] = r
+        for a in range(3):
+            md.sph_pos[k][a] = c[a]
+    assert len(sph) == 16 and [md.sph_cnt[b] for b in (0, 3, 4, 9, 10)] == [8, 2, 2, 2, 2]
+    cfg = Cfg(); cfg.dt = DEFAULT_PHYS["dt"]; cfg.clamp_qd = 1; cfg.body_gate = DEFAULT_PHYS["body_gate_height"]
     for a in range(3):
         cfg.g[a] = DEFAULT_PHYS["g"][a]
     for k in ("contact_k", "contact_d", "contact_ramp", "friction_visc", "limit_k", "limit_d", "terrain_mu", "terrain_restitution"):
         setattr(cfg, k, DEFAULT_PHYS[k])
     rng = np.random.default_rng(1)
     hf = rng.integers(-10, 10, size=(60, 60)).astype(np.int16)
-    for terrain, contact, tol in ((None, False, 2e-5), (None, True, 5e-4), (dict(height_field_raw=hf, hscale=0.1, vscale=0.005, border_px=30), True, 5e-4)):
+    # contact: False = airborne, True = standing height (sole contacts), "low" = trunk 0.15-0.5 m above the ground in any orientation, so that
+    # the trunk box and the hip-yaw / shank cylinders touch (explicit sphere contacts) as well
+    for terrain, contact, tol in ((None, False, 2e-5), (None, True, 5e-4), (dict(height_field_raw=hf, hscale=0.1, vscale=0.005, border_px=30), True, 5e-4),
+                                  (None, "low", 1e-3), (dict(height_field_raw=hf, hscale=0.1, vscale=0.005, border_px=30), "low", 1e-3)):
         d = DynRef(m, terrain=terrain)
         t = Terr()
         if terrain is not None:
             t.type, t.rows, t.cols, t.border_px, t.inv_hscale, t.vscale, t.hf = 1, 60, 60, 30, 10.0, 0.005, hf.ctypes.data
-        worst, ncontact = 0.0, 0
+        worst, ncontact, nbody = 0.0, 0, 0
         for _ in range(150):
-            root = np.zeros(13); root[2] = rng.uniform(0.55, 0.72) if contact else 5.0
+            root = np.zeros(13); root[2] = (rng.uniform(0.15, 0.5) if contact == "low" else rng.uniform(0.55, 0.72)) if contact else 5.0
             root[:2] = rng.uniform(-1, 1, 2)
-            ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 0.3)
+            ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 3.0 if contact == "low" else 0.3)
             root[3:6], root[6] = ax * np.sin(ang / 2), np.cos(ang / 2)
             root[7:13] = rng.normal(size=6) * (0.3 if contact else 1.0)
             q = (np.array([-0.2, 0, 0, 0.4, -0.25, 0] * 2) + rng.normal(size=12) * 0.1) if contact else rng.uniform(m.dof_lower - 0.05, m.dof_upper + 0.05)
@@ -305,14 +319,18 @@ def test_product_dynamics_header_matches_oracle(harness, flat_model):
             fm = np.array([rng.uniform(0.1, 2), rng.uniform(0.5, 1.5), rng.uniform(0.1, 0.9)] * 2)
             f32 = lambda a: np.ascontiguousarray(a, dtype=np.float32)
             arrs = [f32(ms), f32(co.reshape(39)), f32(fm), f32(root), f32(q), f32(qd), f32(tau), f32(w)]
-            qa, cf32 = np.zeros(18, np.float32), np.zeros(6, np.float32)
+            qa, cf32, bcf = np.zeros(18, np.float32), np.zeros(6, np.float32), np.zeros((13, 3), np.float32)
             p = lambda a: a.ctypes.data_as(C.c_void_p)
-            hh.hh_forward(C.byref(md), C.byref(cfg), C.byref(t), *[p(a) for a in arrs], p(qa), p(cf32), 0)
+            hh.hh_forward(C.byref(md), C.byref(cfg), C.byref(t), *[p(a) for a in arrs], p(qa), p(cf32), 0, p(bcf))
             qacc, cf = d.forward(arrs[3], arrs[4], arrs[5], arrs[6], base_wrench=arrs[7], mass_scale=arrs[0], com_off=arrs[1].reshape(13, 3), foot_mat=arrs[2])
             worst = max(worst, np.abs(qa - qacc).max() / max(1.0, np.abs(qacc).max()))
             ncontact += int(np.abs(cf).max() > 0)
+            body_rows = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11]
+            nbody += int(np.abs(cf[body_rows]).max() > 0)
+            assert np.abs(bcf[body_rows] - cf[body_rows]).max() <= 2e-3 * max(1.0, np.abs(cf).max())
         assert worst < tol, (terrain is not None, contact, worst)
-        assert (ncontact > 50) == contact
+        assert (ncontact > 50) == bool(contact)
+        assert (nbody > 30) == (contact == "low"), nbody
 
 
 # ------------------------------------------------------------------ data parallel under gloo, world_size 2

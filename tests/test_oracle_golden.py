@@ -254,6 +254,31 @@ def test_body_wrench_semantics(dyn, flat_model):
     assert np.allclose(r[7:], root[7:] + dyn.phys.dt * a1[:6], atol=1e-12) and np.allclose(v, np.clip(qd + dyn.phys.dt * a1[6:], -lim, lim), atol=1e-12)
 
 
+def test_body_contacts_enter_newtons_law(dyn, flat_model):
+    """Non-foot body contacts (trunk box corners, hip-yaw / shank cylinder spheres): for a robot at rest in a random low pose the sum of all
+    reported contact forces plus gravity equals the rate of change of the total linear momentum (sum of m_i * a_com_i), and the spheres are
+    only evaluated below the gate height."""
+    m, rng, seen = flat_model, np.random.default_rng(4), 0
+    g = np.array([0.0, 0.0, -9.81])
+    for _ in range(60):
+        root = np.zeros(13); root[2] = rng.uniform(0.1, 0.4)
+        ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 3.0)
+        root[3:6], root[6] = ax * np.sin(ang / 2), np.cos(ang / 2)
+        q = rng.uniform(m.dof_lower, m.dof_upper)
+        tau = rng.uniform(-m.dof_effort, m.dof_effort) * 0.2
+        qacc, cf, ab = dyn.forward(root, q, np.zeros(12), tau, want_body_acc=True)
+        pos, R = dyn.body_poses(root, q)
+        dp = sum(m.mass[b] * (R[b] @ (ab[b, 3:] + np.cross(ab[b, :3], m.com[b]))) for b in range(13))  # velocities are zero: a_com = a + alpha x c
+        assert np.abs(dp - (cf.sum(axis=0) + m.mass.sum() * g)).max() < 1e-7 * max(1.0, np.abs(cf).max())
+        seen += int(np.abs(cf[[0, 3, 4, 9, 10]]).max() > 1.0)
+        assert np.abs(cf[[1, 2, 5, 7, 8, 11]]).max() == 0.0  # bodies without collision shapes
+    assert seen > 30
+    root = np.zeros(13); root[2], root[6] = dyn.phys.body_gate_height + 0.01, 1.0
+    q = np.zeros(12); q[[0, 6]] = -1.5; q[[3, 9]] = 2.3  # legs folded forward: a shank sphere would dip under the ground plane
+    _, cf = dyn.forward(root, q, np.zeros(12), np.zeros(12))
+    assert np.abs(cf[[0, 3, 4, 9, 10]]).max() == 0.0  # above the gate height the spheres are not evaluated
+
+
 def test_free_fall(dyn):
     root = np.zeros(13); root[2], root[6] = 5.0, 1.0
     qacc, cf = dyn.forward(root, np.zeros(12), np.zeros(12), np.zeros(12))
