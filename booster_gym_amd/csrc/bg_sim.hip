@@ -86,7 +86,7 @@ __device__ __forceinline__ void copy_out_rows(const StepOut& out, int e0, int ro
     }
 }
 
-template <bool H16>
+template <bool H16, bool GATED>
 __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __restrict__ act, uint32_t step, int mode, StepOut out,
                                                       unsigned* __restrict__ lowmask) {
     __shared__ float s_obs[ENVS_PER_BLOCK * BG_NUM_OBS];
@@ -103,7 +103,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __r
     LdsSink sink{s_obs, s_priv, lane >> 1};
     // decided once per env step from the trunk height at its start; both lanes of an env agree
     const V3 p0 = v3(E.f[(size_t)(F_ROOT + 0) * E.n + e], E.f[(size_t)(F_ROOT + 1) * E.n + e], E.f[(size_t)(F_ROOT + 2) * E.n + e]);
-    const bool low = mode == 0 && lowmask && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, p0);
+    const bool low = GATED && mode == 0 && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, p0);
     if (low) { if (valid && !(lane & 1)) atomicOr(&s_low, 1u << (lane >> 1)); }
     else env_step_lane<DppSwap, LdsSink, H16, false>(E, x, sink, e, lane & 1, valid, act, step, mode, out);
     __syncthreads();
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __r
     } else {
         copy_out_rows(out, e0, rows, ~lowm, s_obs, s_priv);
     }
-    if (lowmask && lane == 0) lowmask[blockIdx.x] = lowm;
+    if (GATED && lane == 0) lowmask[blockIdx.x] = lowm;
 }
 
 // kernel B: the envs kernel A left out (trunk low at the start of the step), with the non-foot body contacts
@@ -190,25 +190,30 @@ __device__ __forceinline__ void forward_dynamics_lane(const EnvDev& E, int e, bo
     for (int i = 0; i < LEG_LINKS; i++) o[6 + leg * 6 + i] = qdd[i];
     for (int a = 0; a < 3; a++) E.f[(size_t)(F_CONTACT + 3 * leg + a) * n + e] = fw.e[a];
 }
+// GATED = false: no env of this launch can need the body contacts (lowmask is null): the plain kernel.  GATED = true: kernel A of the
+// two-kernel scheme (see env_step_kernel).
+template <bool GATED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
                                                               const float* __restrict__ qd, const float* __restrict__ tau,
                                                               const float* __restrict__ wrench, float* __restrict__ qacc,
                                                               unsigned* __restrict__ lowmask) {
     __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
-    __shared__ unsigned s_low;
     const int lane = threadIdx.x;
     int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
     const bool valid = e < E.n;
     if (!valid) e = E.n - 1;
-    if (lowmask) {
+    if constexpr (!GATED) {
+        forward_dynamics_lane<false>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+    } else {
+        __shared__ unsigned s_low;
         if (lane == 0) s_low = 0u;
         __syncthreads();
-    }
-    const float* r = root + (size_t)e * 13;
-    const bool low = lowmask && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]));
-    if (low) { if (valid && !(lane & 1)) atomicOr(&s_low, 1u << (lane >> 1)); }
-    else forward_dynamics_lane<false>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
-    if (lowmask) {
+        const float* r = root + (size_t)e * 13;
+        if (body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]))) {
+            if (valid && !(lane & 1)) atomicOr(&s_low, 1u << (lane >> 1));
+        } else {
+            forward_dynamics_lane<false>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+        }
         __syncthreads();
         if (lane == 0) lowmask[blockIdx.x] = s_low;
     }
@@ -591,8 +596,13 @@ static int launch_step(bg_env* e, const float* actions, int mode, const StepOut&
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
     hipStream_t st = (hipStream_t)stream;
     const uint32_t cnt = (uint32_t)e->step_count;
-    if (e->h) hipLaunchKernelGGL(env_step_kernel<true>, grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
-    else hipLaunchKernelGGL(env_step_kernel<false>, grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
+    if (e->lowmask) {
+        if (e->h) hipLaunchKernelGGL((env_step_kernel<true, true>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
+        else hipLaunchKernelGGL((env_step_kernel<false, true>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
+    } else {
+        if (e->h) hipLaunchKernelGGL((env_step_kernel<true, false>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, (unsigned*)nullptr);
+        else hipLaunchKernelGGL((env_step_kernel<false, false>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, (unsigned*)nullptr);
+    }
     if (e->lowmask && mode == 0) {  // kernel B: the envs whose trunk was low at the start of the step (usually none)
         const int nb = (int)grid.x;
         dim3 gb(nb < BODY_GRID ? nb : BODY_GRID);
@@ -716,8 +726,9 @@ extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float
                                        float* qacc, void* stream) {
     if (!e || !root || !q || !qd || !tau || !qacc) return fail(-1, "bg_env_forward_dynamics: null argument");
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
-    hipLaunchKernelGGL(forward_dynamics_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->lowmask);
-    if (e->lowmask) {
+    if (!e->lowmask) hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, (unsigned*)nullptr);
+    else {
+        hipLaunchKernelGGL(forward_dynamics_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->lowmask);
         const int nb = (int)grid.x;
         hipLaunchKernelGGL(forward_dynamics_body_kernel, dim3(nb < BODY_GRID ? nb : BODY_GRID), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
                            wrench, qacc, (const unsigned*)e->lowmask, nb);
