@@ -165,6 +165,38 @@ def test_fp16_state_rollout_tracks_the_fp32_rollout():
     assert abs(float(s32[0]) - float(s16[0])) <= 0.02 * n + 5  # finished episodes
 
 
+def test_fallen_robots_come_to_rest_on_their_collision_shapes():
+    """Height termination off: robots dropped from 1 m at random orientations (1 to 3 rad from upright) must come to rest ON the ground, carried
+    by the trunk box / leg cylinders (the second kernel of the two-kernel scheme), not sink through it.  With contact.body_contacts: false only
+    the soles collide and the same robots end up with the trunk far below the ground plane."""
+    n = 2048
+    over = {"rewards.terminate_height": -10.0, "rewards.terminate_vel": 1.0e9, "rewards.episode_length_s": 1000.0}
+    lowest = {}
+    for body_contacts in (True, False):
+        env = _env(n, "plane", dict(over, **{"contact.body_contacts": body_contacts}))
+        env.reset()
+        g = torch.Generator(device="cpu").manual_seed(3)
+        root = env.root_states.clone().cpu()
+        ax = torch.randn(n, 3, generator=g); ax /= ax.norm(dim=1, keepdim=True)
+        ang = torch.rand(n, generator=g) * 2.0 + 1.0
+        root[:, 2] = 1.0
+        root[:, 3:6], root[:, 6] = ax * torch.sin(ang / 2)[:, None], torch.cos(ang / 2)
+        root[:, 7:] = 0.0
+        env.set_field("root_states", root)
+        act = torch.zeros(n, 12, device=env.device)
+        for _ in range(300):
+            obs, rew, done, extras = env.step(act)
+        rs = env.root_states
+        assert torch.isfinite(rs).all()
+        lowest[body_contacts] = rs[:, 2].clone()
+        if body_contacts:
+            assert float(env.episode_stats(reset=False)[-1]) == 0
+            assert float(rs[:, 2].min()) > 0.005, "a trunk origin sank to the ground plane"
+            assert float(rs[:, 7:].abs().mean()) < 0.1, "the fallen robots did not come to rest"
+            assert float((extras["rew_terms"]["collision"] < 0).float().mean()) > 0.5  # most of them lie on penalised bodies
+    assert float((lowest[False] < 0.0).float().mean()) > 0.5 and float((lowest[True] < 0.0).float().mean()) == 0.0
+
+
 def test_isaac_layout_state_views_through_the_abi():
     """bg_env_get_state / bg_env_set_state: the Isaac Gym tensor layouts the reference's task code assumes (t1.py:215-220):
     root [N][13], dof [N][12][2] interleaved (pos, vel), net contact force [N][13][3] (only the feet rows 6 and 12 can be non-zero here)."""
