@@ -90,10 +90,19 @@ def cpu_baseline(n_sample=2048):
     """CPU restatement baseline ("port"), timed in a child process that never touches the GPU (oracle/cpu_baseline.py)."""
     import subprocess
 
-    r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(n_sample)], cwd=ROOT, capture_output=True, text=True, timeout=600)
-    if r.returncode != 0:
-        raise RuntimeError(r.stderr[-400:])
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    def run(n, threads=None):
+        env = dict(os.environ)
+        if threads:
+            env["BG_CPU_THREADS"] = str(threads)
+        r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(n)], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        if r.returncode != 0:
+            raise RuntimeError(r.stderr[-400:])
+        return json.loads(r.stdout.strip().splitlines()[-1])
+
+    out = run(n_sample)  # all cores of this GPU's share of the host (SURVEY section 8d: report single-thread and all-core)
+    one = run(max(128, n_sample // 16), threads=1)
+    out["single_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
+    return out
 
 
 def main():
