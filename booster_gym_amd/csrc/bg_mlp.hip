@@ -73,7 +73,7 @@ __device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, 
 // NB = number of 128-column blocks of the layer (1, 2; 0 = any): it only gives every layer shape its own kernel symbol, so that a profiler's
 // per-kernel average is the average of ONE shape (bench.py's roofline line is checked against the rocprofv3 summary in profiles/).
 template <int K, int EPI, int NB>
-__global__ __launch_bounds__(256, 2) void mlp_fwd_kernel(int M, int ldy, const float* __restrict__ X, const float* __restrict__ Wfull,
+__global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const float* __restrict__ X, const float* __restrict__ Wfull,
                                                          const float* __restrict__ biasfull, float* __restrict__ Yfull,
                                                          const float* __restrict__ auxfull, float* __restrict__ colpart) {
     constexpr int N = 128;
