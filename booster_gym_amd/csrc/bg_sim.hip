@@ -464,24 +464,15 @@ static EnvDev env_dev(const bg_env* e) {
     return E;
 }
 
-extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_env** out) {
-    if (!cfg || !model || !out) return fail(-1, "bg_env_create: null argument");
-    if (cfg->num_envs <= 0) return fail(-1, "bg_env_create: num_envs must be positive");
-    if (cfg->decimation <= 0 || !(cfg->sim_dt > 0.f)) return fail(-1, "bg_env_create: bad sim dt / decimation");
-    int ndev = 0;
-    hipError_t de = hipGetDeviceCount(&ndev);
-    if (de != hipSuccess || ndev == 0) return fail(-3, "bg_env_create: no HIP device available (this library has no CPU path)");
-    if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "bg_env_create: device ordinal out of range");
-    HIP_OK(hipSetDevice(cfg->device));
-    bg_env* e = new bg_env;
+extern "C" void bg_env_destroy(bg_env* e);
+// allocations and uploads of bg_env_create; on failure the caller destroys whatever was allocated so far
+static int env_create_fill(bg_env* e, const bg_env_cfg* cfg, const bg_model* model) {
     e->cfg = *cfg; e->model = model->desc; e->n = cfg->num_envs;
     const size_t n = (size_t)e->n;
     HIP_OK(hipMalloc(&e->f, sizeof(float) * n * F_COUNT));
     HIP_OK(hipMalloc(&e->i, sizeof(int32_t) * n * I_COUNT));
     HIP_OK(hipMalloc(&e->stats, sizeof(float) * STATS_COUNT));
     HIP_OK(hipMalloc(&e->model_dev, sizeof(ModelDev)));
-    if (cfg->lin_vel_levels < 0 || cfg->ang_vel_levels < 0 || cfg->lin_vel_levels > 64 || cfg->ang_vel_levels > 64)
-        return fail(-1, "bg_env_create: curriculum levels out of range");
     e->curr_cells = (2 * cfg->lin_vel_levels + 1) * (2 * cfg->ang_vel_levels + 1);
     HIP_OK(hipMalloc(&e->curr, sizeof(float) * e->curr_cells));
     HIP_OK(hipMalloc(&e->curr_read, sizeof(float) * e->curr_cells));
@@ -537,6 +528,26 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
         std::vector<bg_half_bits> hh(n * FP16_SLAB_FIELDS, 0);
         for (size_t k = 0; k < n; k++) hh[(size_t)(F_ROOT + 6) * n + k] = 0x3C00;  // 1.0
         HIP_OK(hipMemcpy(e->h, hh.data(), sizeof(bg_half_bits) * hh.size(), hipMemcpyHostToDevice));
+    }
+    return 0;
+}
+
+extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_env** out) {
+    if (!cfg || !model || !out) return fail(-1, "bg_env_create: null argument");
+    if (cfg->num_envs <= 0) return fail(-1, "bg_env_create: num_envs must be positive");
+    if (cfg->decimation <= 0 || !(cfg->sim_dt > 0.f)) return fail(-1, "bg_env_create: bad sim dt / decimation");
+    if (cfg->lin_vel_levels < 0 || cfg->ang_vel_levels < 0 || cfg->lin_vel_levels > 64 || cfg->ang_vel_levels > 64)
+        return fail(-1, "bg_env_create: curriculum levels out of range");
+    int ndev = 0;
+    hipError_t de = hipGetDeviceCount(&ndev);
+    if (de != hipSuccess || ndev == 0) return fail(-3, "bg_env_create: no HIP device available (this library has no CPU path)");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(-1, "bg_env_create: device ordinal out of range");
+    HIP_OK(hipSetDevice(cfg->device));
+    bg_env* e = new bg_env;
+    const int rc = env_create_fill(e, cfg, model);
+    if (rc != 0) {  // the message of the failing call is already set
+        bg_env_destroy(e);
+        return rc;
     }
     *out = e;
     return 0;
