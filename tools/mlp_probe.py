@@ -1,3 +1,4 @@
+"""Fused fp32-MFMA layer kernels against torch (hipBLASLt) at the training shapes: forward Linear+bias+ELU and backward Linear^T+ELU'+bias-grad, HIP events."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch

@@ -1,3 +1,4 @@
+"""Launch time of the fused forward layer (256 x 256) over M, in units of dispatch rounds: where the per-round prologue / epilogue overhead shows."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
