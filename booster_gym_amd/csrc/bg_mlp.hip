@@ -22,6 +22,19 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 // exp(x) - 1 through v_exp_f32: absolute error ~1e-7 on (-1, 0], far below fp32 activation noise; expm1f costs ~20 VALU per element
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
+// 4 x 4 transpose across the 4 lanes of a quad: in: lane c holds (v0..v3) = column c of a block M[k][c]; out: lane c holds row c, M[c][0..3].
+__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int c) {
+    const bool odd = c & 1, hi = c & 2;
+    // stage 1 (lanes c ^ 1): swap the off-diagonal elements of the 2 x 2 blocks (v0, v1) and (v2, v3)
+    float s01 = dpp_xor1(odd ? v0 : v1), s23 = dpp_xor1(odd ? v2 : v3);
+    if (odd) { v0 = s01; v2 = s23; } else { v1 = s01; v3 = s23; }
+    // stage 2 (lanes c ^ 2): swap the off-diagonal 2 x 2 blocks: (v0, v1) of the upper lanes with (v2, v3) of the lower ones
+    float t02 = dpp_xor2(hi ? v0 : v2), t13 = dpp_xor2(hi ? v1 : v3);
+    if (hi) { v0 = t02; v1 = t13; } else { v2 = t02; v3 = t13; }
+}
+
 constexpr int FW_BM = 128;   // rows per workgroup (4 waves x 32 rows)
 constexpr int FW_KC = 32;    // k-chunk staged in LDS
 constexpr int FW_LDW = 36;   // LDS row stride (floats): 16-byte aligned rows, spreads the 16-byte reads over the banks
@@ -92,7 +105,7 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
 #pragma unroll
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     f32x4 wA[LD4], wB[LD4], aA[4], aB[4];
-    float auxv[EPI == 2 ? NT : 1][16];
+    f32x4 auxq[EPI == 2 ? NT : 1][4];  // elu' operand of the backward epilogue in the TRANSPOSED (row, 4 columns) layout of the stores
     load_w_chunk<K, LD4>(wA, W, 0);
     load_a_chunk(aA, xrow, 0);
     store_w_chunk<LD4>(wA, sW[0]);
@@ -117,9 +130,9 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int r = 0; r < 16; r++) {
-                    const int rr = rb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    auxv[t][r] = auxp[(size_t)(rr < M ? rr : M - 1) * ldy + t * 32 + i];
+                for (int g = 0; g < 4; g++) {
+                    const int rr = rb + 8 * g + 4 * h + (lane & 3);
+                    auxq[t][g] = *reinterpret_cast<const f32x4*>(auxp + (size_t)(rr < M ? rr : M - 1) * ldy + t * 32 + (i & ~3));
                 }
         }
         mfma_chunk<NT>(acc, aB, sw1);
@@ -129,35 +142,52 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
     // epilogue: C layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int rbase = blockIdx.x * FW_BM + wave * 32;
     if constexpr (EPI <= 1) {
+        // The C layout gives a lane ONE column and 4 consecutive rows per register group; a 4 x 4 transpose inside every lane quad (two DPP
+        // exchange stages) turns that into one row and 4 consecutive columns, so that the tile leaves as 16 wide stores of 16 bytes per lane
+        // (8 full 128-byte lines per instruction) instead of 64 dword stores: the store tail of these kernels is issue-bound.
+        const int c4 = lane & 3;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
             const float bv = bias[t * 32 + i];
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rr = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float v = acc[t][r] + bv;
-                if (EPI == 1) v = elu_f(v);
-                if (rr < M) Y[(size_t)rr * ldy + t * 32 + i] = v;
+            for (int g = 0; g < 4; g++) {
+                float v0 = acc[t][4 * g] + bv, v1 = acc[t][4 * g + 1] + bv, v2 = acc[t][4 * g + 2] + bv, v3 = acc[t][4 * g + 3] + bv;
+                if (EPI == 1) { v0 = elu_f(v0); v1 = elu_f(v1); v2 = elu_f(v2); v3 = elu_f(v3); }
+                quad_transpose(v0, v1, v2, v3, c4);
+                const int rr = rbase + 8 * g + 4 * h + c4;
+                if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
             }
         }
     } else {
         float* csum = &sW[0][0];  // reuse the weight staging buffer: [4 waves][128 columns]
         __syncthreads();
+        const int c4 = lane & 3;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            float cs = 0.f;
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // this lane's row contributions to columns t * 32 + (i & ~3) + 0..3
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int rr = rbase + (r & 3) + 8 * (r >> 2) + 4 * h;
+            for (int g = 0; g < 4; g++) {
+                float v0 = acc[t][4 * g], v1 = acc[t][4 * g + 1], v2 = acc[t][4 * g + 2], v3 = acc[t][4 * g + 3];
+                quad_transpose(v0, v1, v2, v3, c4);
+                const f32x4 a = auxq[t][g];
+                const int rr = rbase + 8 * g + 4 * h + c4;
                 if (rr < M) {
-                    const float a = auxv[t][r];
-                    const float v = acc[t][r] * (a > 0.f ? 1.0f : a + 1.0f);
-                    Y[(size_t)rr * ldy + t * 32 + i] = v;
+                    const f32x4 v = {v0 * (a.x > 0.f ? 1.0f : a.x + 1.0f), v1 * (a.y > 0.f ? 1.0f : a.y + 1.0f),
+                                     v2 * (a.z > 0.f ? 1.0f : a.z + 1.0f), v3 * (a.w > 0.f ? 1.0f : a.w + 1.0f)};
+                    *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = v;
                     cs += v;
                 }
             }
-            cs += __shfl_xor(cs, 32);  // the two lane halves hold different rows of the same column
-            if (h == 0) csum[wave * N + t * 32 + i] = cs;
+            // rows live in the 4 lanes of a quad and in the two lane halves: add them up, lane (c4 == 0, h == 0) of every quad writes 4 columns
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float x = cs[k];
+                x += dpp_xor1(x);
+                x += dpp_xor2(x);
+                x += __shfl_xor(x, 32);
+                cs[k] = x;
+            }
+            if (h == 0 && c4 == 0) *reinterpret_cast<f32x4*>(&csum[wave * N + t * 32 + i]) = cs;
         }
         __syncthreads();
         if (threadIdx.x < N)
