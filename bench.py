@@ -228,7 +228,7 @@ def main():
         gemm_flop = 2.0 * rows_g * kg * ng
         gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_d_env_pmc.json")
+        pmc = os.path.join(ROOT, "profiles", "r01_e_env_pmc.json")
         if N == 4096 and os.path.isfile(pmc):  # PMC counters are collected offline by tools/profile.sh (separate rocprofv3 passes)
             k = json.load(open(pmc))["kernels"]["env_step_kernel"]
             traffic = (k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
