@@ -230,8 +230,12 @@ def main():
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "r01_e_env_pmc.json")
         if N == 4096 and os.path.isfile(pmc):  # PMC counters are collected offline by tools/profile.sh (separate rocprofv3 passes)
-            k = json.load(open(pmc))["kernels"]["env_step_kernel"]
-            traffic = (k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
+            try:
+                ks = json.load(open(pmc))["kernels"]
+                k = next(v for name, v in ks.items() if name.startswith("env_step_kernel"))  # "env_step_kernel<false, false>": the plain instantiation
+                traffic = (k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
+            except (StopIteration, KeyError, ValueError):
+                traffic = None
         out = {
             "metric": "env-steps/sec (whole node), PPO rollout+update, T1 4096 envs/GPU",
             "value": world * N * T * args.steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
