@@ -42,7 +42,7 @@ class MLPTrainer:
     def _fusable(cls, k_in, n_out):
         return cls.FUSED and k_in in (64, 128, 256) and n_out % 128 == 0
 
-    def __init__(self, seq, max_split=int(__import__("os").environ.get("BG_SPLIT", "32"))):
+    def __init__(self, seq, max_split=32):
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
         self.max_split = max_split
         self.x = None
