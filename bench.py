@@ -105,6 +105,27 @@ def cpu_baseline(n_sample=2048):
     return out
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(n, argv):
+    """Start `python -m torch.distributed.run --nproc-per-node n bench.py <argv>` as a child process (one rank per GPU over RCCL) and relay
+    its stdout (rank 0's JSON line), stderr and exit status.  The launcher itself never initialises the GPU."""
+    import subprocess
+
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: the only mode the host driver supports (RCCL needs it)
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -118,11 +139,14 @@ def main():
     args = ap.parse_args()
 
     t_start = time.perf_counter()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: this process becomes the launcher.  Nothing above has touched the GPU (importing torch
+        # and loading the .so do not), the ranks are CHILD processes and this one only relays their output and exit status.
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:]))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("bench.py --gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        raise SystemExit(f"bench.py --gpus {args.gpus} does not match WORLD_SIZE={world} of the launcher")
     import torch.distributed as dist
 
     from booster_gym_amd.utils.config import load_cfg
@@ -163,12 +187,14 @@ def main():
 
     runner.env.step_to = timed_step_to
     runner._critic_tr.timed_layer = 1  # critic 256 -> 256 hidden layer: the single largest kernel of the update
+    if world > 1:
+        runner.dp.timed_events = []  # HIP events around the gradient-bucket all-reduce of every mini-epoch
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         r0, r1, r2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
         r0.record(); runner.rollout(); r1.record(); runner.update(); r2.record()
-        runner.buffer["obses"][0].copy_(runner.buffer["obses"][T]); runner.buffer["privileged_obses"][0].copy_(runner.buffer["privileged_obses"][T])
+        runner.buffer.roll()
         phase_events.append((r0, r1, r2))
     barrier()
     wall = time.perf_counter() - t0
@@ -182,6 +208,9 @@ def main():
         step_ms = sum(a.elapsed_time(b) for a, b in step_events) / max(len(step_events), 1)
         roll_ms = sum(a.elapsed_time(b) for a, b, _ in phase_events) / len(phase_events)
         upd_ms = sum(b.elapsed_time(c) for _, b, c in phase_events) / len(phase_events)
+        # gradient-bucket all-reduce (712 kB, SURVEY 8e exchange 2), per mini-epoch, rank 0's view: collective + waiting for the slowest rank
+        ar = runner.dp.timed_events or []
+        ar_ms = sum(a.elapsed_time(b) for a, b in ar) / len(ar) if ar else 0.0
         env_bytes = N * ENV_STEP_BYTES
         sim_gbs = env_bytes / (step_ms * 1e-3) / 1e9
         flops = gemm_flops_per_iteration(N, T, E)
@@ -244,7 +273,7 @@ def main():
             "config": {"workload": f"T1 {args.terrain} terrain, {N} envs/GPU, horizon {T}, {E} mini-epochs, full batch (BASELINE.json configs[1])",
                        "envs_per_gpu": N, "parallelism": f"dp{world}"},
             "ppo_iters_per_s": args.steps / wall,
-            "phase_ms": {"rollout": roll_ms, "update": upd_ms},
+            "phase_ms": {"rollout": roll_ms, "update": upd_ms, "all_reduce_ms": ar_ms},
             "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF, "traffic": None,
                          "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop,
                          "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,

@@ -21,6 +21,7 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = os.environ.get("BG_DIST_BACKEND", backend or "nccl")
         self.owns_group = False
+        self.timed_events = None
         # device of this rank: LOCAL_RANK, unless the launcher already narrowed the visible devices to one per process
         # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), or a test shares one GPU between ranks (BG_LOCAL_DEVICE)
         ndev = torch.cuda.device_count()
@@ -43,11 +44,36 @@ class DataParallel:
         return t
 
     def average_(self, t):
-        """In-place mean over ranks: the flat gradient bucket."""
+        """In-place mean over ranks: the flat gradient bucket.  With `timed_events` set to a list (bench.py) every call is bracketed by
+        events on the current stream: the span is the collective plus the wait for the slowest rank to arrive."""
         if self.active:
+            ev = self.timed_events
+            if ev is not None and t.is_cuda:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             t.mul_(1.0 / self.world_size)
+            if ev is not None and t.is_cuda:
+                e1.record()
+                ev.append((e0, e1))
         return t
+
+    def sync_grid(self, cur, last):
+        """Command-curriculum grid under data parallelism (reference envs/t1.py:404-413 on one process): every rank has added
+        its own increments to `cur` since the common state `last`; the new common state is last + SUM over ranks of (cur - last), clamped
+        at 1 like the reference's update.  `last` must be the grid all ranks shared at the previous sync -- after a checkpoint restore that
+        is the RESTORED grid, not the initial one (otherwise the restored part would be counted world_size times)."""
+        delta = cur - last
+        self.sum_(delta)
+        return torch.clamp(last + delta, max=1.0)
+
+    def broadcast_int(self, value, src=0):
+        """One Python int from rank `src` to every rank (the drawn seed when basic.seed == -1)."""
+        if not self.active:
+            return int(value)
+        box = [int(value)]
+        dist.broadcast_object_list(box, src=src)
+        return int(box[0])
 
     def max_(self, t):
         if self.active:

@@ -139,6 +139,12 @@ class Runner:
         self.dp.broadcast_parameters(self.model)  # identical initial weights on every rank
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.learning_rate)
         self._load()
+        # Resume semantics of the reference (runner.py:31-34,174-180): the restored param_group lr serves the FIRST optimiser step only; the
+        # first KL adaptation then overwrites it with a value derived from self.learning_rate = the yaml value, so adaptation restarts from
+        # cfg.algorithm.learning_rate, not from the checkpoint's lr.  Same here (see update()).
+        self._lr_restart = bool(self.cfg["basic"].get("checkpoint"))
+        # common state of the command-curriculum grid across ranks = whatever the env holds now (initial grid, or the restored one)
+        self._curr_last = self.env.curriculum_prob.clone() if self.dp.active and self.cfg["commands"].get("curriculum", False) else None
 
         T, N = self.cfg["runner"]["horizon_length"], self.env.num_envs
         self.buffer = ExperienceBuffer(T, N, self.device)
@@ -202,7 +208,9 @@ class Runner:
 
     def _set_seed(self):
         if self.cfg["basic"]["seed"] == -1:
-            self.cfg["basic"]["seed"] = np.random.randint(0, 10000)
+            # one draw for the whole job: terrain and the logged config.yaml must be the same on every rank (rank offsets are applied
+            # where per-rank streams are wanted: T1._cfg_struct and the rollout seed)
+            self.cfg["basic"]["seed"] = self.dp.broadcast_int(np.random.randint(0, 10000))
         seed = self.cfg["basic"]["seed"]
         if self.rank == 0:
             print("Setting seed: {}".format(seed))
@@ -330,6 +338,9 @@ class Runner:
                 main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
                 self.optimizer.step()
+                if self._lr_restart:  # first step after a checkpoint load: see __init__
+                    self.optimizer.lr.fill_(float(cfg["algorithm"]["learning_rate"]))
+                    self._lr_restart = False
                 self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
                 self._stats_acc += self._stats
         return self._stats_acc
@@ -338,22 +349,14 @@ class Runner:
         buf, T = self.buffer, self.cfg["runner"]["horizon_length"]
         self.rollout()
         stats = self.update()
-        # carry the last observation into row 0 of the next rollout
-        buf["obses"][0].copy_(buf["obses"][T])
-        buf["privileged_obses"][0].copy_(buf["privileged_obses"][T])
+        buf.roll()  # carry the last observation into row 0 of the next rollout
         return stats
 
     def _sync_curriculum(self):
         """Multi-rank command curriculum: sum every rank's increments of the probability grid since the last sync."""
         if not (self.dp.active and self.cfg["commands"].get("curriculum", False)):
             return
-        cur = self.env.curriculum_prob
-        last = getattr(self, "_curr_last", None)
-        if last is None:
-            last = self.env._curriculum_init
-        delta = cur - last
-        self.dp.sum_(delta)
-        new = torch.clamp(last + delta, max=1.0)
+        new = self.dp.sync_grid(self.env.curriculum_prob, self._curr_last)
         self.env.curriculum_prob = new
         self._curr_last = new
 

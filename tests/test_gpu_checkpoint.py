@@ -45,6 +45,14 @@ def test_checkpoint_roundtrip_and_reference_layout(tmp_path):
     assert torch.equal(r.optimizer.exp_avg.cpu(), r2.optimizer.exp_avg.cpu()) and r2.optimizer.step_count == 2
     assert abs(r2.optimizer.lr.item() - r.optimizer.lr.item()) < 1e-12
     assert torch.equal(r.env.curriculum_prob.cpu(), r2.env.curriculum_prob.cpu())
+    # learning rate after a resume, as the reference does it (runner.py:31-34,174-180): the restored lr serves the first optimiser step, then the
+    # KL rule restarts from the yaml value (first mini-epoch KL = 0 -> x1.5) whatever the checkpoint held
+    r3 = _runner(epochs=1, **{"basic.checkpoint": path})
+    r3.optimizer.lr.fill_(3e-4)  # as if the checkpoint had been saved at a much larger adapted lr
+    obs, infos = r3.env.reset()
+    r3.buffer["obses"][0].copy_(obs); r3.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+    r3.iteration()
+    assert abs(r3.optimizer.lr.item() - 1.5 * r3.cfg["algorithm"]["learning_rate"]) < 1e-9
 
 
 def test_torchscript_export_matches_the_actor(tmp_path):

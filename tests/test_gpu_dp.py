@@ -12,6 +12,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except BaseException as ex:  # the parent fails fast with the real error instead of a queue time-out
+        import traceback
+
+        q.put(("error", rank, "".join(traceback.format_exception(type(ex), ex, ex.__traceback__))))
+        raise
+
+
+def _worker_body(rank, world, port, q):
     os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
                       BG_DIST_BACKEND="gloo", BG_LOCAL_DEVICE="0")
     sys.path.insert(0, ROOT)
@@ -54,19 +64,38 @@ def _worker(rank, world, port, q):
     r.dp.shutdown()
 
 
+def _free_port():
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
 def test_two_rank_update_equals_reference_on_the_union():
     import torch.multiprocessing as mp
 
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29600 + (os.getpid() % 300)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = [q.get(timeout=300) for _ in procs]
-    for p in procs:
-        p.join(timeout=60)
-        assert p.exitcode == 0
+    try:
+        res = []
+        for _ in procs:
+            item = q.get(timeout=300)
+            if item[0] == "error":
+                pytest.fail(f"rank {item[1]} raised:\n{item[2]}")
+            res.append(item)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:  # never leave a rank behind holding the GPU, the port and a blocked collective
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=10)
     for rank, rank_diff, ref_diff, moved, kl, kl_ref, vl, vl_ref, lr, lr_ref, ok in res:
         assert ok
         assert rank_diff == 0.0, "ranks diverged"

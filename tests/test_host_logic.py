@@ -198,9 +198,15 @@ def test_experience_buffer_and_recorder(tmp_path):
 
     b = ExperienceBuffer(4, 3, "cpu")
     b.add_buffer("obses", (5,), extra_rows=1); b.add_buffer("dones", (), dtype=torch.bool)
-    assert b["obses"].shape == (5, 3, 5) and b["dones"].dtype == torch.bool and len(b) == 2 and set(b.keys()) == {"obses", "dones"}
-    b.update_data("obses", 2, torch.ones(3, 5))
-    assert b["obses"][2].sum() == 15
+    assert b["obses"].shape == (5, 3, 5) and b["dones"].shape == (4, 3) and b["dones"].dtype == torch.bool and b.names() == ("obses", "dones")
+    b.row("obses", 4).fill_(2.0)  # the carried row: observation after the last step
+    b.row("obses", 2).copy_(torch.ones(3, 5))
+    assert b.flat("obses").shape == (12, 5) and b.flat("obses", with_carry=True).shape == (15, 5) and b.flat("obses")[6:9].sum() == 15
+    assert b.flat("obses").data_ptr() == b["obses"].data_ptr()  # views, not copies
+    b.roll()
+    assert b["obses"][0].eq(2.0).all() and b.nbytes() == 5 * 3 * 5 * 4 + 4 * 3
+    with pytest.raises(KeyError):
+        b.add_buffer("obses", (5,))
     rec = Recorder({"basic": {"task": "T1"}, "runner": {"use_wandb": False}}, root=str(tmp_path))
     rec.record_statistics({"value_loss": 1.5, "lr": 1e-5}, 3)
     path = rec.save({"model": {}, "optimizer": {}, "curriculum": torch.zeros(21, 21)}, 100)
@@ -400,3 +406,58 @@ def test_data_parallel_update_equals_single_process_full_batch():
         assert n == 177945
         assert err < 2e-4 * scale + 2e-6, (rank, err, scale)
         assert abs(kl - kl_ref) < 1e-3 * abs(kl_ref)
+
+
+def _grid_worker(rank, world, port, q):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BG_DIST_BACKEND="gloo")
+    import torch
+
+    from booster_gym_amd.utils.parallel import DataParallel
+
+    dp = DataParallel()
+    g = torch.Generator().manual_seed(7)
+    restored = torch.rand(21, 21, generator=g) * 0.6  # a non-trivial grid out of a checkpoint, the same on both ranks
+    init = torch.zeros(21, 21); init[10, 10] = 1.0
+    # (1) resume, no episode finished since: the grid must come back unchanged
+    same = dp.sync_grid(restored.clone(), restored.clone())
+    # (2) what the round-1 code did (baseline = the INITIAL grid): the restored part is counted world_size times
+    wrong = dp.sync_grid(restored.clone(), init.clone())
+    # (3) increments made by one rank only reach every rank once; clamped at 1
+    cur = restored.clone()
+    if rank == 0:
+        cur[3, 4] += 0.25; cur[0, 0] += 5.0
+    inc = dp.sync_grid(cur, restored.clone())
+    seed = dp.broadcast_int(1234 + rank)
+    q.put((rank, float((same - restored).abs().max()), float((wrong - restored).abs().max()), float(inc[3, 4] - restored[3, 4]), float(inc[0, 0]),
+           float((inc - restored).abs().sum()), float(min(1.0, restored[0, 0] + 5.0) - restored[0, 0]) + 0.25, seed))
+    dp.shutdown()
+
+
+def test_curriculum_grid_sync_after_resume_two_ranks():
+    """after a checkpoint restore the first grid sync must only carry increments made since the restore."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grid_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = [q.get(timeout=180) for _ in procs]
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    for rank, same_err, wrong_err, d34, v00, total, expect_total, seed in res:
+        assert same_err == 0.0
+        assert wrong_err > 0.1  # the failure mode the fix removes
+        assert abs(d34 - 0.25) < 1e-6 and v00 == 1.0 and abs(total - expect_total) < 1e-5
+        assert seed == 1234  # rank 0's draw everywhere
