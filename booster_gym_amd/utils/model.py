@@ -63,12 +63,30 @@ class MLPTrainer:
         self.acts = [torch.empty(rows, l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
         self.gin = [None] + [torch.empty(B, l.weight.shape[1], dtype=torch.float32, device=dev) for l in self.layers[1:]]
         self.cs = [torch.empty(((B + 127) // 128) * l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
-        self.dw = [torch.empty(self._S, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1], dtype=torch.float32, device=dev)
+        # weight gradients: hand-written split-over-the-batch MFMA kernel (bg_mlp_weight_grad) where the shape allows, scratch = slices x dW
+        self.wg_slices = [self._wgrad_slices(B, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1]) for i, l in enumerate(self.layers)]
+        self.dw = [torch.empty(self.wg_slices[i] or self._S, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1], dtype=torch.float32, device=dev)
                    for i, l in enumerate(self.layers)]
         self.wt = [None] * len(self.layers)  # transposed weights for the fused backward kernel
         l0 = self.layers[0]
         self.w0pad = torch.zeros(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if k_in != l0.weight.shape[1] else None
         self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
+
+    # BG_FUSED_WGRAD=0 keeps the library path (split-K bmm + sum) for A/B comparisons
+    FUSED_WGRAD = __import__("os").environ.get("BG_FUSED_WGRAD", "1") == "1"
+    WGRAD_WORKGROUPS = int(__import__("os").environ.get("BG_WGRAD_WORKGROUPS", "256"))  # one 4-wave workgroup per CU
+
+    @classmethod
+    def _wgrad_slices(cls, B, c_out, c_in):
+        """Number of batch slices for bg_mlp_weight_grad (0 = shape not supported: library GEMM).  One workgroup per (128 x 128 output tile,
+        slice); slices a multiple of 8 (same-slice tiles share an XCD); runs of 16 row pairs per wave keep the MFMA loop free of idle trips."""
+        if not (cls.FUSED_WGRAD and cls.FUSED) or c_out % 128 or (c_in != 64 and c_in % 128) or B % 2 or B < 64:
+            return 0
+        ntiles = (c_out // 128) * max(1, c_in // 128)
+        s = max(8, cls.WGRAD_WORKGROUPS // ntiles // 8 * 8)
+        while s > 8 and s * 8 > B:
+            s -= 8
+        return s
 
     def forward_hidden(self, x, train_rows=None):
         """All layers but the output layer: returns the activations of the last hidden (ELU) layer [rows, width].  The output layer then runs
@@ -138,7 +156,11 @@ class MLPTrainer:
             l = self.layers[i]
             a_in = (self.acts[i - 1] if i > 0 else self.x)[:B]
             C_out, C_in = l.weight.shape
-            if i == 0 and self.w0pad is not None:  # padded input columns: their gradient columns are dropped
+            if self.wg_slices[i]:
+                # dW = G^T A in one hand-written launch pair, written straight into the flat gradient buffer (padded input columns dropped)
+                _lib.check(lib.bg_mlp_weight_grad(B, C_out, a_in.shape[1], C_in, _lib.ptr(g), _lib.ptr(a_in), _lib.ptr(l.weight.grad), _lib.ptr(self.dw[i]),
+                                                  self.wg_slices[i], stream), "bg_mlp_weight_grad")
+            elif i == 0 and self.w0pad is not None:  # padded input columns: their gradient columns are dropped
                 torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, self._kin), out=self.dw[0])
                 torch.sum(self.dw[0], dim=0, out=self.dw0sum)
                 l.weight.grad.copy_(self.dw0sum[:, :C_in])

@@ -242,6 +242,16 @@ int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const 
 int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const float* G, const float* Wt, const float* act_below, float* Gout,
                           float* bias_grad_below, float* scratch, void* stream);
 
+/* Weight gradient of one Linear layer over the batch (the dW part of `loss.backward()`, utils/runner.py:163, for model.py:9-26's layers):
+ * dW [C_out][C_in_real] = G [M][C_out]^T . A [M][C_in][:, :C_in_real], fp32 MFMA, the sum over the M rows split over `slices` x 4 waves
+ * inside the launch and finished in a fixed order (deterministic, no atomics).  G = dL/dz of the layer, A = its input activations with
+ * the feature dimension C_in possibly zero-padded (the first layers: 47 / 61 -> 64); only the first C_in_real columns are written, with
+ * row stride C_in_real, so dW can be the parameter's .grad view in the flat gradient buffer.
+ * C_out a multiple of 128, C_in 64 or a multiple of 128, M even, slices a multiple of 8 with slices * 8 <= M;
+ * scratch: slices * C_out * C_in floats.  Otherwise -4 / -1. */
+int bg_mlp_weight_grad(int32_t M, int32_t C_out, int32_t C_in, int32_t C_in_real, const float* G, const float* A, float* dW, float* scratch,
+                       int32_t slices, void* stream);
+
 /* ---- output ("head") layers fused with the loss: the 128 -> 12 / 128 -> 1 Linear layers of utils/model.py:13,21 together with
  * runner.py:145-174.  h [rows][128] = activations of the last hidden (ELU) layer, 16-byte aligned.  One launch reads h once instead of
  * the seven library GEMM / elementwise passes these skinny layers otherwise take per network and mini-epoch.

@@ -63,3 +63,48 @@ def test_mlp_layer_backward_matches_torch(M, K, N):
     assert torch.isfinite(out).all() and err <= max(4 * err_t, 1e-5), (err, err_t)
     cs = ref.sum(0)
     assert torch.allclose(bg.double(), cs, rtol=1e-4, atol=2e-3 * max(1.0, cs.abs().max().item()))
+
+
+# the six hidden-layer shapes of the two networks at the training batch (actor 47(64)-256-128-128, critic 61(64)-256-256-128; utils/model.py:9-26)
+# + ragged / small / asymmetric cases: run lengths that are not multiples of the kernel's 16-row-pair trip, one slice group, wide C_in
+@pytest.mark.parametrize("M,C_out,C_in,C_real,slices", [(98304, 256, 64, 47, 128), (98304, 128, 256, 256, 128), (98304, 128, 128, 128, 256),
+                                                       (98304, 256, 64, 61, 128), (98304, 256, 256, 256, 64), (98304, 128, 256, 256, 64),
+                                                       (1536, 128, 128, 128, 8), (1000, 256, 128, 128, 16), (70, 128, 64, 64, 8), (4098, 384, 256, 256, 24)])
+def test_mlp_weight_grad_matches_torch_fp64(M, C_out, C_in, C_real, slices):
+    """dW = G^T A against torch float64; the tolerance is that of torch's own fp32 GEMM of the same product (summation order only)."""
+    from booster_gym_amd import _lib
+
+    torch.manual_seed(M + C_out + 7 * C_in)
+    G = torch.randn(M, C_out, device=DEV)
+    A = torch.randn(M, C_in, device=DEV)
+    A[:, C_real:] = 0.0  # zero-padded input columns, as the runner provides them
+    # asymmetric markers: a transposed / permuted output map cannot pass
+    G[:, 3] *= 3.0; A[:, 1] += 0.5; G[0, C_out - 1] = 40.0; A[0, C_real - 1] = -25.0
+    dW = torch.full((C_out, C_real), float("nan"), device=DEV)
+    scratch = torch.empty(slices * C_out * C_in, device=DEV)
+    _lib.check(_lib.load().bg_mlp_weight_grad(M, C_out, C_in, C_real, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(scratch), slices,
+                                              _lib.current_stream_ptr()), "bg_mlp_weight_grad")
+    ref64 = G.double().t() @ A.double()[:, :C_real]
+    ref32 = G.t() @ A[:, :C_real]
+    err, err_t = (dW.double() - ref64).abs().max().item(), (ref32.double() - ref64).abs().max().item()
+    assert torch.isfinite(dW).all() and err <= max(4 * err_t, 1e-4), (err, err_t)
+    # deterministic: a second launch gives the same bits
+    dW2 = torch.empty_like(dW)
+    _lib.check(_lib.load().bg_mlp_weight_grad(M, C_out, C_in, C_real, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW2), _lib.ptr(scratch), slices,
+                                              _lib.current_stream_ptr()), "bg_mlp_weight_grad")
+    assert torch.equal(dW, dW2)
+
+
+def test_mlp_weight_grad_rejects_bad_arguments():
+    from booster_gym_amd import _lib
+
+    lib = _lib.load()
+    G = torch.zeros(256, 128, device=DEV); A = torch.zeros(256, 128, device=DEV); dW = torch.zeros(128, 128, device=DEV); sc = torch.zeros(8 * 128 * 128, device=DEV)
+    st = _lib.current_stream_ptr()
+    assert lib.bg_mlp_weight_grad(256, 100, 128, 128, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 8, st) == -4   # C_out
+    assert lib.bg_mlp_weight_grad(256, 128, 96, 96, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 8, st) == -4     # C_in
+    assert lib.bg_mlp_weight_grad(255, 128, 128, 128, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 8, st) == -4   # odd M
+    assert lib.bg_mlp_weight_grad(256, 128, 128, 128, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 12, st) == -4  # slices % 8
+    assert lib.bg_mlp_weight_grad(32, 128, 128, 128, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 8, st) == -4    # slices * 8 > M
+    assert lib.bg_mlp_weight_grad(256, 128, 128, 129, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 8, st) == -1   # C_in_real
+    assert lib.bg_mlp_weight_grad(256, 128, 128, 128, _lib.ptr(G), None, _lib.ptr(dW), _lib.ptr(sc), 8, st) == -1
