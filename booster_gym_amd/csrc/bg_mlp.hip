@@ -207,142 +207,6 @@ __global__ __launch_bounds__(256) void mlp_colsum_finish_kernel(int nb, int C, c
     if (threadIdx.x == 0) out[c] = sm[0];
 }
 
-// ---------------------------------------------------------------------------------------------------------------------------------------
-// Weight gradient dW[C_out][C_in] = G^T A over the batch (reference utils/runner.py:163 `loss.backward()` through model.py:9-26's Linear
-// layers): G [M][C_out] = dL/dz of the layer, A [M][C_in] = its input activations, M = 98,304 rows, C_* in {64, 128, 256}.
-// The reduction dimension is the BATCH, and both operands are row-major over it, which is exactly the MFMA operand layout: for
-// v_mfma_f32_32x32x2_f32 lane (i = lane & 31, h = lane >> 5) supplies A-operand element [i][k = h] and B-operand element [k = h][i]; with
-// k = batch row 2*kp + h a lane loads 16 bytes of row (2*kp + h) of G and of A, and the four floats serve four different output tiles
-// (output columns 4*i + t: a fixed permutation of the output, undone by the store).  So ONE 16-byte load of each operand feeds 16 MFMAs of
-// a 128 x 128 output tile held in 256 accumulator registers: no LDS staging, no barriers in the main loop, 2 KB of loads per 65,536 flop.
-// Split over the batch inside the launch: every wave owns a contiguous run of row pairs, the 4 waves of a workgroup add their tiles through
-// LDS, one partial tile per workgroup goes to `P[slice]`, and a second kernel adds the slices in a fixed order (deterministic; no atomics).
-// Workgroups that read the same rows (the tiles of one slice) are given block indices 8 apart, i.e. the same XCD and L2 (speed only).
-template <int TCI>  // 32-column C_in tiles per wave: 4 (128 input columns per workgroup) or 2 (64: the zero-padded first layers)
-__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(int M, int Cout, int Cin, const float* __restrict__ G, const float* __restrict__ A,
-                                                           float* __restrict__ P, int ntile_ci, int ntiles, int slices) {
-    constexpr int D = 8;  // row pairs per register set: 2 sets x D x (4 + TCI) registers of loads in flight under D x 4 x TCI MFMAs
-    typedef float avec __attribute__((ext_vector_type(TCI)));
-    __shared__ __attribute__((aligned(16))) float red[4][64 * 16 * 2 * TCI];
-    const int b = blockIdx.x, q = b >> 3, tile = q % ntiles, slice = (q / ntiles) * 8 + (b & 7);
-    const int tco = tile / ntile_ci, tci = tile % ntile_ci;
-    // wave-uniform values are forced into SGPRs: the loads then take the scalar-base + 32-bit lane offset form and the walk over the rows
-    // is scalar arithmetic (per-lane 64-bit addresses for 2 x D x 2 loads in flight do not fit beside 256 accumulators)
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const long KP = M >> 1, W = (long)slices * 4, widx = (long)slice * 4 + wave;
-    const int kp0 = (int)(KP * widx / W), kp1 = (int)(KP * (widx + 1) / W);
-    const unsigned gofb = 4u * (h * Cout + tco * 128 + 4 * i), aofb = 4u * (h * Cin + tci * (32 * TCI) + TCI * i);  // byte offsets of this lane
-    const char* Gb = reinterpret_cast<const char*>(G);
-    const char* Ab = reinterpret_cast<const char*>(A);
-    f32x16 acc[4][TCI];
-#pragma unroll
-    for (int t = 0; t < 4; t++)
-#pragma unroll
-        for (int u = 0; u < TCI; u++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) acc[t][u][r] = 0.f;
-    f32x4 g0[D], g1[D];
-    avec a0[D], a1[D];
-    auto load = [&](f32x4 (&g)[D], avec (&a)[D], int kp) {
-#pragma unroll
-        for (int d = 0; d < D; d++) {
-            const bool ok = kp + d < kp1;  // scalar
-            const size_t r = 2 * (size_t)(ok ? kp + d : kp1 - 1);
-            g[d] = *reinterpret_cast<const f32x4*>(Gb + r * Cout * 4 + gofb);
-            a[d] = *reinterpret_cast<const avec*>(Ab + r * Cin * 4 + aofb);
-            if (!ok) g[d] = f32x4{0.f, 0.f, 0.f, 0.f};  // past the end of this wave's run: contributes nothing
-        }
-    };
-    auto fma_set = [&](const f32x4 (&g)[D], const avec (&a)[D]) {
-#pragma unroll
-        for (int d = 0; d < D; d++)
-#pragma unroll
-            for (int t = 0; t < 4; t++)
-#pragma unroll
-                for (int u = 0; u < TCI; u++) acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x2f32(g[d][t], a[d][u], acc[t][u], 0, 0, 0);
-    };
-    // straight-line body (no conditional MFMAs: the accumulators must stay put in their 256 registers): row pairs past the end of the run are
-    // loaded from a clamped address and zeroed, so a run whose length is not a multiple of 2 * D only wastes the idle MFMAs of its last trip
-    load(g0, a0, kp0);
-    for (int kp = kp0; kp < kp1; kp += 2 * D) {
-        load(g1, a1, kp + D);
-        fma_set(g0, a0);
-        load(g0, a0, kp + 2 * D);
-        fma_set(g1, a1);
-    }
-    // Add the four waves' tiles through LDS in two rounds of two co-tiles (4 waves x 2 x 16 registers x 64 lanes x TCI floats = 128 KB at
-    // TCI = 4): every wave writes its half, then wave w sums the four copies of 8 registers of co-tile (w >> 1) of the round and stores them.
-    // The same code for every wave (no wave-conditional use of the accumulators), and the partial tile leaves through all four waves.
-    // C layout of a 32 x 32 tile: column (B operand index) = lane & 31, row (A operand index) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
-    // Tile (t, u) of a wave holds output rows co = 4 * row + t and columns ci = TCI * col + u: a lane stores TCI consecutive columns.
-    float* pt = P + (size_t)slice * Cout * Cin + (size_t)(tco * 128) * Cin + tci * (32 * TCI) + TCI * i;
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        if (half) __syncthreads();
-#pragma unroll
-        for (int tt = 0; tt < 2; tt++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                avec v;
-#pragma unroll
-                for (int u = 0; u < TCI; u++) v[u] = acc[2 * half + tt][u][r];
-                *reinterpret_cast<avec*>(&red[wave][((tt * 16 + r) * 64 + lane) * TCI]) = v;
-            }
-        __syncthreads();
-        const int tt = wave >> 1, t = 2 * half + tt;
-#pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) {
-            const int r = 8 * (wave & 1) + r8, idx = ((tt * 16 + r) * 64 + lane) * TCI;
-            const avec v = (*reinterpret_cast<const avec*>(&red[0][idx]) + *reinterpret_cast<const avec*>(&red[1][idx])) +
-                           (*reinterpret_cast<const avec*>(&red[2][idx]) + *reinterpret_cast<const avec*>(&red[3][idx]));
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
-            *reinterpret_cast<avec*>(pt + (size_t)(4 * row + t) * Cin) = v;
-        }
-    }
-}
-
-// dW[co][ci < Cin_real] = sum over slices of P[s][co][ci], slices added in a fixed order; 64 float4 columns x 4 slice groups per workgroup
-__global__ __launch_bounds__(256) void mlp_wgrad_finish_kernel(int S, int Cin, int Cin_real, int n4, const float* __restrict__ P, float* __restrict__ dW) {
-    __shared__ f32x4 sm[4][64];
-    const int c = threadIdx.x & 63, sg = threadIdx.x >> 6, e4 = blockIdx.x * 64 + c;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (e4 < n4)
-        for (int s = sg; s < S; s += 4) acc += *reinterpret_cast<const f32x4*>(P + ((size_t)s * n4 + e4) * 4);
-    sm[sg][c] = acc;
-    __syncthreads();
-    if (sg == 0 && e4 < n4) {
-        const f32x4 v = (sm[0][c] + sm[1][c]) + (sm[2][c] + sm[3][c]);
-        const int row = (e4 * 4) / Cin, col = (e4 * 4) % Cin;
-        if (Cin_real == Cin) {
-            *reinterpret_cast<f32x4*>(dW + (size_t)row * Cin + col) = v;
-        } else {
-#pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (col + k < Cin_real) dW[(size_t)row * Cin_real + col + k] = v[k];
-        }
-    }
-}
-
-extern "C" int bg_mlp_weight_grad(int32_t M, int32_t C_out, int32_t C_in, int32_t C_in_real, const float* G, const float* A, float* dW,
-                                  float* scratch, int32_t slices, void* stream) {
-    if (M <= 0 || !G || !A || !dW || !scratch) return bg_set_error(-1, "bg_mlp_weight_grad: bad argument");
-    if ((((uintptr_t)G | (uintptr_t)A | (uintptr_t)scratch) & 15) != 0) return bg_set_error(-1, "bg_mlp_weight_grad: G, A, scratch must be 16-byte aligned");
-    if (C_in_real == C_in && (((uintptr_t)dW) & 15) != 0) return bg_set_error(-1, "bg_mlp_weight_grad: dW must be 16-byte aligned");
-    if (C_out % 128 != 0 || C_out > 1024) return bg_set_error(-4, "bg_mlp_weight_grad: unsupported C_out (multiples of 128 up to 1024)");
-    if (C_in != 64 && (C_in % 128 != 0 || C_in > 1024)) return bg_set_error(-4, "bg_mlp_weight_grad: unsupported C_in (64, or multiples of 128 up to 1024)");
-    if (C_in_real <= 0 || C_in_real > C_in) return bg_set_error(-1, "bg_mlp_weight_grad: C_in_real must be in [1, C_in]");
-    if (M % 2 != 0) return bg_set_error(-4, "bg_mlp_weight_grad: M must be even (rows are consumed in pairs)");
-    if (slices <= 0 || slices % 8 != 0 || (long)slices * 8 > M) return bg_set_error(-4, "bg_mlp_weight_grad: slices must be a multiple of 8 with slices * 8 <= M");
-    const int tci_w = C_in == 64 ? 64 : 128, ntile_ci = C_in / tci_w, ntiles = (C_out / 128) * ntile_ci;
-    hipStream_t st = (hipStream_t)stream;
-    if (C_in == 64) hipLaunchKernelGGL((mlp_wgrad_kernel<2>), dim3(ntiles * slices), dim3(256), 0, st, M, C_out, C_in, G, A, scratch, ntile_ci, ntiles, slices);
-    else hipLaunchKernelGGL((mlp_wgrad_kernel<4>), dim3(ntiles * slices), dim3(256), 0, st, M, C_out, C_in, G, A, scratch, ntile_ci, ntiles, slices);
-    const int n4 = C_out * C_in / 4;
-    hipLaunchKernelGGL(mlp_wgrad_finish_kernel, dim3((n4 + 63) / 64), dim3(256), 0, st, slices, C_in, C_in_real, n4, scratch, dW);
-    HIP_OK(hipGetLastError());
-    return 0;
-}
-
 extern "C" int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const float* W, const float* bias, float* Y, int32_t elu,
                                     void* stream) {
     if (M <= 0 || !X || !W || !bias || !Y) return bg_set_error(-1, "bg_mlp_layer_forward: bad argument");

@@ -72,8 +72,13 @@ class MLPTrainer:
         self.w0pad = torch.zeros(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if k_in != l0.weight.shape[1] else None
         self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
 
-    # BG_FUSED_WGRAD=0 keeps the library path (split-K bmm + sum) for A/B comparisons
-    FUSED_WGRAD = __import__("os").environ.get("BG_FUSED_WGRAD", "1") == "1"
+    # Weight gradients: BG_FUSED_WGRAD=1 selects the hand-written kernel (bg_mlp_weight_grad), the default is the library path (split-K bmm + sum).
+    # Measured on MI355X at M = 98,304 (tools/wgrad_probe.py, tools/ab_wgrad.sh; round 2): stand-alone 111 vs 102 us (256x256), 67 vs 59 (128x256),
+    # 42 vs 34 (128x128), 39 vs 35 us (256x64) -- the MFMA loop itself runs at 80-90 % of the fp32 matrix rate, but a K-split over 256 workgroups
+    # writes and re-reads 16.8 MB of partial tiles per call where hipBLASLt's 32-slice batched GEMM moves 2-8 MB; in the training loop the
+    # update phase takes 26.6 ms with it against 24.6 ms with the library GEMMs (its 512-register workgroups cannot share a CU with the other
+    # stream's kernels).  So the faster path stays the default.
+    FUSED_WGRAD = __import__("os").environ.get("BG_FUSED_WGRAD", "0") == "1"
     WGRAD_WORKGROUPS = int(__import__("os").environ.get("BG_WGRAD_WORKGROUPS", "256"))  # one 4-wave workgroup per CU
 
     @classmethod
