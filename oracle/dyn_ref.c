@@ -30,6 +30,23 @@
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
+/* Second build of the SAME source in single precision (libdynref32.so: `-DREF_F32 -fsingle-precision-constant`, Makefile): every
+ * `double` below, the ABI structs and arrays included, becomes float and the libm calls their float entry points.  It serves
+ * (1) the parity tests, as the measure of how far fp32 rounding ALONE moves this very algorithm on a given state (tests/test_gpu_env.py:
+ * an env may deviate from the float64 result only as far as this build does, times a fixed factor), and (2) bench.py's cpu_baseline
+ * leg (the CPU baseline computes in fp32 like the reference's PhysX-CPU path).  Parity proper stays on the double build. */
+#ifdef REF_F32
+#define double float
+#define sqrt sqrtf
+#define cos cosf
+#define sin sinf
+#define fabs fabsf
+#define floor floorf
+#define fmin fminf
+#define REF_TINY 1e-30f
+#else
+#define REF_TINY 1e-300
+#endif
 
 #define NB 13
 #define ND 12
@@ -388,7 +405,7 @@ static int solve6(double A[6][6], double b[6]) {
     for (int c = 0; c < 6; c++) {
         int piv = c;
         for (int r = c + 1; r < 6; r++) if (fabs(A[r][c]) > fabs(A[piv][c])) piv = r;
-        if (fabs(A[piv][c]) < 1e-300) return -1;
+        if (fabs(A[piv][c]) < REF_TINY) return -1;
         if (piv != c) {
             for (int k = 0; k < 6; k++) { double t = A[c][k]; A[c][k] = A[piv][k]; A[piv][k] = t; }
             double t = b[c]; b[c] = b[piv]; b[piv] = t;

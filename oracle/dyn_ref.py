@@ -12,75 +12,84 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 NB, ND = 13, 12
 
 
-class RefModel(C.Structure):
-    _fields_ = [
-        ("nb", C.c_int32),
-        ("parent", C.c_int32 * NB),
-        ("axis", C.c_int32 * NB),
-        ("pos", C.c_double * 3 * NB),
-        ("mass", C.c_double * NB),
-        ("com", C.c_double * 3 * NB),
-        ("inertia", C.c_double * 6 * NB),
-        ("q_lower", C.c_double * ND),
-        ("q_upper", C.c_double * ND),
-        ("qd_limit", C.c_double * ND),
-        ("foot_body", C.c_int32 * 2),
-        ("foot_corner", C.c_double * 3 * 4),
-        ("n_sph", C.c_int32),
-        ("sph_body", C.c_int32 * 16),
-        ("sph_pos", C.c_double * 3 * 16),
-        ("sph_r", C.c_double * 16),
-    ]
+def _structs(ct):
+    """ctypes mirrors of ref_model_t / ref_phys_t / ref_terrain_t for one real type (c_double: libdynref.so, c_float: libdynref32.so)."""
+
+    class RefModel(C.Structure):
+        _fields_ = [
+            ("nb", C.c_int32),
+            ("parent", C.c_int32 * NB),
+            ("axis", C.c_int32 * NB),
+            ("pos", ct * 3 * NB),
+            ("mass", ct * NB),
+            ("com", ct * 3 * NB),
+            ("inertia", ct * 6 * NB),
+            ("q_lower", ct * ND),
+            ("q_upper", ct * ND),
+            ("qd_limit", ct * ND),
+            ("foot_body", C.c_int32 * 2),
+            ("foot_corner", ct * 3 * 4),
+            ("n_sph", C.c_int32),
+            ("sph_body", C.c_int32 * 16),
+            ("sph_pos", ct * 3 * 16),
+            ("sph_r", ct * 16),
+        ]
+
+    class RefPhys(C.Structure):
+        _fields_ = [
+            ("dt", ct),
+            ("g", ct * 3),
+            ("contact_k", ct),
+            ("contact_d", ct),
+            ("contact_ramp", ct),
+            ("friction_visc", ct),
+            ("limit_k", ct),
+            ("limit_d", ct),
+            ("terrain_mu", ct),
+            ("terrain_restitution", ct),
+            ("clamp_qd", C.c_int32),
+            ("pad", C.c_int32),
+            ("body_gate_height", ct),
+        ]
+
+    class RefTerrain(C.Structure):
+        _fields_ = [
+            ("type", C.c_int32),
+            ("rows", C.c_int32),
+            ("cols", C.c_int32),
+            ("border_px", C.c_int32),
+            ("hscale", ct),
+            ("vscale", ct),
+            ("hf", C.c_void_p),
+        ]
+
+    return RefModel, RefPhys, RefTerrain
 
 
-class RefPhys(C.Structure):
-    _fields_ = [
-        ("dt", C.c_double),
-        ("g", C.c_double * 3),
-        ("contact_k", C.c_double),
-        ("contact_d", C.c_double),
-        ("contact_ramp", C.c_double),
-        ("friction_visc", C.c_double),
-        ("limit_k", C.c_double),
-        ("limit_d", C.c_double),
-        ("terrain_mu", C.c_double),
-        ("terrain_restitution", C.c_double),
-        ("clamp_qd", C.c_int32),
-        ("pad", C.c_int32),
-        ("body_gate_height", C.c_double),
-    ]
+RefModel, RefPhys, RefTerrain = _structs(C.c_double)
+_STRUCTS32 = _structs(C.c_float)
 
 
-class RefTerrain(C.Structure):
-    _fields_ = [
-        ("type", C.c_int32),
-        ("rows", C.c_int32),
-        ("cols", C.c_int32),
-        ("border_px", C.c_int32),
-        ("hscale", C.c_double),
-        ("vscale", C.c_double),
-        ("hf", C.c_void_p),
-    ]
-
-
-def build(force=False):
-    so = os.path.join(_HERE, "libdynref.so")
+def build(force=False, f32=False):
+    name = "libdynref32.so" if f32 else "libdynref.so"
+    so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "dyn_ref.c")
     if force or not os.path.isfile(so) or (os.path.isfile(src) and os.path.getmtime(src) > os.path.getmtime(so)):
-        subprocess.check_call(["make", "-C", _HERE, "-s", "libdynref.so"])
+        subprocess.check_call(["make", "-C", _HERE, "-s", name])
     return so
 
 
-_lib = None
+_libs = {}
 
 
-def lib():
-    global _lib
-    if _lib is None:
-        _lib = C.CDLL(build())
-        _lib.ref_terrain_height.restype = C.c_double
-        _lib.ref_terrain_height.argtypes = [C.c_void_p, C.c_double, C.c_double]
-    return _lib
+def lib(f32=False):
+    if f32 not in _libs:
+        l = C.CDLL(build(f32=f32))
+        ct = C.c_float if f32 else C.c_double
+        l.ref_terrain_height.restype = ct
+        l.ref_terrain_height.argtypes = [C.c_void_p, ct, ct]
+        _libs[f32] = l
+    return _libs[f32]
 
 
 def _p(a):
@@ -121,8 +130,14 @@ def contact_spheres(flat_model, foot_bodies):
 class DynRef:
     """Holds model/physics/terrain structs and exposes the oracle entry points on numpy arrays."""
 
-    def __init__(self, flat_model, foot_names=("left_foot_link", "right_foot_link"), feet_edge_pos=None, phys=None, terrain=None, body_contacts=True):
-        m = RefModel()
+    def __init__(self, flat_model, foot_names=("left_foot_link", "right_foot_link"), feet_edge_pos=None, phys=None, terrain=None, body_contacts=True,
+                 real="f64"):
+        """real: "f64" = the oracle proper (libdynref.so); "f32" = the single-precision twin of the same source (libdynref32.so), used as the
+        per-state measure of fp32 rounding sensitivity and as the CPU baseline.  Inputs / outputs are float64 numpy arrays either way."""
+        self.f32 = real == "f32"
+        self.rt = np.float32 if self.f32 else np.float64
+        self._S = _STRUCTS32 if self.f32 else (RefModel, RefPhys, RefTerrain)
+        m = self._S[0]()
         m.nb = flat_model.num_bodies
         assert m.nb == NB and flat_model.num_dofs == ND
         for i in range(NB):
@@ -156,7 +171,7 @@ class DynRef:
         self.model = m
         ph = dict(DEFAULT_PHYS)
         ph.update(phys or {})
-        p = RefPhys()
+        p = self._S[1]()
         p.dt = ph["dt"]
         for a in range(3):
             p.g[a] = ph["g"][a]
@@ -169,7 +184,7 @@ class DynRef:
 
     def set_terrain(self, terrain):
         """terrain: None/plane, or dict(height_field_raw int16[rows,cols], hscale, vscale, border_px)."""
-        t = RefTerrain()
+        t = self._S[2]()
         if terrain is None:
             t.type = 0
             self._hf = None
@@ -183,89 +198,113 @@ class DynRef:
             t.hf = self._hf.ctypes.data
         self.terrain = t
 
+    # ---- array plumbing: callers hand float64 numpy arrays; the f32 twin gets float32 copies and results are widened back
+    def _in(self, a):
+        return None if a is None else np.ascontiguousarray(a, dtype=self.rt)
+
+    def _out(self, *shape):
+        return np.zeros(shape, dtype=self.rt)
+
+    def _wide(self, a):
+        return None if a is None else (a.astype(np.float64) if self.f32 else a)
+
+    def _inplace(self, arrays):
+        """Working copies of in-place float64 arrays in the library's real type (the arrays themselves for the double build)."""
+        for a in arrays:
+            assert a.dtype == np.float64 and a.flags.c_contiguous
+        return [a.astype(np.float32) for a in arrays] if self.f32 else list(arrays)
+
+    def _writeback(self, arrays, work):
+        if self.f32:
+            for a, w in zip(arrays, work):
+                a[...] = w
+
+    @property
+    def _l(self):
+        return lib(self.f32)
+
+    def _refs(self):
+        return C.byref(self.model), C.byref(self.phys), C.byref(self.terrain)
+
     def terrain_height(self, x, y):
-        return lib().ref_terrain_height(C.byref(self.terrain), float(x), float(y))
+        return float(self._l.ref_terrain_height(C.byref(self.terrain), float(x), float(y)))
 
     def forward(self, root, q, qd, tau, base_wrench=None, mass_scale=None, com_off=None, foot_mat=None, want_body_acc=False):
-        root, q, qd, tau = _f64(root), _f64(q), _f64(qd), _f64(tau)
-        base_wrench, mass_scale, com_off, foot_mat = _f64(base_wrench), _f64(mass_scale), _f64(com_off), _f64(foot_mat)
-        qacc = np.zeros(18)
-        cf = np.zeros((NB, 3))
-        ab = np.zeros((NB, 6)) if want_body_acc else None
-        r = lib().ref_forward(C.byref(self.model), C.byref(self.phys), C.byref(self.terrain), _p(mass_scale), _p(com_off), _p(foot_mat),
-                              _p(root), _p(q), _p(qd), _p(tau), _p(base_wrench), _p(qacc), _p(cf), _p(ab))
+        i = self._in
+        qacc, cf = self._out(18), self._out(NB, 3)
+        ab = self._out(NB, 6) if want_body_acc else None
+        r = self._l.ref_forward(*self._refs(), _p(i(mass_scale)), _p(i(com_off)), _p(i(foot_mat)), _p(i(root)), _p(i(q)), _p(i(qd)), _p(i(tau)),
+                                _p(i(base_wrench)), _p(qacc), _p(cf), _p(ab))
         if r:
             raise RuntimeError("ref_forward failed")
-        return (qacc, cf, ab) if want_body_acc else (qacc, cf)
+        return (self._wide(qacc), self._wide(cf), self._wide(ab)) if want_body_acc else (self._wide(qacc), self._wide(cf))
 
     def inverse(self, root, q, qd, qacc, mass_scale=None, com_off=None):
-        root, q, qd, qacc = _f64(root), _f64(q), _f64(qd), _f64(qacc)
-        mass_scale, com_off = _f64(mass_scale), _f64(com_off)
-        res = np.zeros(18)
-        lib().ref_inverse(C.byref(self.model), C.byref(self.phys), _p(mass_scale), _p(com_off), _p(root), _p(q), _p(qd), _p(qacc), _p(res))
-        return res
+        i = self._in
+        res = self._out(18)
+        self._l.ref_inverse(C.byref(self.model), C.byref(self.phys), _p(i(mass_scale)), _p(i(com_off)), _p(i(root)), _p(i(q)), _p(i(qd)), _p(i(qacc)), _p(res))
+        return self._wide(res)
 
     def body_poses(self, root, q):
-        root, q = _f64(root), _f64(q)
-        pos, rot = np.zeros((NB, 3)), np.zeros((NB, 3, 3))
-        lib().ref_body_poses(C.byref(self.model), _p(root), _p(q), _p(pos), _p(rot))
-        return pos, rot
+        pos, rot = self._out(NB, 3), self._out(NB, 3, 3)
+        self._l.ref_body_poses(C.byref(self.model), _p(self._in(root)), _p(self._in(q)), _p(pos), _p(rot))
+        return self._wide(pos), self._wide(rot)
 
     def step(self, root, q, qd, tau, base_wrench=None, mass_scale=None, com_off=None, foot_mat=None):
         """One substep, in place on float64 arrays root[13], q[12], qd[12]. Returns contact forces [13,3]."""
-        assert root.dtype == np.float64 and q.dtype == np.float64 and qd.dtype == np.float64
-        tau, base_wrench, mass_scale, com_off, foot_mat = _f64(tau), _f64(base_wrench), _f64(mass_scale), _f64(com_off), _f64(foot_mat)
-        cf = np.zeros((NB, 3))
-        r = lib().ref_step(C.byref(self.model), C.byref(self.phys), C.byref(self.terrain), _p(mass_scale), _p(com_off), _p(foot_mat),
-                           _p(root), _p(q), _p(qd), _p(tau), _p(base_wrench), _p(cf))
+        i = self._in
+        st = (root, q, qd)
+        w = self._inplace(st)
+        cf = self._out(NB, 3)
+        r = self._l.ref_step(*self._refs(), _p(i(mass_scale)), _p(i(com_off)), _p(i(foot_mat)), _p(w[0]), _p(w[1]), _p(w[2]), _p(i(tau)),
+                             _p(i(base_wrench)), _p(cf))
         if r:
             raise RuntimeError("ref_step failed")
-        return cf
+        self._writeback(st, w)
+        return self._wide(cf)
 
     def forward_bw(self, root, q, qd, tau, body_force=None, body_torque=None, mass_scale=None, com_off=None, foot_mat=None):
         """Forward dynamics with a force / torque on every body (local frame, force at the centre of mass): t1.py:522-527."""
-        root, q, qd, tau = _f64(root), _f64(q), _f64(qd), _f64(tau)
-        body_force, body_torque, mass_scale, com_off, foot_mat = map(_f64, (body_force, body_torque, mass_scale, com_off, foot_mat))
-        qacc = np.zeros(18)
-        cf = np.zeros((NB, 3))
-        r = lib().ref_forward_bw(C.byref(self.model), C.byref(self.phys), C.byref(self.terrain), _p(mass_scale), _p(com_off), _p(foot_mat),
-                                 _p(root), _p(q), _p(qd), _p(tau), _p(body_force), _p(body_torque), _p(qacc), _p(cf))
+        i = self._in
+        qacc, cf = self._out(18), self._out(NB, 3)
+        r = self._l.ref_forward_bw(*self._refs(), _p(i(mass_scale)), _p(i(com_off)), _p(i(foot_mat)), _p(i(root)), _p(i(q)), _p(i(qd)), _p(i(tau)),
+                                   _p(i(body_force)), _p(i(body_torque)), _p(qacc), _p(cf))
         if r:
             raise RuntimeError("ref_forward_bw failed")
-        return qacc, cf
+        return self._wide(qacc), self._wide(cf)
 
     def step_bw(self, root, q, qd, tau, body_force=None, body_torque=None, mass_scale=None, com_off=None, foot_mat=None):
         """One gym.simulate (t1.py:451) in place on float64 root[13], q[12], qd[12] with per-body applied forces. Returns contact forces."""
-        assert root.dtype == np.float64 and q.dtype == np.float64 and qd.dtype == np.float64
-        tau, body_force, body_torque, mass_scale, com_off, foot_mat = map(_f64, (tau, body_force, body_torque, mass_scale, com_off, foot_mat))
-        cf = np.zeros((NB, 3))
-        r = lib().ref_step_bw(C.byref(self.model), C.byref(self.phys), C.byref(self.terrain), _p(mass_scale), _p(com_off), _p(foot_mat),
-                              _p(root), _p(q), _p(qd), _p(tau), _p(body_force), _p(body_torque), _p(cf))
+        i = self._in
+        st = (root, q, qd)
+        w = self._inplace(st)
+        cf = self._out(NB, 3)
+        r = self._l.ref_step_bw(*self._refs(), _p(i(mass_scale)), _p(i(com_off)), _p(i(foot_mat)), _p(w[0]), _p(w[1]), _p(w[2]), _p(i(tau)),
+                                _p(i(body_force)), _p(i(body_torque)), _p(cf))
         if r:
             raise RuntimeError("ref_step_bw failed")
-        return cf
+        self._writeback(st, w)
+        return self._wide(cf)
 
     def body_states(self, root, q, qd):
         """Rigid-body state rows [13,13] (t1.py:220): pos, quat xyzw (w >= 0), lin vel of the origin, ang vel, world frame."""
-        root, q, qd = _f64(root), _f64(q), _f64(qd)
-        out = np.zeros((NB, 13))
-        lib().ref_body_states(C.byref(self.model), _p(root), _p(q), _p(qd), _p(out))
-        return out
+        out = self._out(NB, 13)
+        self._l.ref_body_states(C.byref(self.model), _p(self._in(root)), _p(self._in(q)), _p(self._in(qd)), _p(out))
+        return self._wide(out)
 
     def substeps_batch(self, decimation, mass_scale, com_off, foot_mat, kp, kd, fric, tau_limit, root, q, qd, targets, last_targets,
                        delay, base_wrench):
         """Decimation loop for n envs, in place on root[n,13], q[n,12], qd[n,12], last_targets[n,12] (float64)."""
         n = root.shape[0]
-        for a in (root, q, qd, last_targets):
-            assert a.dtype == np.float64 and a.flags.c_contiguous
-        mass_scale, com_off, foot_mat, kp, kd, fric = map(_f64, (mass_scale, com_off, foot_mat, kp, kd, fric))
-        tau_limit, targets, base_wrench = _f64(tau_limit), _f64(targets), _f64(base_wrench)
+        i = self._in
+        st = (root, q, qd, last_targets)
+        w = self._inplace(st)
         delay = np.ascontiguousarray(delay, dtype=np.int32)
-        tm = np.zeros((n, ND))
-        cf = np.zeros((n, NB, 3))
-        r = lib().ref_substeps_batch(C.byref(self.model), C.byref(self.phys), C.byref(self.terrain), int(decimation), int(n),
-                                     _p(mass_scale), _p(com_off), _p(foot_mat), _p(kp), _p(kd), _p(fric), _p(tau_limit), _p(root), _p(q),
-                                     _p(qd), _p(targets), _p(last_targets), _p(delay), _p(base_wrench), _p(tm), _p(cf))
+        tm, cf = self._out(n, ND), self._out(n, NB, 3)
+        r = self._l.ref_substeps_batch(*self._refs(), int(decimation), int(n), _p(i(mass_scale)), _p(i(com_off)), _p(i(foot_mat)), _p(i(kp)), _p(i(kd)),
+                                       _p(i(fric)), _p(i(tau_limit)), _p(w[0]), _p(w[1]), _p(w[2]), _p(i(targets)), _p(w[3]), _p(delay), _p(i(base_wrench)),
+                                       _p(tm), _p(cf))
         if r:
             raise RuntimeError("ref_substeps_batch failed")
-        return tm, cf
+        self._writeback(st, w)
+        return self._wide(tm), self._wide(cf)
