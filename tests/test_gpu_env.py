@@ -203,9 +203,9 @@ def test_body_contacts_collision_reward_and_contact_termination_match_oracle():
     root[:, 7:] = 0.0
     env.set_field("root_states", torch.tensor(root, dtype=torch.float32))
     env.common_step_counter = 7
-    # lying robots on explicit (non-implicit) sphere contacts are the stiffest states this build simulates: wider state tolerances than for a
-    # walking robot, and the same rule: whatever is outside has to be explained
-    sp = StepParity(cfg, env, ref, max_explained_frac=0.05, state_tol={"root": 5e-3, "dof_pos": 5e-3, "dof_vel": 2e-2, "torques": 1e-2, "obs": 1e-2, "priv": 1e-2})
+    # lying robots on explicit (non-implicit) sphere contacts are the stiffest states this build simulates: the same tolerances as for a walking
+    # robot, the same rule (whatever is outside has to be explained), a little more room for explained cases
+    sp = StepParity(cfg, env, ref, max_explained_frac=0.03)
     coll_seen, term_seen, flags_bad, coll_diff = 0, 0, 0, 0
     for s in range(4):
         sp.begin()
