@@ -37,6 +37,10 @@ class ModelDesc(C.Structure):
     ]
 
 
+class AssetOptions(C.Structure):
+    _fields_ = [("collapse_fixed_joints", C.c_int32), ("body_contacts", C.c_int32), ("foot_names", C.c_char_p * 2), ("feet_edge_pos", C.c_float * 3 * 4)]
+
+
 class Rand(C.Structure):
     _fields_ = [("mode", C.c_int32), ("a", C.c_float), ("b", C.c_float)]
 
@@ -76,7 +80,7 @@ class EnvCfg(C.Structure):
 HEAD_SCRATCH_FLOATS = 768 * 1720  # BG_HEAD_SCRATCH_FLOATS
 
 SYMBOLS = [
-    "bg_model_create", "bg_model_get", "bg_model_destroy", "bg_env_create", "bg_env_destroy", "bg_env_set_heightfield",
+    "bg_model_create", "bg_model_get", "bg_model_destroy", "bg_model_load_urdf", "bg_model_body_name", "bg_model_dof_name", "bg_model_find_body", "bg_env_create", "bg_env_destroy", "bg_env_set_heightfield",
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
     "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
     "bg_env_forward_dynamics", "bg_sim_bind_state", "bg_sim_set_actuation", "bg_sim_apply_body_wrench_local", "bg_sim_simulate",
@@ -103,6 +107,10 @@ def load():
     sig = {
         "bg_model_create": (i32, [C.POINTER(ModelDesc), C.POINTER(vp)]),
         "bg_model_get": (i32, [vp, C.POINTER(ModelDesc)]),
+        "bg_model_load_urdf": (i32, [C.c_char_p, C.POINTER(AssetOptions), C.POINTER(vp)]),
+        "bg_model_body_name": (C.c_char_p, [vp, i32]),
+        "bg_model_dof_name": (C.c_char_p, [vp, i32]),
+        "bg_model_find_body": (i32, [vp, C.c_char_p]),
         "bg_model_destroy": (None, [vp]),
         "bg_env_create": (i32, [C.POINTER(EnvCfg), vp, C.POINTER(vp)]),
         "bg_env_destroy": (None, [vp]),

@@ -120,6 +120,23 @@ typedef struct {
 
 /* ---- model (replaces gym.load_asset and the asset queries, t1.py:54-108) */
 int bg_model_create(const bg_model_desc* desc, bg_model** out);
+/* gym.load_asset(sim, root, file, asset_options) with collapse_fixed_joints (envs/t1.py:39-54, envs/T1.yaml:61-83) for hosts without the Python
+ * loader: parses the URDF at `path`, folds links behind fixed joints into their parents (masses, centres of mass, inertias, collision
+ * primitives), orders bodies / DoFs depth-first like Isaac Gym and fills the flat model, including the contact spheres of the non-foot
+ * collision primitives.  foot_names = cfg asset.foot_names (their boxes are the sole-corner contacts, not spheres), feet_edge_pos = cfg
+ * asset.feet_edge_pos.  The same algorithm as booster_gym_amd/utils/urdf.py (tests/test_host_logic.py compares the two on the same files). */
+typedef struct {
+    int32_t collapse_fixed_joints;  /* envs/T1.yaml:67 */
+    int32_t body_contacts;          /* 0: no contact spheres (feet-only contact) */
+    const char* foot_names[2];      /* envs/T1.yaml:78 */
+    float feet_edge_pos[4][3];      /* envs/T1.yaml:79-82 */
+} bg_asset_options;
+int bg_model_load_urdf(const char* path, const bg_asset_options* options, bg_model** out);
+/* gym.get_asset_rigid_body_names / get_asset_dof_names / find_asset_rigid_body_index (t1.py:57,85,92-106); NULL / -1 when out of range or
+ * when the model was made by bg_model_create (no names).  Counts, limits and efforts (t1.py:55-67): bg_model_get. */
+const char* bg_model_body_name(const bg_model* m, int32_t i);
+const char* bg_model_dof_name(const bg_model* m, int32_t j);
+int32_t bg_model_find_body(const bg_model* m, const char* name);
 int bg_model_get(const bg_model* m, bg_model_desc* out);
 void bg_model_destroy(bg_model* m);
 

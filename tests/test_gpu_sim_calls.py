@@ -40,15 +40,19 @@ def test_simulate_matches_oracle_step(flat_model, contact, tol):
     bt = rng.normal(size=(n, 13, 3)) * 2.0
     dev = env.device
     f32 = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
-    root_t, dof_t = gym.acquire_actor_root_state_tensor(), gym.acquire_dof_state_tensor().view(n, 12, 2)
-    contact_t, body_t = gym.acquire_net_contact_force_tensor().view(n, 13, 3), gym.acquire_rigid_body_state_tensor().view(n, 13, 13)
+    from booster_gym_amd.envs.gym_calls import gymapi, gymtorch
+
+    sim = gym.sim
+    root_t, dof_t = gymtorch.wrap_tensor(gym.acquire_actor_root_state_tensor(sim)), gymtorch.wrap_tensor(gym.acquire_dof_state_tensor(sim)).view(n, 12, 2)
+    contact_t = gymtorch.wrap_tensor(gym.acquire_net_contact_force_tensor(sim)).view(n, 13, 3)
+    body_t = gymtorch.wrap_tensor(gym.acquire_rigid_body_state_tensor(sim)).view(n, 13, 13)
     root_t.copy_(f32(root)); dof_t[..., 0] = f32(q); dof_t[..., 1] = f32(qd)
-    gym.set_dof_actuation_force_tensor(f32(tau))
-    gym.apply_rigid_body_force_tensors(f32(bf), f32(bt), "LOCAL_SPACE")
-    gym.simulate()
+    gym.set_dof_actuation_force_tensor(sim, gymtorch.unwrap_tensor(f32(tau)))
+    gym.apply_rigid_body_force_tensors(sim, gymtorch.unwrap_tensor(f32(bf)), gymtorch.unwrap_tensor(f32(bt)), gymapi.LOCAL_SPACE)
+    gym.simulate(sim)
     got1 = (root_t.cpu().numpy().astype(np.float64), dof_t.cpu().numpy().astype(np.float64), contact_t.cpu().numpy().astype(np.float64),
             body_t.cpu().numpy().astype(np.float64))
-    gym.simulate()  # applied forces were consumed by the first simulate; the actuation persists
+    gym.simulate(sim)  # applied forces were consumed by the first simulate; the actuation persists
     got2 = (root_t.cpu().numpy().astype(np.float64), dof_t.cpu().numpy().astype(np.float64))
 
     r32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
@@ -111,25 +115,54 @@ def test_decimation_loop_on_gym_calls_equals_fused_step(flat_model):
     default = env.default_dof_pos.view(1, 12)
     actions = (0.5 * torch.randn(n, 12, generator=g)).to(dev)
 
-    # ---- granular: the reference's loop on gym calls
-    root_t, dof_t = gym.acquire_actor_root_state_tensor(), gym.acquire_dof_state_tensor().view(n, 12, 2)
-    root_t.copy_(root0); dof_t[..., 0] = q0; dof_t[..., 1] = qd0
+    # ---- granular: the reference's own lines (t1.py:203-220, 439-456, 522-527) with only `gym`, `sim`, `gymtorch`, `gymapi` rebound
+    from booster_gym_amd.envs.gym_calls import gymapi, gymtorch
+
+    class Task:  # stands for the reference's T1 instance: attribute names as in t1.py
+        pass
+
+    self = Task()
+    self.gym, self.sim, self.cfg, self.num_envs, self.num_bodies = gym, gym.sim, cfg, n, 13
+    actor_root_state = self.gym.acquire_actor_root_state_tensor(self.sim)        # t1.py:203
+    dof_state_tensor = self.gym.acquire_dof_state_tensor(self.sim)               # t1.py:204
+    self.gym.refresh_dof_state_tensor(self.sim)                                  # t1.py:208-212
+    self.gym.refresh_actor_root_state_tensor(self.sim)
+    self.gym.refresh_net_contact_force_tensor(self.sim)
+    self.gym.refresh_dof_force_tensor(self.sim)
+    self.gym.refresh_rigid_body_state_tensor(self.sim)
+    self.root_states = gymtorch.wrap_tensor(actor_root_state)                    # t1.py:215-218
+    self.dof_state = gymtorch.wrap_tensor(dof_state_tensor)
+    self.dof_pos = self.dof_state.view(self.num_envs, 12, 2)[..., 0]
+    self.dof_vel = self.dof_state.view(self.num_envs, 12, 2)[..., 1]
+    root_t, dof_t = self.root_states, self.dof_state.view(n, 12, 2)
+    # start state through the indexed setters (t1.py:323-325, 341)
+    self.root_states.copy_(root0); self.dof_pos.copy_(q0); self.dof_vel.copy_(qd0)
+    env_ids_int32 = torch.arange(n, dtype=torch.int32, device=dev)
+    self.gym.set_dof_state_tensor_indexed(self.sim, gymtorch.unwrap_tensor(self.dof_state), gymtorch.unwrap_tensor(env_ids_int32), len(env_ids_int32))
+    self.gym.set_actor_root_state_tensor(self.sim, gymtorch.unwrap_tensor(self.root_states))
     clip = cfg["normalization"]["clip_actions"]
-    target = default + cfg["control"]["action_scale"] * torch.clip(actions, -clip, clip)
-    forces = torch.zeros(n, 13, 3, device=dev); torques = torch.zeros(n, 13, 3, device=dev)
-    forces[:, 0] = push[:, :3]; torques[:, 0] = push[:, 3:]
-    gym.apply_rigid_body_force_tensors(forces, torques, "LOCAL_SPACE")
+    self.actions = torch.clip(actions, -clip, clip)
+    dof_targets = default + cfg["control"]["action_scale"] * self.actions      # t1.py:441-442
+    self.pushing_forces = torch.zeros(n, 13, 3, device=dev); self.pushing_torques = torch.zeros(n, 13, 3, device=dev)
+    self.pushing_forces[:, 0] = push[:, :3]; self.pushing_torques[:, 0] = push[:, 3:]
+    self.gym.apply_rigid_body_force_tensors(                                     # t1.py:522-527
+        self.sim,
+        gymtorch.unwrap_tensor(self.pushing_forces),
+        gymtorch.unwrap_tensor(self.pushing_torques),
+        gymapi.LOCAL_SPACE,
+    )
     tsum = torch.zeros(n, 12, device=dev)
-    for s in range(cfg["control"]["decimation"]):
-        last_tgt = torch.where(delay == s, target, last_tgt)
-        t = kp * (last_tgt - dof_t[..., 0]) - kd * dof_t[..., 1]
-        t = t - torch.minimum(fric, t.abs()) * torch.sign(t)
-        t = torch.clip(t, -limit, limit)
-        tsum += t
-        gym.set_dof_actuation_force_tensor(t)
-        gym.simulate()
-        gym.fetch_results(True)
-        gym.refresh_dof_state_tensor()
+    for i in range(cfg["control"]["decimation"]):                                # t1.py:444-456
+        last_tgt = torch.where(delay == i, dof_targets, last_tgt)                # t1.py:445
+        dof_torques = kp * (last_tgt - self.dof_pos) - kd * self.dof_vel
+        friction = torch.min(fric, dof_torques.abs()) * torch.sign(dof_torques)
+        dof_torques = torch.clip(dof_torques - friction, min=-limit, max=limit)
+        tsum += dof_torques
+        self.gym.set_dof_actuation_force_tensor(self.sim, gymtorch.unwrap_tensor(dof_torques))
+        self.gym.simulate(self.sim)
+        self.gym.fetch_results(self.sim, True)
+        self.gym.refresh_dof_state_tensor(self.sim)
+        self.gym.refresh_dof_force_tensor(self.sim)
     # ---- fused
     _, _, done, _ = env.step(actions)
     keep = ~done.bool()
@@ -154,17 +187,28 @@ def test_write_back_and_errors(flat_model):
     with pytest.raises(RuntimeError, match="bg_sim_bind_state"):
         _lib.check(env0._lib.bg_sim_simulate(env0._env, None), "bg_sim_simulate")
     cfg, env, gym = _make(n)
+    from booster_gym_amd.envs.gym_calls import gymapi
+
+    sim = gym.sim
     with pytest.raises(ValueError):
-        gym.apply_rigid_body_force_tensors(torch.zeros(n, 13, 3), None, "ENV_SPACE")
+        gym.apply_rigid_body_force_tensors(sim, torch.zeros(n, 13, 3), None, gymapi.ENV_SPACE)
     with pytest.raises(ValueError):
-        gym.set_dof_actuation_force_tensor(torch.zeros(n, 11))
-    root_t = gym.acquire_actor_root_state_tensor()
-    body_t = gym.acquire_rigid_body_state_tensor().view(n, 13, 13)
+        gym.set_dof_actuation_force_tensor(sim, torch.zeros(n, 11))
+    with pytest.raises(TypeError):  # the pre-round-2 call shape (no sim handle) is an error, not a silent mis-binding
+        gym.set_dof_actuation_force_tensor(torch.zeros(n, 12))
+    # asset queries of t1.py:54-59, 85-108
+    asset = gym.load_asset(sim, "resources", "T1/T1_locomotion.urdf", None)
+    assert gym.get_asset_dof_count(asset) == 12 and gym.get_asset_rigid_body_count(asset) == 13
+    assert gym.get_asset_dof_names(asset)[3] == "Left_Knee_Pitch" and gym.find_asset_rigid_body_index(asset, "Trunk") == 0
+    props = gym.get_asset_dof_properties(asset)
+    assert abs(float(props["effort"][3]) - 60.0) < 1e-6 and float(props["lower"][3]) == 0.0
+    root_t = gym.acquire_actor_root_state_tensor(sim)
+    body_t = gym.acquire_rigid_body_state_tensor(sim).view(n, 13, 13)
     mine = root_t.clone()
     mine[:, 0] = torch.arange(n, device=mine.device, dtype=torch.float32)
     mine[:, 2] = 0.72
     ids = torch.tensor([3, 10, 63], dtype=torch.int32, device=mine.device)
-    gym.set_actor_root_state_tensor_indexed(mine, ids, 3)
+    gym.set_actor_root_state_tensor_indexed(sim, mine, ids, 3)
     torch.cuda.synchronize()
     assert root_t[3, 0] == 3 and root_t[10, 0] == 10 and root_t[63, 0] == 63 and root_t[4, 0] == 0
     assert torch.equal(body_t[:, 0, :3], root_t[:, :3])  # trunk row re-derived

@@ -461,3 +461,135 @@ def test_curriculum_grid_sync_after_resume_two_ranks():
         assert wrong_err > 0.1  # the failure mode the fix removes
         assert abs(d34 - 0.25) < 1e-6 and v00 == 1.0 and abs(total - expect_total) < 1e-5
         assert seed == 1234  # rank 0's draw everywhere
+
+
+def _synthetic_urdf(flat_model, path):
+    """A URDF of the T1 topology written from the flat model, with the things the loader must fold: the trunk split into a root link plus two
+    links behind FIXED joints (one of them rotated, one a chain of two), an inertial frame given with rpy, and a fixed sensor link on a shank."""
+    m = flat_model
+    L = ['<?xml version="1.0"?>', "<!-- generated by tests/test_host_logic.py -->", '<robot name="T1_synth">']
+
+    def link(name, mass, com, i6, rpy=(0, 0, 0), shapes=()):
+        L.append(f'  <link name="{name}">')
+        L.append(f'    <inertial><origin xyz="{com[0]} {com[1]} {com[2]}" rpy="{rpy[0]} {rpy[1]} {rpy[2]}"/><mass value="{mass}"/>')
+        L.append(f'      <inertia ixx="{i6[0]}" iyy="{i6[1]}" izz="{i6[2]}" ixy="{i6[3]}" ixz="{i6[4]}" iyz="{i6[5]}"/></inertial>')
+        for kind, size, pos in shapes:
+            geo = f'<box size="{size[0]} {size[1]} {size[2]}"/>' if kind == "box" else f'<cylinder radius="{size[0]}" length="{size[1]}"/>'
+            L.append(f'    <collision><origin xyz="{pos[0]} {pos[1]} {pos[2]}"/><geometry>{geo}</geometry></collision>')
+        L.append("  </link>")
+
+    def joint(name, typ, parent, child, xyz, rpy=(0, 0, 0), axis=None, lim=None):
+        L.append(f'  <joint name="{name}" type="{typ}"><parent link="{parent}"/><child link="{child}"/><origin xyz="{xyz[0]} {xyz[1]} {xyz[2]}" rpy="{rpy[0]} {rpy[1]} {rpy[2]}"/>')
+        if axis is not None:
+            L.append(f'    <axis xyz="{axis[0]} {axis[1]} {axis[2]}"/>')
+        if lim is not None:
+            L.append(f'    <limit lower="{lim[0]}" upper="{lim[1]}" velocity="{lim[2]}" effort="{lim[3]}"/>')
+        L.append("  </joint>")
+
+    shp = lambda b: [(s["type"], s["size"], s["pos"]) for s in m.shapes if s["body"] == b]
+    # trunk = 60 % root link + head (rotated fixed joint) + arm + hand (chain of fixed joints)
+    link("Trunk", 0.6 * m.mass[0], m.com[0], 0.6 * m.inertia[0], shapes=shp(0))
+    link("Head", 1.1, (0.01, 0.0, 0.05), (0.004, 0.005, 0.003, 1e-4, -2e-4, 5e-5), rpy=(0.1, -0.2, 0.3))
+    joint("Head_fixed", "fixed", "Trunk", "Head", (0.02, 0.0, 0.3), rpy=(0.0, 0.3, 0.5))
+    link("Arm", 1.7, (0.0, 0.05, -0.1), (0.01, 0.011, 0.002, 0, 0, 1e-4))
+    joint("Arm_fixed", "fixed", "Trunk", "Arm", (0.0, 0.2, 0.2), rpy=(0.4, 0.0, 0.0))
+    link("Hand", 0.4, (0.0, 0.0, -0.03), (5e-4, 5e-4, 2e-4, 0, 0, 0))
+    joint("Hand_fixed", "fixed", "Arm", "Hand", (0.0, 0.02, -0.25), rpy=(0.0, -0.1, 0.2))
+    ax = {1: (1, 0, 0), 2: (0, 1, 0), 3: (0, 0, 1)}
+    for b in range(1, 13):
+        link(m.body_names[b], m.mass[b], m.com[b], m.inertia[b], shapes=shp(b))
+        j = b - 1
+        joint(m.dof_names[j], "revolute", m.body_names[m.parent[b]], m.body_names[b], m.body_pos[b], axis=ax[int(m.joint_axis[b])],
+              lim=(m.dof_lower[j], m.dof_upper[j], m.dof_velocity[j], m.dof_effort[j]))
+        if b == 4:  # a massless-ish sensor frame on the left shank, folded into it
+            link("Shank_IMU", 0.05, (0.0, 0.0, 0.0), (1e-6, 1e-6, 1e-6, 0, 0, 0))
+            joint("Shank_IMU_fixed", "fixed", m.body_names[4], "Shank_IMU", (0.03, 0.0, -0.1))
+    L.append("</robot>")
+    open(path, "w").write("\n".join(L))
+
+
+def _load_urdf_c(path, collapse=1, feet=("left_foot_link", "right_foot_link"), body_contacts=1):
+    import ctypes as C
+
+    from booster_gym_amd import _lib
+
+    lib = _lib.load()
+    opt = _lib.AssetOptions()
+    opt.collapse_fixed_joints, opt.body_contacts = collapse, body_contacts
+    opt.foot_names[0], opt.foot_names[1] = feet[0].encode(), feet[1].encode()
+    edge = [[0.1215, 0.05, -0.03], [0.1215, -0.05, -0.03], [-0.1015, 0.05, -0.03], [-0.1015, -0.05, -0.03]]
+    for c in range(4):
+        for a in range(3):
+            opt.feet_edge_pos[c][a] = edge[c][a]
+    h = C.c_void_p()
+    rc = lib.bg_model_load_urdf(str(path).encode(), C.byref(opt), C.byref(h))
+    if rc != 0:
+        return rc, lib.bg_last_error().decode(), None, None
+    d = _lib.ModelDesc()
+    _lib.check(lib.bg_model_get(h, C.byref(d)))
+    names = ([lib.bg_model_body_name(h, i).decode() for i in range(d.num_bodies)], [lib.bg_model_dof_name(h, j).decode() for j in range(d.num_dofs)])
+    found = (lib.bg_model_find_body(h, b"Trunk"), lib.bg_model_find_body(h, b"right_foot_link"), lib.bg_model_find_body(h, b"nope"))
+    assert lib.bg_model_body_name(h, 99) is None
+    lib.bg_model_destroy(h)
+    return 0, d, names, found
+
+
+def _compare_c_and_python_models(d, names, py):
+    assert names[0] == list(py.body_names) and names[1] == list(py.dof_names)
+    assert list(d.parent) == list(py.parent) and list(d.joint_axis) == list(py.joint_axis)
+    f = lambda a: np.array([list(r) if hasattr(r, "__len__") else r for r in a], dtype=np.float64)
+    assert np.allclose(f(d.mass), py.mass, rtol=2e-7) and np.allclose(f(d.com), py.com, atol=1e-7) and np.allclose(f(d.body_pos), py.body_pos, atol=1e-7)
+    assert np.allclose(f(d.inertia), py.inertia, rtol=1e-6, atol=1e-8)
+    for k in ("dof_lower", "dof_upper", "dof_velocity", "dof_effort"):
+        assert np.allclose(f(getattr(d, k)), getattr(py, k), rtol=2e-7)
+    sph = py.contact_spheres(exclude_bodies=(py.find_body("left_foot_link"), py.find_body("right_foot_link")))
+    assert d.num_body_spheres == len(sph)
+    for k, (b, c, r) in enumerate(sph):
+        assert d.sphere_body[k] == b and np.allclose(list(d.sphere_pos[k]), c, atol=1e-7) and abs(d.sphere_radius[k] - r) < 1e-7
+
+
+def test_c_urdf_loader_matches_the_python_loader(flat_model, tmp_path):
+    """bg_model_load_urdf (the asset loader of the C ABI, t1.py:39-59) against booster_gym_amd.utils.urdf.load_urdf on the same file: fixed-joint
+    folding with rotated frames and chains, depth-first order, limits, contact spheres; and against the packaged flat model for the legs."""
+    from booster_gym_amd.utils.urdf import load_urdf
+
+    p = tmp_path / "t1_synth.urdf"
+    _synthetic_urdf(flat_model, p)
+    py = load_urdf(str(p), collapse_fixed_joints=True)
+    assert py.num_bodies == 13 and py.num_dofs == 12 and abs(py.mass[0] - (0.6 * flat_model.mass[0] + 1.1 + 1.7 + 0.4)) < 1e-9
+    rc, d, names, found = _load_urdf_c(p)
+    assert rc == 0, d
+    assert found == (0, 12, -1)
+    _compare_c_and_python_models(d, names, py)
+    # the legs are the packaged model's (nothing folded there except the IMU frame on body 4)
+    for b in (1, 2, 3, 5, 6, 7, 12):
+        assert abs(d.mass[b] - flat_model.mass[b]) < 1e-6 and np.allclose(list(d.inertia[b]), flat_model.inertia[b], rtol=1e-6, atol=1e-9)
+    assert abs(d.mass[4] - (flat_model.mass[4] + 0.05)) < 1e-6
+    # without collapsing, the fixed joints remain: refused with the offending joint, like the Python loader
+    rc, msg, _, _ = _load_urdf_c(p, collapse=0)
+    assert rc == -1 and "Head_fixed" in msg and "fixed" in msg
+    # malformed / unsupported inputs fail with the offending name, like the Python loader's ValueError
+    bad = open(p).read().replace('<axis xyz="0 1 0"/>', '<axis xyz="0 0.7 0.7"/>', 1)
+    pb = tmp_path / "bad_axis.urdf"; pb.write_text(bad)
+    rc, msg, _, _ = _load_urdf_c(pb)
+    assert rc == -1 and "axis" in msg
+    pt = tmp_path / "truncated.urdf"; pt.write_text(open(p).read()[:2000])
+    rc, msg, _, _ = _load_urdf_c(pt)
+    assert rc == -1 and "XML" in msg
+    rc, msg, _, _ = _load_urdf_c(tmp_path / "missing.urdf")
+    assert rc == -3 and "cannot open" in msg
+
+
+def test_c_urdf_loader_on_the_reference_asset(flat_model):
+    """The real T1 URDF (only where the reference tree is present: this container, not the GPU box): both loaders against the packaged flat model."""
+    path = "/root/reference/resources/T1/T1_locomotion.urdf"
+    if not os.path.isfile(path):
+        pytest.skip("reference tree not present")
+    from booster_gym_amd.utils.urdf import load_urdf
+
+    py = load_urdf(path, collapse_fixed_joints=True)
+    rc, d, names, found = _load_urdf_c(path)
+    assert rc == 0, d
+    _compare_c_and_python_models(d, names, py)
+    assert names[0] == list(flat_model.body_names) and abs(sum(d.mass) - 31.6144) < 1e-3
+    assert np.allclose([list(r) for r in d.inertia], flat_model.inertia, rtol=1e-5, atol=1e-8)
