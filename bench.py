@@ -52,6 +52,23 @@ ABA_BYTES = 4 * (13 + 12 + 12 + 12 + 6 + 18 + 6 + 58)  # forward_dynamics_kernel
 from booster_gym_amd import _lib  # noqa: E402  (raw ABI calls for the kernel-level timings)
 
 
+PMC_TAG = "r02"
+PMC_SOURCE = (f"profiles/{PMC_TAG}_bench_pmc.json / profiles/{PMC_TAG}_env_pmc.json: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes of "
+              "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra` and `tools/prof_env.py 4096 plane` (tools/profile.sh); "
+              "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE for the 16-byte-per-lane MFMA layer kernels (the guide's gfx950 correction), FETCH_SIZE + WRITE_SIZE otherwise")
+
+
+def pmc_traffic(kernel_prefix, which="bench"):
+    """HBM bytes per launch of a kernel from the committed PMC summary of this round (None if the profile is absent)."""
+    path = os.path.join(ROOT, "profiles", f"{PMC_TAG}_{which}_pmc.json")
+    try:
+        ks = json.load(open(path))["kernels"]
+        k = next(v for name, v in ks.items() if name.startswith(kernel_prefix))
+        return float(k["hbm_bytes"])
+    except (OSError, StopIteration, KeyError, ValueError):
+        return None
+
+
 def aba_roofline(n=1 << 20, launches=30):
     """HBM roofline of the ABA kernel on a FULL chip: forward_dynamics_kernel (one substep's accelerations per launch) on n synthetic states
     (joints around the default pose, unit-normal joint velocities, torques within the effort limits), HIP events on the
@@ -86,22 +103,24 @@ def aba_roofline(n=1 << 20, launches=30):
             "note": "VALU-issue bound: 88% of the issue slots at 1M envs (profiles/r01_d_aba_pmc.json); curve over N in profiles/r01_d_aba_roofline_curve.json"}
 
 
-def cpu_baseline(n_sample=2048):
-    """CPU restatement baseline ("port"), timed in a child process that never touches the GPU (oracle/cpu_baseline.py)."""
+def cpu_baseline(n_envs=4096):
+    """CPU restatement baseline ("port"), timed in a child process that never touches the GPU (oracle/cpu_baseline.py): the bench's own
+    workload (n_envs envs x 24 env-steps with task logic + 20 full-batch mini-epochs) on all host cores of this GPU's share, and the same
+    on ONE core at a quarter of the envs (report single-thread and all-core)."""
     import subprocess
 
     def run(n, threads=None):
         env = dict(os.environ)
         if threads:
             env["BG_CPU_THREADS"] = str(threads)
-        r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(n)], cwd=ROOT, capture_output=True, text=True, timeout=600, env=env)
+        r = subprocess.run([sys.executable, "-m", "oracle.cpu_baseline", str(n)], cwd=ROOT, capture_output=True, text=True, timeout=900, env=env)
         if r.returncode != 0:
             raise RuntimeError(r.stderr[-400:])
         return json.loads(r.stdout.strip().splitlines()[-1])
 
-    out = run(n_sample)  # all cores of this GPU's share of the host (SURVEY section 8d: report single-thread and all-core)
-    one = run(max(128, n_sample // 16), threads=1)
-    out["single_thread"] = {"value": one["value"], "unit": one["unit"], "cores": 1, "sample": one["sample"]}
+    out = run(n_envs)
+    one = run(max(1024, n_envs // 4), threads=1)
+    out["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "num_envs", "phase_s", "sample")}
     return out
 
 
@@ -186,7 +205,9 @@ def main():
         step_events.append((e0, e1))
 
     runner.env.step_to = timed_step_to
-    runner._critic_tr.timed_layer = 1  # critic 256 -> 256 hidden layer: the single largest kernel of the update
+    # critic layer 1 (256 -> 256): the single largest kernel of the update; critic layer 2 (256 -> 128): the symbol with the largest TOTAL time
+    # (mlp_fwd_kernel<256,1,1>, shared with the actor's layer 1)
+    runner._critic_tr.timed_layer = (1, 2)
     if world > 1:
         runner.dp.timed_events = []  # HIP events around the gradient-bucket all-reduce of every mini-epoch
     barrier()
@@ -217,7 +238,18 @@ def main():
         stats = runner.env.episode_stats(reset=False).cpu().tolist()
         # dominant kernel by GPU time (rocprof, profiles/): the hand-written fused Linear+ELU layer mlp_fwd_kernel<256,1>; its largest instance
         # (critic 256 -> 256, [rows x 256] x [256 x 256]) is timed inside the timed region with HIP events on the stream it is launched on
-        ev = runner._critic_tr.timed_events
+        ev_all = runner._critic_tr.timed_events
+        ev = [e for e in ev_all if e[5] == 1]
+        ev2 = [e for e in ev_all if e[5] == 2]
+        top_by_time = None
+        if ev2:
+            us2 = sum(a.elapsed_time(b) for a, b, *_ in ev2) / len(ev2) * 1e3
+            r2_, k2_, n2_ = ev2[0][2], ev2[0][3], ev2[0][4]
+            fl2 = 2.0 * r2_ * k2_ * n2_
+            top_by_time = {"kernel": f"mlp_fwd_kernel<256,1,1>: fused Linear+bias+ELU, critic layer 3, [{r2_}x{k2_}]x[{k2_}x{n2_}] (the symbol with the largest total "
+                                     "time in the rocprofv3 summary: the actor's layer 2 runs on it too)", "bound": "mfma", "achieved": fl2 / (us2 * 1e-6) / 1e12,
+                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "avg_launch_us": us2,
+                           "algorithmic_flops_per_launch": fl2, "traffic": pmc_traffic("mlp_fwd_kernel<256, 1, 1>")}
         if ev:
             gemm_us = sum(a.elapsed_time(b) for a, b, *_ in ev) / len(ev) * 1e3
             rows_g, kg, ng = ev[0][2], ev[0][3], ev[0][4]
@@ -256,15 +288,9 @@ def main():
             solo_us = gemm_us
         gemm_flop = 2.0 * rows_g * kg * ng
         gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "r01_e_env_pmc.json")
-        if N == 4096 and os.path.isfile(pmc):  # PMC counters are collected offline by tools/profile.sh (separate rocprofv3 passes)
-            try:
-                ks = json.load(open(pmc))["kernels"]
-                k = next(v for name, v in ks.items() if name.startswith("env_step_kernel"))  # "env_step_kernel<false, false>": the plain instantiation
-                traffic = (k["FETCH_SIZE"]["mean"] + k["WRITE_SIZE"]["mean"]) * 1024.0
-            except (StopIteration, KeyError, ValueError):
-                traffic = None
+        # HBM traffic per launch comes from PMC counters, which rocprofv3 collects in separate passes of the same command (tools/profile.sh
+        # -> profiles/<PMC_TAG>_*_pmc.json, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes); the JSON line names the file it cites
+        traffic = pmc_traffic("env_step_kernel", which="env") if N == 4096 else None
         out = {
             "metric": "env-steps/sec (whole node), PPO rollout+update, T1 4096 envs/GPU",
             "value": world * N * T * args.steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -274,19 +300,22 @@ def main():
                        "envs_per_gpu": N, "parallelism": f"dp{world}"},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms, "all_reduce_ms": ar_ms},
-            "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF, "traffic": None,
+            "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF,
+                         "traffic": pmc_traffic("mlp_fwd_kernel<256, 1, 2>") if rows_g == (T + 1) * 4096 else None, "traffic_source": PMC_SOURCE,
                          "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop,
                          "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,
                                               "frac": gemm_flop / (solo_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}},
             "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",
                                   "achieved": sim_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS, "traffic": traffic,
-                                  "avg_launch_us": step_ms * 1e3, "algorithmic_bytes_per_launch": env_bytes,
+                                  "traffic_source": PMC_SOURCE, "avg_launch_us": step_ms * 1e3, "algorithmic_bytes_per_launch": env_bytes,
                                   "note": "issue-latency-bound at 128 waves: SQ counters in profiles/ show VALU busy 73% of wave cycles at 4 cycles/instruction"},
             "roofline_update": {"bound": "mfma", "achieved": flops / (upd_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": flops / (upd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                                 "note": "all actor+critic GEMM flops of the update phase / update-phase wall time (which also holds GAE, loss, ELU, Adam)"},
             "nonfinite_resets": stats[-1],
         }
+        if top_by_time is not None:
+            out["roofline_top_by_time"] = top_by_time
         if args.no_extra:
             out["roofline"].pop("alone_on_the_gpu", None)
         if world == 1 and not args.no_extra:
@@ -298,7 +327,7 @@ def main():
         if not args.no_cpu_baseline and world == 1:
             try:
                 log("cpu baseline ...")
-                out["cpu_baseline"] = cpu_baseline()
+                out["cpu_baseline"] = cpu_baseline(N)
                 log("cpu baseline done")
             except Exception as ex:  # the bench line must still print
                 out["cpu_baseline"] = {"error": repr(ex)}

@@ -116,7 +116,7 @@ class MLPTrainer:
                 w, k_in = self.w0pad, self._kin
             if i < last and self._fusable(k_in, n_out):
                 # hand-written fp32-MFMA layer with bias + ELU in the epilogue (bg_mlp.hip)
-                timed = self.timed_layer == i
+                timed = self.timed_layer is not None and (i == self.timed_layer or (isinstance(self.timed_layer, (tuple, list, set)) and i in self.timed_layer))
                 if timed:  # bench.py: HIP events on the launch stream around this one kernel
                     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     e0.record()
@@ -124,7 +124,7 @@ class MLPTrainer:
                                                     stream), "bg_mlp_layer_forward")
                 if timed:
                     e1.record()
-                    self.timed_events.append((e0, e1, h.shape[0], k_in, n_out))
+                    self.timed_events.append((e0, e1, h.shape[0], k_in, n_out, i))
                 h = self.acts[i]
                 continue
             torch.addmm(l.bias, h, w.t(), out=self.acts[i])

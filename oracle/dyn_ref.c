@@ -686,6 +686,12 @@ void ref_body_states(const ref_model_t *m, const double *root, const double *q, 
     }
 }
 
+/* the same for n envs (env-major arrays), OpenMP over envs: the task oracle's feet state and the CPU baseline */
+void ref_body_states_batch(const ref_model_t *m, int n, const double *root, const double *q, const double *qd, double *out) {
+#pragma omp parallel for schedule(static)
+    for (int e = 0; e < n; e++) ref_body_states(m, root + 13 * e, q + ND * e, qd + ND * e, out + (size_t)NB * 13 * e);
+}
+
 /* ------------------------------------------------------------------ decimation loop with the PD actuator
  * (envs/t1.py:443-456).  targets: this step's dof targets; last_targets in/out; delay: switch-over substep.
  * torques_mean out = mean clipped torque over the substeps (t1.py:449,456).  The base wrench acts on the

@@ -292,6 +292,13 @@ class DynRef:
         self._l.ref_body_states(C.byref(self.model), _p(self._in(root)), _p(self._in(q)), _p(self._in(qd)), _p(out))
         return self._wide(out)
 
+    def body_states_batch(self, root, q, qd):
+        """body_states for n envs at once: [n,13,13]."""
+        n = root.shape[0]
+        out = self._out(n, NB, 13)
+        self._l.ref_body_states_batch(C.byref(self.model), int(n), _p(self._in(root)), _p(self._in(q)), _p(self._in(qd)), _p(out))
+        return self._wide(out)
+
     def substeps_batch(self, decimation, mass_scale, com_off, foot_mat, kp, kd, fric, tau_limit, root, q, qd, targets, last_targets,
                        delay, base_wrench):
         """Decimation loop for n envs, in place on root[n,13], q[n,12], qd[n,12], last_targets[n,12] (float64)."""

@@ -337,12 +337,9 @@ class T1Ref:
 
     # -- helpers
     def _feet(self):
-        pos, quat = np.zeros((self.n, 2, 3)), np.zeros((self.n, 2, 4))
-        for e in range(self.n):
-            p, R = self.dyn.body_poses(self.root[e], self.q[e])
-            for f, b in enumerate((6, 12)):
-                pos[e, f], quat[e, f] = p[b], mat_to_quat(R[b])
-        return pos, quat
+        """Foot rows of the rigid-body state tensor (t1.py:529-531): world position and orientation (xyzw) of both foot links."""
+        bs = self.dyn.body_states_batch(self.root, self.q, self.qd)
+        return bs[:, (6, 12), 0:3].copy(), bs[:, (6, 12), 3:7].copy()
 
     def _r4(self, stream, step, so, env=None):
         return rand4(self.seed, self.env_ids if env is None else env, step, so + stream)
