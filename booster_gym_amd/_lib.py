@@ -73,6 +73,7 @@ class EnvCfg(C.Structure):
         ("terrain_type", C.c_int32), ("terrain_env_width", C.c_float), ("terrain_env_length", C.c_float), ("terrain_border", C.c_float),
         ("state_fp16", C.c_int32),
         ("body_gate_height", C.c_float), ("penalized_body_mask", C.c_int32), ("terminate_body_mask", C.c_int32),
+        ("exact_still_count", C.c_int32), ("same_step_curriculum", C.c_int32),
     ]
 
 

@@ -50,7 +50,7 @@ enum {
     F_EP_SUMS = 254,       // 27
     F_COUNT = 281
 };
-enum { I_EP_LEN = 0, I_CMD_TIME = 1, I_DELAY = 2, I_EP_STEPS = 3, I_CURR_LIN = 4, I_CURR_ANG = 5, I_COUNT = 6 };
+enum { I_EP_LEN = 0, I_CMD_TIME = 1, I_DELAY = 2, I_EP_STEPS = 3, I_CURR_LIN = 4, I_CURR_ANG = 5, I_RESAMPLED = 6, I_COUNT = 7 };  // I_RESAMPLED: this step resampled the env's command (exact-resampling modes)
 // global statistics accumulator: [0] finished episodes, [1] sum of their lengths, [2] sum reward, [3..28] sum of terms, [29] non-finite resets
 constexpr int STATS_COUNT = 4 + BG_NUM_REWARD_TERMS;  // last entry: resets caused by a non-finite state
 
@@ -101,6 +101,46 @@ BG_HD float pymod(float x, float m) {  // python / torch `%` (floor mod) for m >
     return r < 0.f ? r + m : r;
 }
 BG_HD float wrap_pi(float x) { return pymod(x + 3.14159265358979f, 6.28318530717959f) - 3.14159265358979f; }
+
+// t1.py:415-435: multinomial draw of a curriculum grid cell from `grid` (values clamped at 1 like curriculum_prob.clamp_), then the command inside
+// the cell.  cr.u[0] picks the cell, cr.u[1..3] jitter.
+BG_HD void curriculum_draw(const bg_env_cfg& C, const float* grid, const Rand4& cr, float* cmd, int* lin_level, int* ang_level) {
+    const int ny = 2 * C.ang_vel_levels + 1, cells = (2 * C.lin_vel_levels + 1) * ny;
+    float total = 0.f;
+    for (int k = 0; k < cells; k++) total += fminf(grid[k], 1.0f);
+    float target = cr.u[0] * total, run = 0.f;
+    int idx = cells - 1;
+    for (int k = 0; k < cells; k++) {
+        run += fminf(grid[k], 1.0f);
+        if (run > target) { idx = k; break; }
+    }
+    *lin_level = idx % ny - C.lin_vel_levels; *ang_level = idx / ny - C.ang_vel_levels;
+    cmd[0] = ((float)*lin_level + (cr.u[1] - 0.5f)) * C.lin_vel_x_resolution;
+    cmd[1] = fabsf((float)*lin_level) * (2.0f * cr.u[2] - 1.0f) * C.lin_vel_y_resolution;
+    cmd[2] = ((float)*ang_level + (cr.u[3] - 0.5f)) * C.ang_vel_resolution;
+}
+
+// A keyed pseudo-random PERMUTATION of [0, K): 4-round Feistel network on the smallest even-width bit field covering K, cycle-walked back into
+// range.  perm(p) < m for position p selects exactly m of K positions, a random subset (the role of torch.randperm(K)[:m], t1.py:381).
+BG_HD uint32_t mix32(uint32_t x) { x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16; return x; }
+BG_HD uint32_t keyed_perm(uint32_t p, uint32_t K, uint32_t key) {
+    if (K <= 1u) return 0u;
+    uint32_t bits = 2u;
+    while (bits < 32u && (1u << bits) < K) bits += 2u;
+    const uint32_t hb = bits >> 1, hm = (1u << hb) - 1u;
+    uint32_t x = p;
+    for (int walk = 0; walk < 64; walk++) {
+        uint32_t L = x >> hb, R = x & hm;
+        for (uint32_t r = 0; r < 4u; r++) {
+            const uint32_t f = mix32(R ^ (key + r * 0x9E3779B9u)) & hm;
+            const uint32_t t = L ^ f;
+            L = R; R = t;
+        }
+        x = (L << hb) | R;
+        if (x < K) return x;
+    }
+    return p;  // unreachable in practice (each walk step lands in range with probability > 1/4)
+}
 
 // foot pose after the last substep (positions only)
 template <int I, class St>
@@ -493,38 +533,35 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
         pf_store.e[0] += sx; pf_store.e[1] += sy2;
     }
     // ------------------------------------------------------------ command resample (t1.py:362-389)
+    // Reference-exact modes (cfg.exact_still_count / cfg.same_step_curriculum): the parts of _resample_commands that couple envs -- which envs stand
+    // still (an exact count over the envs resampling in this step) and the curriculum draw from the grid as updated by THIS step's resets -- are
+    // left to resample_apply_kernel, which runs after this launch and patches commands, gait frequency and the command entries of the observation.
+    const bool defer_still = C.exact_still_count != 0, defer_curr = C.curriculum && C.same_step_curriculum != 0;
+    int resampled = 0;
     if (ep_len == cmd_time) {
+        resampled = 1;
         Rand4 c0 = rand4(C.seed, (uint32_t)e, step, so + RS_CMD0), c1 = rand4(C.seed, (uint32_t)e, step, so + RS_CMD1);
-        if (C.curriculum) {
+        if (C.curriculum && !defer_curr) {
             // t1.py:415-435: draw a grid cell ~ multinomial(curriculum_prob as of the start of this step), then jitter inside the cell.  The reference decodes
             // lin = idx % cols - L and ang = idx // cols - A although it updates prob[lin + L][ang + A] (a transposition); kept.
             Rand4 cr = rand4(C.seed, (uint32_t)e, step, so + RS_CURR);
-            const int ny = 2 * C.ang_vel_levels + 1, cells = (2 * C.lin_vel_levels + 1) * ny;
-            float total = 0.f;
-            for (int k = 0; k < cells; k++) total += fminf(E.curr_read[k], 1.0f);
-            float target = cr.u[0] * total, run = 0.f;
-            int idx = cells - 1;
-            for (int k = 0; k < cells; k++) {
-                run += fminf(E.curr_read[k], 1.0f);
-                if (run > target) { idx = k; break; }
-            }
-            const int lin_level = idx % ny - C.lin_vel_levels, ang_level = idx / ny - C.ang_vel_levels;
+            int lin_level, ang_level;
+            curriculum_draw(C, E.curr_read, cr, cmd, &lin_level, &ang_level);
             if (leg == 0 && valid) { II[(size_t)I_CURR_LIN * n + e] = lin_level; II[(size_t)I_CURR_ANG * n + e] = ang_level; }
-            cmd[0] = ((float)lin_level + (cr.u[1] - 0.5f)) * C.lin_vel_x_resolution;
-            cmd[1] = fabsf((float)lin_level) * (2.0f * cr.u[2] - 1.0f) * C.lin_vel_y_resolution;
-            cmd[2] = ((float)ang_level + (cr.u[3] - 0.5f)) * C.ang_vel_resolution;
-        } else {
+        } else if (!C.curriculum) {
             cmd[0] = C.cmd_lin_vel_x[0] + (C.cmd_lin_vel_x[1] - C.cmd_lin_vel_x[0]) * c0.u[0];
             cmd[1] = C.cmd_lin_vel_y[0] + (C.cmd_lin_vel_y[1] - C.cmd_lin_vel_y[0]) * c0.u[1];
             cmd[2] = C.cmd_ang_vel_yaw[0] + (C.cmd_ang_vel_yaw[1] - C.cmd_ang_vel_yaw[0]) * c0.u[2];
         }
         gait_f = C.cmd_gait_frequency[0] + (C.cmd_gait_frequency[1] - C.cmd_gait_frequency[0]) * c0.u[3];
-        if (c1.u[0] < C.still_proportion) { cmd[0] = cmd[1] = cmd[2] = 0.f; gait_f = 0.f; }  // per-env Bernoulli (reference: exact count via randperm)
+        // per-env Bernoulli (reference: exact count via randperm -> cfg.exact_still_count)
+        if (!defer_still && !defer_curr && c1.u[0] < C.still_proportion) { cmd[0] = cmd[1] = cmd[2] = 0.f; gait_f = 0.f; }
         int span = C.resample_steps[1] - C.resample_steps[0];
         int add = C.resample_steps[0] + (span > 0 ? (int)(c1.u[1] * (float)span) : 0);
         if (span > 0 && add >= C.resample_steps[1]) add = C.resample_steps[1] - 1;
         cmd_time += add;
     }
+    if ((defer_still || defer_curr) && leg == 0 && valid) II[(size_t)I_RESAMPLED * n + e] = resampled;
     // ------------------------------------------------------------ observations (t1.py:574-603)
     {
         Rand4 o0 = rand4(C.seed, (uint32_t)e, step, so + RS_OBS0), o1 = rand4(C.seed, (uint32_t)e, step, so + RS_OBS1), o2 = rand4(C.seed, (uint32_t)e, step, so + RS_OBS2);

@@ -33,6 +33,7 @@ struct bg_env {
     int n;
     float* f = nullptr;
     bg_half_bits* h = nullptr;  // fp16 slab of the dynamic state (cfg.state_fp16), else null
+    int* rs_counts = nullptr;     // [blocks of RS_BLOCK envs] envs resampled in this step (exact-resampling modes), else null
     unsigned* lowmask = nullptr;  // [blocks of 32 envs] envs left to the body-contact kernel (two-kernel scheme), null = no body spheres
     int32_t* i = nullptr;
     float* stats = nullptr;
@@ -142,6 +143,73 @@ __global__ __launch_bounds__(64) void env_step_body_kernel(EnvDev E, const float
         copy_out_rows(out, e0, min(ENVS_PER_BLOCK, E.n - e0), lowm, s_obs, s_priv);
         __syncthreads();
     }
+}
+
+// ------------------------------------------------------------------ reference-exact command resampling (cfg.exact_still_count / same_step_curriculum)
+// The two parts of _resample_commands (t1.py:362-389) that couple envs, as two small launches after the env step:
+//   resample_count_kernel   counts, per block of RS_BLOCK envs, the envs whose command was resampled in this step (I_RESAMPLED)
+//   resample_apply_kernel   position p of every such env in env order (block offsets from the counts + a scan inside the block), K = their number;
+//                           curriculum draw from the grid as it is NOW, i.e. after this step's resets have updated it (t1.py:305 precedes :365);
+//                           the env stands still iff keyed_perm(p) < int(still_proportion * K): exactly that many, a random subset (t1.py:381-383);
+//                           commands / gait frequency are written to the state and to entries 6..10 of the env's observation row.
+constexpr int RS_BLOCK = 256;
+__global__ __launch_bounds__(RS_BLOCK) void resample_count_kernel(EnvDev E, int* __restrict__ counts) {
+    __shared__ int s_cnt;
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
+    const int e = blockIdx.x * RS_BLOCK + threadIdx.x;
+    const int flag = e < E.n ? E.i[(size_t)I_RESAMPLED * E.n + e] : 0;
+    if (flag) atomicAdd(&s_cnt, 1);
+    __syncthreads();
+    if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
+}
+__global__ __launch_bounds__(RS_BLOCK) void resample_apply_kernel(EnvDev E, const int* __restrict__ counts, int nblocks, uint32_t step, int mode, float* __restrict__ obs) {
+    __shared__ int s_scan[RS_BLOCK];
+    __shared__ int s_off, s_total;
+    const bg_env_cfg& C = E.cfg;
+    const int n = E.n, e = blockIdx.x * RS_BLOCK + threadIdx.x;
+    const int flag = e < n ? E.i[(size_t)I_RESAMPLED * n + e] : 0;
+    if (threadIdx.x == 0) {
+        int off = 0, tot = 0;
+        for (int b = 0; b < nblocks; b++) { const int c = counts[b]; if (b < (int)blockIdx.x) off += c; tot += c; }
+        s_off = off; s_total = tot;
+    }
+    s_scan[threadIdx.x] = flag;
+    __syncthreads();
+    for (int d = 1; d < RS_BLOCK; d <<= 1) {  // inclusive scan of the flags
+        const int v = (int)threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (!flag) return;
+    const uint32_t so = mode ? 64u : 0u;
+    const uint32_t K = (uint32_t)s_total, p = (uint32_t)(s_off + s_scan[threadIdx.x] - 1);
+    float cmd[3] = {E.f[(size_t)(F_CMD + 0) * n + e], E.f[(size_t)(F_CMD + 1) * n + e], E.f[(size_t)(F_CMD + 2) * n + e]};
+    float gait_f = E.f[(size_t)F_GAIT_F * n + e];
+    if (C.curriculum && C.same_step_curriculum) {
+        Rand4 cr = rand4(C.seed, (uint32_t)e, step, so + RS_CURR);
+        int lin_level, ang_level;
+        curriculum_draw(C, E.curr, cr, cmd, &lin_level, &ang_level);
+        E.i[(size_t)I_CURR_LIN * n + e] = lin_level; E.i[(size_t)I_CURR_ANG * n + e] = ang_level;
+    }
+    bool still;
+    if (C.exact_still_count) {
+        const uint32_t m = (uint32_t)((double)C.still_proportion * (double)K);  // int(still_proportion * len(env_ids)), t1.py:381
+        const uint32_t key = mix32((uint32_t)C.seed ^ mix32(step + 0x632BE5ABu * (so + 1u)));
+        still = keyed_perm(p, K, key) < m;
+    } else {
+        still = rand4(C.seed, (uint32_t)e, step, so + RS_CMD1).u[0] < C.still_proportion;
+    }
+    if (still) { cmd[0] = cmd[1] = cmd[2] = 0.f; gait_f = 0.f; }
+    for (int a = 0; a < 3; a++) E.f[(size_t)(F_CMD + a) * n + e] = cmd[a];
+    E.f[(size_t)F_GAIT_F * n + e] = gait_f;
+    float* o = obs + (size_t)e * BG_NUM_OBS;  // t1.py:584-586
+    o[6] = cmd[0] * C.norm_lin_vel; o[7] = cmd[1] * C.norm_lin_vel; o[8] = cmd[2] * C.norm_ang_vel;
+    float sg, cg;
+    bg_sincos(6.28318530717959f * E.f[(size_t)F_GAIT_P * n + e], &sg, &cg);
+    const float on = gait_f > 1.0e-8f ? 1.f : 0.f;
+    o[9] = cg * on; o[10] = sg * on;
 }
 
 // ------------------------------------------------------------------ dynamics only: qacc for N independent states
@@ -481,6 +549,10 @@ static int env_create_fill(bg_env* e, const bg_env_cfg* cfg, const bg_model* mod
     e->curr_cells = (2 * cfg->lin_vel_levels + 1) * (2 * cfg->ang_vel_levels + 1);
     HIP_OK(hipMalloc(&e->curr, sizeof(float) * e->curr_cells));
     HIP_OK(hipMalloc(&e->curr_read, sizeof(float) * e->curr_cells));
+    if (cfg->exact_still_count || (cfg->curriculum && cfg->same_step_curriculum)) {
+        if (cfg->state_fp16) return fail(-4, "bg_env_create: exact_still_count / same_step_curriculum are not available with state_fp16");
+        HIP_OK(hipMalloc(&e->rs_counts, sizeof(int) * ((n + 255) / 256)));
+    }
     {   // t1.py:249-255: all mass on the centre cell
         std::vector<float> c0(e->curr_cells, 0.f);
         c0[cfg->lin_vel_levels * (2 * cfg->ang_vel_levels + 1) + cfg->ang_vel_levels] = 1.f;
@@ -561,7 +633,7 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
 extern "C" void bg_env_destroy(bg_env* e) {
     if (!e) return;
     (void)hipFree(e->sim_tau); (void)hipFree(e->sim_bforce); (void)hipFree(e->sim_btorque);
-    (void)hipFree(e->f); (void)hipFree(e->h); (void)hipFree(e->lowmask); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
+    (void)hipFree(e->f); (void)hipFree(e->h); (void)hipFree(e->lowmask); (void)hipFree(e->rs_counts); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
     delete e;
 }
 
@@ -624,6 +696,11 @@ static int launch_step(bg_env* e, const float* actions, int mode, const StepOut&
         dim3 gb(nb < BODY_GRID ? nb : BODY_GRID);
         if (e->h) hipLaunchKernelGGL(env_step_body_kernel<true>, gb, block, 0, st, env_dev(e), actions, cnt, out, (const unsigned*)e->lowmask, nb);
         else hipLaunchKernelGGL(env_step_body_kernel<false>, gb, block, 0, st, env_dev(e), actions, cnt, out, (const unsigned*)e->lowmask, nb);
+    }
+    if (e->rs_counts) {  // reference-exact resampling: the cross-env part of _resample_commands (see resample_apply_kernel)
+        const int nb = (e->n + RS_BLOCK - 1) / RS_BLOCK;
+        hipLaunchKernelGGL(resample_count_kernel, dim3(nb), dim3(RS_BLOCK), 0, st, env_dev(e), e->rs_counts);
+        hipLaunchKernelGGL(resample_apply_kernel, dim3(nb), dim3(RS_BLOCK), 0, st, env_dev(e), (const int*)e->rs_counts, nb, cnt, mode, out.obs);
     }
     HIP_OK(hipGetLastError());
     if (e->cfg.curriculum && mode == 0)  // publish this step's curriculum increments to the next step's samplers

@@ -223,7 +223,10 @@ class T1(BaseTask):
         c.kick_interval = int(math.ceil(rc["kick_interval_s"] / self.dt))
         c.push_interval = int(math.ceil(rc["push_interval_s"] / self.dt))
         c.push_duration = int(math.ceil(rc["push_duration_s"] / self.dt))
-        c.shared_reset_noise = int(bool((cfg.get("parallel", {}) or {}).get("shared_reset_noise", True)))
+        par = cfg.get("parallel", {}) or {}
+        c.shared_reset_noise = int(bool(par.get("shared_reset_noise", True)))
+        c.exact_still_count = int(bool(par.get("exact_still_count", False)))
+        c.same_step_curriculum = int(bool(par.get("same_step_curriculum", False)))
         cm = cfg["commands"]
         for k in range(2):
             c.cmd_lin_vel_x[k], c.cmd_lin_vel_y[k] = cm["lin_vel_x"][k], cm["lin_vel_y"][k]
@@ -316,6 +319,8 @@ class T1(BaseTask):
         for name in self.reward_names:
             self.extras["rew_terms"][name] = self._rew_terms[_lib.REWARD_NAMES.index(name)]
         self._actions_scratch = torch.zeros(self.num_envs, self.num_actions, dtype=torch.float, device=self.device)
+        self._stale_tout = bool((self.cfg.get("parallel", {}) or {}).get("stale_time_outs", False))
+        self._time_outs_at_last_reset = torch.zeros_like(self.time_out_buf)  # T1.reset(): _reset_idx(all) binds the initial (all False) buffer
 
     def __del__(self):
         try:
@@ -334,10 +339,20 @@ class T1(BaseTask):
         _lib.check(self._lib.bg_env_reset(self._env, _lib.current_stream_ptr()), "bg_env_reset")
         return self.obs_buf, self.extras
 
+    def _stale_time_outs(self, done, time_outs):
+        """parallel.stale_time_outs: the reference rebinds extras["time_outs"] only inside _reset_idx (t1.py:317), i.e. on steps in
+        which at least one env was reset; on every other step the runner reads the flags of the last step that had one.  One host sync."""
+        if bool(done.any()):
+            self._time_outs_at_last_reset = time_outs.clone()
+        else:
+            time_outs.copy_(self._time_outs_at_last_reset)
+
     def step(self, actions):
         """One control step = `decimation` physics substeps + task logic (reference t1.py:437-497)."""
         a = self._as_actions(actions)
         _lib.check(self._lib.bg_env_step(self._env, _lib.ptr(a), _lib.current_stream_ptr()), "bg_env_step")
+        if self._stale_tout:
+            self._stale_time_outs(self.reset_buf, self.time_out_buf)
         return self.obs_buf, self.rew_buf, self.reset_buf, self.extras
 
     def step_to(self, actions, obs, privileged_obs, rew, done, time_outs):
@@ -348,6 +363,8 @@ class T1(BaseTask):
                 raise RuntimeError("step_to needs contiguous CUDA output tensors")
         _lib.check(self._lib.bg_env_step_to(self._env, _lib.ptr(a), _lib.ptr(obs), _lib.ptr(privileged_obs), _lib.ptr(rew), _lib.ptr(done),
                                             _lib.ptr(time_outs), _lib.current_stream_ptr()), "bg_env_step_to")
+        if self._stale_tout:
+            self._stale_time_outs(done, time_outs)
 
     def _as_actions(self, actions):
         if actions.shape != (self.num_envs, self.num_actions):

@@ -116,6 +116,12 @@ typedef struct {
      * a body counts when its net contact force exceeds 1 N (t1.py:553,629). */
     float body_gate_height;
     int32_t penalized_body_mask, terminate_body_mask;
+    /* Reference-exact command resampling (T1.yaml parallel.exact_still_count / parallel.same_step_curriculum; default 0 = this build's
+     * single-launch forms).  exact_still_count: exactly int(still_proportion * K) of the K envs that resample in a step stand still, a uniformly
+     * random subset (t1.py:381-383 randperm prefix) instead of a per-env Bernoulli draw.  same_step_curriculum: the curriculum sampler reads the
+     * grid AFTER this step's resets have updated it (t1.py:305 before :365) instead of the grid as of the start of the step.  Either one moves
+     * the cross-env part of _resample_commands into two small follow-up launches per env step (count, apply); not available with state_fp16. */
+    int32_t exact_still_count, same_step_curriculum;
 } bg_env_cfg;
 
 /* ---- model (replaces gym.load_asset and the asset queries, t1.py:54-108) */

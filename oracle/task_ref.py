@@ -285,6 +285,35 @@ def curriculum_commands(grid_idx, ux, uy, uyaw, cm, ncols):
     return lin, ang, cmd
 
 
+def _mix32(x):
+    x = np.uint32(x)
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint32(16); x = np.uint32(x * np.uint32(0x85EBCA6B)); x ^= x >> np.uint32(13); x = np.uint32(x * np.uint32(0xC2B2AE35)); x ^= x >> np.uint32(16)
+    return np.uint32(x)
+
+
+def keyed_perm(p, K, key):
+    """This build's stand-in for torch.randperm(K) (t1.py:381; parallel.exact_still_count): a keyed pseudo-random permutation of [0, K) -- 4-round
+    Feistel network on the smallest even-width bit field covering K, cycle-walked back into range (csrc/bg_env.h:keyed_perm)."""
+    if K <= 1:
+        return 0
+    bits = 2
+    while bits < 32 and (1 << bits) < K:
+        bits += 2
+    hb = bits >> 1
+    hm = (1 << hb) - 1
+    x = int(p)
+    for _ in range(64):
+        L, R = x >> hb, x & hm
+        for r in range(4):
+            f = int(_mix32((R ^ ((int(key) + r * 0x9E3779B9) & 0xFFFFFFFF)) & 0xFFFFFFFF)) & hm
+            L, R = R, L ^ f
+        x = (L << hb) | R
+        if x < K:
+            return x
+    return int(p)
+
+
 # ------------------------------------------------------------------ full env: t1.py:294-341, 437-497 around the C physics oracle
 class T1Ref:
     """State arrays are float64 numpy, env-major.  `dyn` is an oracle.dyn_ref.DynRef (its terrain must match `terrain`)."""
@@ -319,7 +348,10 @@ class T1Ref:
         sc = cfg["rewards"]["scales"]
         self.scales = {k: v * self.dt for k, v in sc.items() if v != 0}
         self.env_ids = np.arange(n, dtype=np.uint32)
-        self.shared_reset_noise = bool((cfg.get("parallel", {}) or {}).get("shared_reset_noise", True))
+        par = cfg.get("parallel", {}) or {}
+        self.shared_reset_noise = bool(par.get("shared_reset_noise", True))
+        self.exact_still_count = bool(par.get("exact_still_count", False))        # t1.py:381-383 as written (exact count, random subset)
+        self.same_step_curriculum = bool(par.get("same_step_curriculum", False))  # t1.py:305 before :365 (grid read after this step's updates)
         cm = cfg["commands"]
         self.curriculum = bool(cm.get("curriculum", False))
         self.curr_prob = np.zeros((2 * cm["lin_vel_levels"] + 1, 2 * cm["ang_vel_levels"] + 1), dtype=np.float64)
@@ -402,7 +434,7 @@ class T1Ref:
                             cm["ang_vel_yaw"][0] + (cm["ang_vel_yaw"][1] - cm["ang_vel_yaw"][0]) * c0u[:, 2]], axis=1).astype(np.float64)
             if self.curriculum:
                 cru, _ = self._r4(RS_CURR, step, so)
-                p = np.minimum(self.curr_prob_read, 1.0).astype(np.float32).reshape(-1)
+                p = np.minimum(self.curr_prob if self.same_step_curriculum else self.curr_prob_read, 1.0).astype(np.float32).reshape(-1)
                 total = np.float32(0.0)
                 for v in p:
                     total = np.float32(total + v)
@@ -414,7 +446,16 @@ class T1Ref:
                 new = ccmd
                 self.curr_levels[rs, 0] = lin[rs]; self.curr_levels[rs, 1] = ang[rs]
             gf = (cm["gait_frequency"][0] + (cm["gait_frequency"][1] - cm["gait_frequency"][0]) * c0u[:, 3]).astype(np.float64)
-            still = c1u[:, 0] < np.float32(cm["still_proportion"])
+            if self.exact_still_count:
+                ids = np.nonzero(rs)[0]  # positions in env order
+                K = len(ids)
+                m = int(float(np.float32(cm["still_proportion"])) * K)
+                key = _mix32(np.uint32(self.seed & 0xFFFFFFFF) ^ _mix32(np.uint32((step + 0x632BE5AB * (so + 1)) & 0xFFFFFFFF)))
+                still = np.zeros(n, dtype=bool)
+                for pos, e in enumerate(ids):
+                    still[e] = keyed_perm(pos, K, key) < m
+            else:
+                still = c1u[:, 0] < np.float32(cm["still_proportion"])
             new[still] = 0.0; gf[still] = 0.0
             lo, hi = int(cm["resampling_time_s"][0] / self.dt), int(cm["resampling_time_s"][1] / self.dt)
             add = lo + np.minimum((c1u[:, 1] * np.float32(hi - lo)).astype(np.int64), hi - lo - 1) if hi > lo else np.full(n, lo)

@@ -66,6 +66,7 @@ class StepParity:
         sync_oracle(self.env, self.ref)
         r = self.ref
         self.pre = {k: getattr(r, k).copy() for k in ("root", "q", "qd", "last_tgt", "push", "delay")}
+        self.pre_cmd_time = r.cmd_time.copy()
 
     # ---- float64 physics of one env from perturbed inputs: envelope of the post-physics state
     def _envelope(self, e, act, delta, P=48):

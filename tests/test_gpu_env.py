@@ -63,11 +63,16 @@ def _close(a, b, tol, frac=0.99, hard=None, what=""):
         assert per_env.max() < hard, f"{what}: worst env error {per_env.max():.3e}"
 
 
-@pytest.mark.parametrize("terrain", ["plane", "trimesh"])
-def test_reset_matches_oracle(terrain):
-    cfg, env, ref = _make(terrain, 64)
+@pytest.mark.parametrize("terrain,overrides", [("plane", None), ("trimesh", None), ("plane", {"parallel.exact_still_count": True})])
+def test_reset_matches_oracle(terrain, overrides):
+    cfg, env, ref = _make(terrain, 64, overrides)
     obs, extras = env.reset()
     o_ref, p_ref = ref.reset()
+    if overrides:  # t1.py:381-383: exactly int(still_proportion * K) of the K = 64 envs resampled by reset() stand still
+        cmd = env.commands.cpu().numpy()
+        still = (cmd == 0).all(axis=1) & (env.get_field("gait_frequency").cpu().numpy()[:, 0] == 0)
+        assert int(still.sum()) == int(cfg["commands"]["still_proportion"] * 64) == 6
+        assert np.array_equal(still, (ref.cmd == 0).all(axis=1))
     _close(obs.cpu().numpy(), o_ref, 2e-5, frac=1.0, what="reset obs")
     _close(extras["privileged_obs"].cpu().numpy(), p_ref, 2e-5, frac=1.0, what="reset privileged obs")
     _close(env.root_states.cpu().numpy(), ref.root, 1e-5, frac=1.0, what="reset root")
@@ -86,8 +91,13 @@ def _settle(env, n, rng, steps=15):
         env.step(torch.tensor(rng.uniform(-0.3, 0.3, (n, 12)), dtype=torch.float32, device=env.device))
 
 
+EXACT = {"parallel.exact_still_count": True, "parallel.same_step_curriculum": True}
+
+
 @pytest.mark.parametrize("terrain,start_count,overrides", [("plane", 0, None), ("plane", 96, None), ("trimesh", 246, None), ("trimesh", 297, None),
-                                                           ("trimesh", 246, {"commands.curriculum": True})])
+                                                           ("trimesh", 246, {"commands.curriculum": True}),
+                                                           ("plane", 96, {"parallel.exact_still_count": True}),
+                                                           ("trimesh", 246, dict(EXACT, **{"commands.curriculum": True}))])
 def test_step_matches_oracle(terrain, start_count, overrides):
     """start_count places the global step counter so that the window covers a kick (cnt % 100 == 0), a push start (cnt % 250 == 0)
     and a push end (cnt % 250 == 50).  The last case is BASELINE configs[2] as SURVEY 8(d) words it: the shipped rough terrain WITH the command
@@ -102,10 +112,13 @@ def test_step_matches_oracle(terrain, start_count, overrides):
     ep[:6, 0] = 1498  # time-out within the window (max_episode_length = 1500)
     env.set_field("episode_length_buf", ep)
     ct = env.get_field("cmd_resample_time")
-    ct[6:12, 0] = ep[6:12, 0] + 2  # command resample within the window
+    exact = bool(cfg["parallel"].get("exact_still_count", False))
+    n_rs = 46 if exact else 12  # exact-count mode: 40 envs resample in one step, so that int(0.1 * K) = 4 of them must stand still
+    ct[6:n_rs, 0] = ep[6:n_rs, 0] + 2  # command resample within the window
     ct[:6, 0] = 5000
     env.set_field("cmd_resample_time", ct)
     env.common_step_counter = start_count
+    still_seen = 0
     if cfg["commands"].get("curriculum", False):
         prob0 = rng.uniform(0.0, 0.8, (21, 21)).astype(np.float32); prob0[10, 10] = 1.0
         env.curriculum_prob = torch.tensor(prob0)
@@ -127,9 +140,15 @@ def test_step_matches_oracle(terrain, start_count, overrides):
         assert (env.get_field("episode_length_buf").cpu().numpy()[:, 0][keep] == ref.ep_len[keep]).all()
         assert PU.rel_state(env.get_field("pushing").cpu().numpy(), ref.push).max() < 1e-4, f"step {s} push"
         assert PU.rel_state(env.commands.cpu().numpy()[keep], ref.cmd[keep]).max() < 1e-5, f"step {s} commands"
+        if exact:
+            rs_now = env.get_field("cmd_resample_time").cpu().numpy()[:, 0] != sp.pre_cmd_time  # envs that resampled in this step
+            st_now = rs_now & (env.commands.cpu().numpy() == 0).all(axis=1) & (env.get_field("gait_frequency").cpu().numpy()[:, 0] == 0)
+            assert int(st_now.sum()) == int(float(np.float32(cfg["commands"]["still_proportion"])) * int(rs_now.sum())), (int(st_now.sum()), int(rs_now.sum()))
+            still_seen += int(st_now.sum())
         if ref.curriculum:
             assert np.allclose(env.curriculum_prob.cpu().numpy(), np.minimum(ref.curr_prob, 1.0), atol=1e-5), f"step {s}: curriculum grid differs"
             assert (env.get_field("env_curriculum_level_lin").cpu().numpy()[:, 0][keep] == ref.curr_levels[keep, 0]).all()
+    assert not exact or still_seen >= 4, "the exact-count path never selected a still env"
     summary = sp.finish()
     print("step parity:", summary, sp.log)
     assert flags_bad <= 2, f"{flags_bad} termination / time-out flags differ"
@@ -329,3 +348,33 @@ def test_trained_reference_policy_walks_on_the_gpu():
     z = env.root_states[:, 2]
     assert float(z.mean()) > 0.6
     assert float(env.episode_stats(reset=False)[-1]) == 0
+
+
+def test_stale_time_outs_flag_reproduces_the_reference_binding():
+    """parallel.stale_time_outs (SURVEY Q3, t1.py:317 vs :556-558): on a step without any reset the reference's runner reads the time-out flags of
+    the LAST step that had a reset.  Two envs with the same seed, flag off / on, stepped with the same actions: same flags whenever an env was
+    reset in the step, the remembered ones otherwise."""
+    n = 64
+    cfg0, env0, _ = _make("plane", n)
+    cfg1, env1, _ = _make("plane", n, {"parallel.stale_time_outs": True})
+    env0.reset(); env1.reset()
+    ct = env0.get_field("cmd_resample_time"); ct[:, 0] = 5000; ct[3, 0] = 4; ct[9, 0] = 7  # resample steps: time_outs without a reset
+    env0.set_field("cmd_resample_time", ct); env1.set_field("cmd_resample_time", ct.clone())
+    ep = env0.get_field("episode_length_buf"); ep[20, 0] = 1495
+    env0.set_field("episode_length_buf", ep); env1.set_field("episode_length_buf", ep.clone())
+    rng = np.random.default_rng(2)
+    remembered = torch.zeros(n, dtype=torch.bool, device=env0.device)  # reset(): _reset_idx(all) bound the initial buffer
+    seen_stale, seen_fresh = 0, 0
+    for s in range(10):
+        a = torch.tensor(rng.uniform(-0.2, 0.2, (n, 12)), dtype=torch.float32, device=env0.device)
+        _, _, d0, x0 = env0.step(a)
+        _, _, d1, x1 = env1.step(a)
+        assert torch.equal(d0, d1)
+        fresh = x0["time_outs"].clone()
+        if bool(d0.any()):
+            remembered = fresh
+            assert torch.equal(x1["time_outs"], fresh); seen_fresh += 1
+        else:
+            assert torch.equal(x1["time_outs"], remembered)
+            seen_stale += int(not torch.equal(fresh, remembered))
+    assert seen_fresh >= 1 and seen_stale >= 1, (seen_fresh, seen_stale)  # both branches exercised, and the stale value really differed
