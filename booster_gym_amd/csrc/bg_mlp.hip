@@ -91,13 +91,19 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
                                                          const float* __restrict__ auxfull, float* __restrict__ colpart) {
     constexpr int N = 128;
     constexpr int NT = N / 32, CH = K / FW_KC, LD4 = N * (FW_KC / 4) / 256;
-    const float* __restrict__ W = Wfull + (size_t)blockIdx.y * N * K;
-    const float* __restrict__ bias = EPI <= 1 ? biasfull + blockIdx.y * N : nullptr;
-    float* __restrict__ Y = Yfull + blockIdx.y * N;
+    // 1-D grid, XCD-aware: workgroups are dealt round-robin over the 8 XCDs, so ids that differ by 8 share an L2.  The column blocks of one row
+    // slab get ids 8 apart (same XCD, dispatched together): the second read of the slab's X rows is an L2 hit instead of a second trip over
+    // the fabric (PMC, profiles/r02_bench_pmc.json: FETCH_SIZE was 2 x |X| with by = column block).  Groups of 8 slabs x ncb column blocks.
+    const int ncb = ldy / N, grp = blockIdx.x / (8 * ncb), rem = blockIdx.x % (8 * ncb);
+    const int bx = grp * 8 + (rem & 7), by = rem >> 3;  // row slab, column block
+    if (bx * FW_BM >= M) return;
+    const float* __restrict__ W = Wfull + (size_t)by * N * K;
+    const float* __restrict__ bias = EPI <= 1 ? biasfull + by * N : nullptr;
+    float* __restrict__ Y = Yfull + by * N;
     static_assert(CH % 2 == 0, "K must be a multiple of 64");
     __shared__ __attribute__((aligned(16))) float sW[2][N * FW_LDW];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const int row = blockIdx.x * FW_BM + wave * 32 + i;
+    const int row = bx * FW_BM + wave * 32 + i;
     const float* xrow = X + (size_t)(row < M ? row : M - 1) * K + 4 * h;
     f32x16 acc[NT];
 #pragma unroll
@@ -125,8 +131,8 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
             load_a_chunk(aA, xrow, kc + 2);
         } else if constexpr (EPI == 2) {
             // last chunk: fetch the epilogue's elu' operand now, so that its HBM latency hides under the final 64 MFMAs
-            const float* __restrict__ auxp = auxfull + blockIdx.y * N;
-            const int rb = blockIdx.x * FW_BM + wave * 32;
+            const float* __restrict__ auxp = auxfull + by * N;
+            const int rb = bx * FW_BM + wave * 32;
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
         __syncthreads();
     }
     // epilogue: C layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int rbase = blockIdx.x * FW_BM + wave * 32;
+    const int rbase = bx * FW_BM + wave * 32;
     if constexpr (EPI <= 1) {
         // The C layout gives a lane ONE column and 4 consecutive rows per register group; a 4 x 4 transpose inside every lane quad (two DPP
         // exchange stages) turns that into one row and 4 consecutive columns, so that the tile leaves as 16 wide stores of 16 bytes per lane
@@ -191,7 +197,7 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
         }
         __syncthreads();
         if (threadIdx.x < N)
-            colpart[(size_t)blockIdx.x * ldy + blockIdx.y * N + threadIdx.x] =
+            colpart[(size_t)bx * ldy + by * N + threadIdx.x] =
                 csum[threadIdx.x] + csum[N + threadIdx.x] + csum[2 * N + threadIdx.x] + csum[3 * N + threadIdx.x];
     }
 }
@@ -212,7 +218,7 @@ extern "C" int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float
     if (M <= 0 || !X || !W || !bias || !Y) return bg_set_error(-1, "bg_mlp_layer_forward: bad argument");
     if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y) & 15) != 0) return bg_set_error(-1, "bg_mlp_layer_forward: pointers must be 16-byte aligned");
     if (N % 128 != 0 || N > 1024) return bg_set_error(-4, "bg_mlp_layer_forward: unsupported N (multiples of 128 up to 1024)");
-    dim3 grid((M + FW_BM - 1) / FW_BM, N / 128), block(256);
+    dim3 grid((((M + FW_BM - 1) / FW_BM + 7) / 8) * 8 * (N / 128)), block(256);  // slabs padded to groups of 8 (mlp_fwd_kernel's XCD-aware mapping)
     hipStream_t st = (hipStream_t)stream;
 #define BG_FWD(KK)                                                                                                      \
     if (K == KK) {                                                                                                      \
@@ -237,7 +243,7 @@ extern "C" int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const floa
         return bg_set_error(-1, "bg_mlp_layer_backward: pointers must be 16-byte aligned");
     if (N % 128 != 0 || N > 1024) return bg_set_error(-4, "bg_mlp_layer_backward: unsupported N (multiples of 128 up to 1024)");
     const int nb = (M + FW_BM - 1) / FW_BM;
-    dim3 grid(nb, N / 128), block(256);
+    dim3 grid(((nb + 7) / 8) * 8 * (N / 128)), block(256);
     hipStream_t st = (hipStream_t)stream;
 #define BG_BWD(KK)                                                                                                                \
     if (K == KK) {                                                                                                                \
