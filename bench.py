@@ -176,9 +176,14 @@ def main():
     T, N, E = cfg["runner"]["horizon_length"], runner.env.num_envs, cfg["runner"]["mini_epochs"]
     dev = runner.device
 
-    obs, infos = runner.env.reset()
-    runner.buffer["obses"][0].copy_(obs)
-    runner.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+    # the timed loop is Runner.train()'s own loop body (train_iteration: rollout, update, statistics read-back, curriculum exchange, logging to a
+    # scratch directory), not a stripped-down copy of it
+    import tempfile
+
+    from booster_gym_amd.utils.recorder import Recorder
+
+    cfg["runner"]["save_interval"] = 10 ** 9  # no checkpoint inside the timed region (the reference saves every 100 iterations)
+    runner.begin_training(Recorder(cfg, root=tempfile.mkdtemp(prefix="bench_logs_"), rank=rank))
 
     def barrier():
         torch.cuda.synchronize()
@@ -192,7 +197,7 @@ def main():
 
     log("env + runner built")
     for w in range(args.warmup):
-        runner.iteration()
+        runner.train_iteration(w)
         torch.cuda.synchronize()
         log(f"warmup iteration {w} done")
     # instrument: HIP events around every env-step launch and around the update phase (torch's current stream is the launch stream)
@@ -212,13 +217,24 @@ def main():
         runner.dp.timed_events = []  # HIP events around the gradient-bucket all-reduce of every mini-epoch
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        r0, r1, r2 = (torch.cuda.Event(enable_timing=True) for _ in range(3))
-        r0.record(); runner.rollout(); r1.record(); runner.update(); r2.record()
-        runner.buffer.roll()
-        phase_events.append((r0, r1, r2))
+    orig_rollout, orig_update = runner.rollout, runner.update
+
+    def timed_rollout():
+        e = torch.cuda.Event(enable_timing=True); e.record(); phase_events.append([e])
+        return orig_rollout()
+
+    def timed_update():
+        e = torch.cuda.Event(enable_timing=True); e.record(); phase_events[-1].append(e)
+        out = orig_update()
+        e2 = torch.cuda.Event(enable_timing=True); e2.record(); phase_events[-1].append(e2)
+        return out
+
+    runner.rollout, runner.update = timed_rollout, timed_update
+    for k in range(args.steps):
+        runner.train_iteration(args.warmup + k)
     barrier()
     wall = time.perf_counter() - t0
+    runner._flush_log()  # the last iteration's scalars (outside the timed region: train() does the same after its loop)
     tw = torch.tensor([wall], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(tw, op=dist.ReduceOp.MAX)
@@ -235,7 +251,6 @@ def main():
         env_bytes = N * ENV_STEP_BYTES
         sim_gbs = env_bytes / (step_ms * 1e-3) / 1e9
         flops = gemm_flops_per_iteration(N, T, E)
-        stats = runner.env.episode_stats(reset=False).cpu().tolist()
         # dominant kernel by GPU time (rocprof, profiles/): the hand-written fused Linear+ELU layer mlp_fwd_kernel<256,1>; its largest instance
         # (critic 256 -> 256, [rows x 256] x [256 x 256]) is timed inside the timed region with HIP events on the stream it is launched on
         ev_all = runner._critic_tr.timed_events
@@ -312,7 +327,7 @@ def main():
             "roofline_update": {"bound": "mfma", "achieved": flops / (upd_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": flops / (upd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                                 "note": "all actor+critic GEMM flops of the update phase / update-phase wall time (which also holds GAE, loss, ELU, Adam)"},
-            "nonfinite_resets": stats[-1],
+            "nonfinite_resets": runner.nonfinite_resets_total,
         }
         if top_by_time is not None:
             out["roofline_top_by_time"] = top_by_time

@@ -47,9 +47,10 @@ class Recorder:
         if self.writer is not None:
             self.writer.add_scalar(path, float(value), it)
 
-    def record_episode_statistics(self, env, reward_names, it):
-        """Flush the device-side episode accumulators: mean over the episodes that ended since the last call."""
-        s = env.episode_stats(reset=True).cpu().tolist()
+    def record_episode_statistics(self, env, reward_names, it, stats=None):
+        """Flush the device-side episode accumulators: mean over the episodes that ended since the last call.  `stats`: the accumulator
+        values already on the host (the runner reads them without stalling, one iteration late); default: read them now."""
+        s = env.episode_stats(reset=True).cpu().tolist() if stats is None else list(stats)
         n = s[0]
         mean = (lambda v: v / n) if n > 0 else (lambda v: 0.0)
         out = {"steps": mean(s[1]), "reward": mean(s[2])}

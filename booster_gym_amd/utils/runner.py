@@ -361,34 +361,81 @@ class Runner:
         self._curr_last = new
 
     def _summarize(self, stats_acc):
-        """Host-side means of the loss terms over the mini-epochs (runner.py:182-204); one device->host read."""
+        """Host-side means of the loss terms over the mini-epochs (runner.py:182-204); one device->host read (blocking: tests and tools)."""
+        s = torch.cat((stats_acc, self._stats, self.optimizer.lr.double())).cpu().tolist()
+        return self._summary_from(s)
+
+    def _summary_from(self, s):
         T, N = self.cfg["runner"]["horizon_length"], self.env.num_envs
         B, A, E = T * N * self.world_size, self.env.num_actions, self.cfg["runner"]["mini_epochs"]
-        s = torch.cat((stats_acc, self._stats, self.optimizer.lr.double())).cpu().tolist()
         self.learning_rate = s[10]
         return {"value_loss": s[0] / (B * E), "actor_loss": s[1] / (B * E), "bound_loss": s[2] / (B * A * E), "entropy": s[3] / (B * E),
                 "kl_mean": s[9] / B, "lr": s[10]}
 
     # ------------------------------------------------------------------ entry points
-    def train(self):
-        self.recorder = Recorder(self.cfg, rank=self.rank)
+    # The reference's loop reads several scalars per mini-epoch with .item() (runner.py:175,182-184) and so stalls the GPU twenty times per
+    # iteration.  Here an iteration's scalars (loss sums, learning rate, episode statistics, curriculum levels: 45 numbers) are gathered into ONE
+    # device vector and copied to pinned host memory without blocking; they are written to the log while the NEXT iteration runs, with their own
+    # iteration number.  The host never waits for the GPU inside the loop, so train() runs at the speed of bench.py's timed region (which calls
+    # the same train_iteration); the last iteration's scalars are flushed after the loop.
+    def begin_training(self, recorder=None):
+        self.recorder = recorder if recorder is not None else Recorder(self.cfg, rank=self.rank)
         obs, infos = self.env.reset()
         self.buffer["obses"][0].copy_(obs)
         self.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+        n = 11 + 4 + _lib.NUM_REWARD_TERMS + 4
+        self._log_dev = torch.zeros(n, dtype=torch.float64, device=self.device)
+        self._log_host = [torch.zeros(n, dtype=torch.float64).pin_memory() for _ in range(2)]
+        self._log_event = [torch.cuda.Event() for _ in range(2)]
+        self._log_pending = None
+        self.nonfinite_resets_total = 0.0  # over the whole run (the per-iteration accumulator is reset when it is read)
+
+    def _flush_log(self):
+        if self._log_pending is None:
+            return
+        slot, it = self._log_pending
+        self._log_event[slot].synchronize()  # recorded one iteration ago: already complete unless the host ran a whole iteration ahead
+        s = self._log_host[slot].tolist()
+        self._log_pending = None
+        summary = self._summary_from(s[:11])
+        ne = 4 + _lib.NUM_REWARD_TERMS
+        self.recorder.record_episode_statistics(self.env, self.env.reward_names, it, stats=s[11 : 11 + ne])
+        self.nonfinite_resets_total += s[11 + ne - 1]
+        lv = s[11 + ne :]
+        if self.cfg["commands"].get("curriculum", False):
+            self.env.mean_lin_vel_level, self.env.mean_ang_vel_level, self.env.max_lin_vel_level, self.env.max_ang_vel_level = lv
+        summary.update({"curriculum/mean_lin_vel_level": self.env.mean_lin_vel_level, "curriculum/mean_ang_vel_level": self.env.mean_ang_vel_level,
+                        "curriculum/max_lin_vel_level": self.env.max_lin_vel_level, "curriculum/max_ang_vel_level": self.env.max_ang_vel_level})
+        self.recorder.record_statistics(summary, it)
+
+    def train_iteration(self, it):
+        """One pass of the reference's training loop body (runner.py:103-213): rollout, update, statistics, curriculum exchange, checkpoint."""
+        stats = self.iteration()
+        d = self._log_dev
+        d[0:5].copy_(stats); d[5:10].copy_(self._stats); d[10:11].copy_(self.optimizer.lr)
+        ne = 4 + _lib.NUM_REWARD_TERMS
+        d[11 : 11 + ne].copy_(self.env.episode_stats(reset=True))
+        self._sync_curriculum()
+        if self.cfg["commands"].get("curriculum", False):
+            lin = self.env.get_field("env_curriculum_level_lin").abs().double()
+            ang = self.env.get_field("env_curriculum_level_ang").abs().double()
+            d[11 + ne :].copy_(torch.stack((lin.mean(), ang.mean(), lin.max(), ang.max())))
+        self._flush_log()  # the previous iteration's scalars: their copy finished long ago
+        slot = it & 1
+        self._log_host[slot].copy_(d, non_blocking=True)
+        self._log_event[slot].record()
+        self._log_pending = (slot, it)
+        if (it + 1) % self.cfg["runner"]["save_interval"] == 0:
+            self.recorder.save(self.checkpoint_dict(), it + 1)
+
+    def train(self):
+        self.begin_training()
         max_it = self.cfg["basic"]["max_iterations"]
         for it in range(max_it):
-            stats = self.iteration()
-            summary = self._summarize(stats)
-            self.recorder.record_episode_statistics(self.env, self.env.reward_names, it)
-            self._sync_curriculum()
-            self.env.refresh_curriculum_levels()
-            summary.update({"curriculum/mean_lin_vel_level": self.env.mean_lin_vel_level, "curriculum/mean_ang_vel_level": self.env.mean_ang_vel_level,
-                            "curriculum/max_lin_vel_level": self.env.max_lin_vel_level, "curriculum/max_ang_vel_level": self.env.max_ang_vel_level})
-            self.recorder.record_statistics(summary, it)
-            if (it + 1) % self.cfg["runner"]["save_interval"] == 0:
-                self.recorder.save(self.checkpoint_dict(), it + 1)
+            self.train_iteration(it)
             if self.rank == 0:
                 print("epoch: {}/{}".format(it + 1, max_it))
+        self._flush_log()
 
     def play(self, max_steps=None, record_path=None):
         """Deterministic rollout with `dist.loc` (runner.py:217-229).  The reference's camera video (runner.py:230-241) is replaced
