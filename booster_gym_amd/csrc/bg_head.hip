@@ -37,15 +37,28 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 __device__ __forceinline__ float elu_grad_from_output(float a) { return a > 0.f ? 1.0f : a + 1.0f; }
 
-// coalesced load of a [HT][HK] activation tile into LDS (rows past B read as zero)
-__device__ __forceinline__ void load_tile(const float* __restrict__ h, int row0, int B, float* s_h) {
+// coalesced load of a [HT][HK] activation tile into LDS (rows past B read as zero), in two halves so that a persistent workgroup can have the
+// NEXT tile's 8 float4 per thread in flight while it computes on the current one (tile_fetch before the compute, tile_put after it)
+constexpr int HTV = HT * HK / 4 / 256;
+__device__ __forceinline__ void tile_fetch(const float* __restrict__ h, int row0, int B, float4 (&v)[HTV]) {
 #pragma unroll
-    for (int i = 0; i < HT * HK / 4 / 256; i++) {
+    for (int i = 0; i < HTV; i++) {
         const int idx = threadIdx.x + 256 * i, r = idx >> 5, c4 = idx & 31;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (row0 + r < B) v = *reinterpret_cast<const float4*>(h + (size_t)(row0 + r) * HK + c4 * 4);
-        *reinterpret_cast<float4*>(s_h + r * HLD + c4 * 4) = v;
+        v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (row0 + r < B) v[i] = *reinterpret_cast<const float4*>(h + (size_t)(row0 + r) * HK + c4 * 4);
     }
+}
+__device__ __forceinline__ void tile_put(const float4 (&v)[HTV], float* s_h) {
+#pragma unroll
+    for (int i = 0; i < HTV; i++) {
+        const int idx = threadIdx.x + 256 * i, r = idx >> 5, c4 = idx & 31;
+        *reinterpret_cast<float4*>(s_h + r * HLD + c4 * 4) = v[i];
+    }
+}
+__device__ __forceinline__ void load_tile(const float* __restrict__ h, int row0, int B, float* s_h) {
+    float4 v[HTV];
+    tile_fetch(h, row0, B, v);
+    tile_put(v, s_h);
 }
 
 // Per-workgroup partial sums, added in a fixed order by head_finish_kernel.  scratch = [HEAD_MAX_GRID records of head_record<NO>() floats:
@@ -84,10 +97,12 @@ __global__ __launch_bounds__(256) void actor_head_kernel(int B, int tiles, const
                                                          float* __restrict__ partial) {
     constexpr int A = HA;
     __shared__ __attribute__((aligned(16))) float s_h[HT * HLD];
-    __shared__ __attribute__((aligned(16))) float s_w[A * HK];
+    // rows of W 132 floats apart: the four (t & 3) groups of a wave read rows 3 apart at the same k, which with a 128-float stride were the same
+    // banks (a 4-way conflict on three of the four LDS reads of the forward loop)
+    __shared__ __attribute__((aligned(16))) float s_w[A * HLD];
     __shared__ __attribute__((aligned(16))) float s_g[HT * A];  // dL/dmu of the tile's rows
     const int t = threadIdx.x;
-    for (int i = t; i < A * HK; i += 256) s_w[i] = W[i];
+    for (int i = t; i < A * HK; i += 256) s_w[(i >> 7) * HLD + (i & (HK - 1))] = W[i];
     const int fr = t >> 2, fq = t & 3;
     float fb[3];
     for (int i = 0; i < 3; i++) fb[i] = bias[3 * fq + i];
@@ -106,16 +121,19 @@ __global__ __launch_bounds__(256) void actor_head_kernel(int B, int tiles, const
         ent = c.ent; mean = c.mean; inv_std = c.inv_std; invB = c.invB; bscale = c.bscale;
     }
     __syncthreads();
+    float4 nxt[HTV];
+    tile_fetch(h, blockIdx.x * HT, B, nxt);
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int row0 = tile * HT;
-        load_tile(h, row0, B, s_h);
+        tile_put(nxt, s_h);
+        if (tile + (int)gridDim.x < tiles) tile_fetch(h, (tile + gridDim.x) * HT, B, nxt);  // in flight under this tile's compute
         __syncthreads();
         {   // mu = h W^T + b
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
             const float4* hr = reinterpret_cast<const float4*>(s_h + fr * HLD);
-            const float4* w0 = reinterpret_cast<const float4*>(s_w + (3 * fq) * HK);
-            const float4* w1 = reinterpret_cast<const float4*>(s_w + (3 * fq + 1) * HK);
-            const float4* w2 = reinterpret_cast<const float4*>(s_w + (3 * fq + 2) * HK);
+            const float4* w0 = reinterpret_cast<const float4*>(s_w + (3 * fq) * HLD);
+            const float4* w1 = reinterpret_cast<const float4*>(s_w + (3 * fq + 1) * HLD);
+            const float4* w2 = reinterpret_cast<const float4*>(s_w + (3 * fq + 2) * HLD);
 #pragma unroll 2
             for (int k4 = 0; k4 < HK / 4; k4++) {
                 const float4 x = hr[k4], u = w0[k4], v = w1[k4], w = w2[k4];
@@ -222,9 +240,12 @@ __global__ __launch_bounds__(256) void critic_head_backward_kernel(int B, int ti
     const float wk = w[kc], invB = 1.0f / (float)B;
     float dW = 0.f, cs = 0.f, db = 0.f;
     double verr2 = 0.0;
+    float4 nxt[HTV];
+    tile_fetch(h, blockIdx.x * HT, B, nxt);
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int row0 = tile * HT;
-        load_tile(h, row0, B, s_h);
+        tile_put(nxt, s_h);
+        if (tile + (int)gridDim.x < tiles) tile_fetch(h, (tile + gridDim.x) * HT, B, nxt);  // in flight under this tile's compute
         if (t < HT) {
             const int b = row0 + t;
             float g = 0.f;
