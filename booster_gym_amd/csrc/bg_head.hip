@@ -121,12 +121,11 @@ __global__ __launch_bounds__(256) void actor_head_kernel(int B, int tiles, const
         ent = c.ent; mean = c.mean; inv_std = c.inv_std; invB = c.invB; bscale = c.bscale;
     }
     __syncthreads();
-    float4 nxt[HTV];
-    tile_fetch(h, blockIdx.x * HT, B, nxt);
+    // (no register prefetch of the next tile here, unlike critic_head_backward_kernel: the 32 extra registers cost this kernel a resident
+    // workgroup per CU, 55.9 -> 62.9 us measured)
     for (int tile = blockIdx.x; tile < tiles; tile += gridDim.x) {
         const int row0 = tile * HT;
-        tile_put(nxt, s_h);
-        if (tile + (int)gridDim.x < tiles) tile_fetch(h, (tile + gridDim.x) * HT, B, nxt);  // in flight under this tile's compute
+        load_tile(h, row0, B, s_h);
         __syncthreads();
         {   // mu = h W^T + b
             float a0 = 0.f, a1 = 0.f, a2 = 0.f;
