@@ -73,6 +73,18 @@ class FlatAdam:
                                             _lib.ptr(self.exp_avg_sq), _lib.ptr(self.lr), self.step_count, self.betas[0], self.betas[1], self.eps,
                                             self.max_grad_norm, _lib.ptr(self._gnorm), _lib.current_stream_ptr()), "bg_adam_step")
 
+    def step_fused(self, stats, stats_acc, stats_last, kl_index, count, desired_kl, grad_logstd=None, ls_off=0, lr_min=1e-5, lr_max=1e-2):
+        """clip + Adam + KL learning-rate rule + statistics bookkeeping in one launch (bg_optimizer_step): what `step()`, `adapt_lr()` and the
+        runner's `stats_acc += stats` / zero fills do as seven dependent launches."""
+        self.step_count += 1
+        if not hasattr(self, "_ticket"):
+            self._ticket = torch.zeros(1, dtype=torch.int32, device=self.flat.device)
+        _lib.check(_lib.load().bg_optimizer_step(self.flat.numel(), _lib.ptr(self.flat), _lib.ptr(self.grad), _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq),
+                                                 _lib.ptr(self.lr), self.step_count, self.betas[0], self.betas[1], self.eps, self.max_grad_norm,
+                                                 _lib.ptr(grad_logstd), int(ls_off), 0 if grad_logstd is None else grad_logstd.numel(), _lib.ptr(stats),
+                                                 _lib.ptr(stats_acc), _lib.ptr(stats_last), stats.numel(), int(kl_index), float(count), desired_kl, lr_min,
+                                                 lr_max, _lib.ptr(self._ticket), _lib.current_stream_ptr()), "bg_optimizer_step")
+
     def adapt_lr(self, kl_sum, count, desired_kl, lr_min=1e-5, lr_max=1e-2):
         _lib.check(_lib.load().bg_adapt_lr(_lib.ptr(kl_sum), float(count), desired_kl, lr_min, lr_max, _lib.ptr(self.lr), _lib.current_stream_ptr()),
                    "bg_adapt_lr")
@@ -168,8 +180,12 @@ class Runner:
         self._grad_logstd = torch.zeros(A, dtype=torch.float64, device=dev)
         self._stats = torch.zeros(5, dtype=torch.float64, device=dev)
         self._stats_acc = torch.zeros(5, dtype=torch.float64, device=dev)
+        self._stats_last = torch.zeros(5, dtype=torch.float64, device=dev)  # the last mini-epoch's sums (kl_mean of the log, runner.py:199)
+        # BG_FUSED_OPT=0: the mini-epoch tail as separate launches (bg_adam_step, bg_adapt_lr, torch adds / fills) for A/B comparisons
+        self._fused_opt = os.environ.get("BG_FUSED_OPT", "1") == "1"
         self._old_logp = torch.zeros(B, device=dev)
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
+        self._logstd_off = (self._logstd_grad_view.data_ptr() - self.optimizer.grad.data_ptr()) // 4  # position of logstd in the flat buffers
         self._actor_tr, self._critic_tr = MLPTrainer(self.model.actor), MLPTrainer(self.model.critic)
         self._side_stream = torch.cuda.Stream(device=self.device)
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
@@ -282,17 +298,17 @@ class Runner:
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
             gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
         self._stats_acc.zero_()
+        self._stats.zero_()
+        self._grad_logstd.zero_()
         # Two HIP streams: the actor and the critic are independent networks, so the HBM-bound elementwise kernels of one overlap
         # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
         main = torch.cuda.current_stream()
         side = self._side_stream if os.environ.get("BG_TWO_STREAMS", "1") == "1" else main
         with torch.no_grad():
             for _ in range(cfg["runner"]["mini_epochs"]):
-                side.wait_stream(main)  # parameters updated by the previous optimiser step
-                if fused_head:  # both heads accumulate into these; zeroed before either can run
-                    self._stats.zero_()
-                    self._grad_logstd.zero_()
-                    zeroed = main.record_event()
+                # parameters updated by the previous optimiser step; the loss accumulators (_stats, _grad_logstd) were zeroed by it (before the loop
+                # for the first mini-epoch): both heads add into them
+                side.wait_stream(main)
                 with torch.cuda.stream(side):
                     if fused_head:
                         hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
@@ -309,7 +325,6 @@ class Runner:
                     # output, the loss terms, dL/dz of the hidden layer and the output layer's gradients.  Both heads add into _stats.
                     ha = self._actor_tr.forward_hidden(obs_flat)
                     with torch.cuda.stream(side):
-                        side.wait_event(zeroed)
                         critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,
                                              c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c)
                         self._critic_tr.backward_hidden()
@@ -334,15 +349,27 @@ class Runner:
                         self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
                         self._critic_tr.backward(self._grad_val.view(B, 1))
                     self._actor_tr.backward(self._grad_mu)
-                self._logstd_grad_view.copy_(self._grad_logstd)
+                fused_tail = self._fused_opt and not self._lr_restart
+                if self.dp.active or not fused_tail:
+                    self._logstd_grad_view.copy_(self._grad_logstd)  # into the flat bucket before the all-reduce
                 main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
-                self.optimizer.step()
-                if self._lr_restart:  # first step after a checkpoint load: see __init__
-                    self.optimizer.lr.fill_(float(cfg["algorithm"]["learning_rate"]))
-                    self._lr_restart = False
-                self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
-                self._stats_acc += self._stats
+                if fused_tail:
+                    # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch
+                    self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
+                                              grad_logstd=None if self.dp.active else self._grad_logstd, ls_off=self._logstd_off)
+                    if self.dp.active:
+                        self._grad_logstd.zero_()
+                else:
+                    self.optimizer.step()
+                    if self._lr_restart:  # first step after a checkpoint load: see __init__
+                        self.optimizer.lr.fill_(float(cfg["algorithm"]["learning_rate"]))
+                        self._lr_restart = False
+                    self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
+                    self._stats_acc += self._stats
+                    self._stats_last.copy_(self._stats)
+                    self._stats.zero_()
+                    self._grad_logstd.zero_()
         return self._stats_acc
 
     def iteration(self):
@@ -362,7 +389,7 @@ class Runner:
 
     def _summarize(self, stats_acc):
         """Host-side means of the loss terms over the mini-epochs (runner.py:182-204); one device->host read (blocking: tests and tools)."""
-        s = torch.cat((stats_acc, self._stats, self.optimizer.lr.double())).cpu().tolist()
+        s = torch.cat((stats_acc, self._stats_last, self.optimizer.lr.double())).cpu().tolist()
         return self._summary_from(s)
 
     def _summary_from(self, s):
@@ -412,7 +439,7 @@ class Runner:
         """One pass of the reference's training loop body (runner.py:103-213): rollout, update, statistics, curriculum exchange, checkpoint."""
         stats = self.iteration()
         d = self._log_dev
-        d[0:5].copy_(stats); d[5:10].copy_(self._stats); d[10:11].copy_(self.optimizer.lr)
+        d[0:5].copy_(stats); d[5:10].copy_(self._stats_last); d[10:11].copy_(self.optimizer.lr)
         ne = 4 + _lib.NUM_REWARD_TERMS
         d[11 : 11 + ne].copy_(self.env.episode_stats(reset=True))
         self._sync_curriculum()

@@ -248,6 +248,15 @@ int bg_adam_step(int32_t n, float* params, const float* grads, float* exp_avg, f
                  float beta1, float beta2, float eps, float max_grad_norm, double* gnorm_scratch, void* stream);
 /* KL-adaptive learning rate on the device (runner.py:174-180): kl_sum [1] float64 (= stats[4] of bg_ppo_loss), count = samples -> lr_device [1] updated in place */
 int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_min, float lr_max, float* lr_device, void* stream);
+/* The tail of a mini-epoch in one launch (runner.py:162-180): global-norm clip + Adam on the flat buffers (as bg_adam_step), then the KL rule on
+ * lr_device (as bg_adapt_lr, with kl_sum = stats[kl_index]), and the bookkeeping of the float64 loss statistics: stats_last = stats,
+ * stats_acc += stats, stats = 0 (and grad_logstd = 0) for the next mini-epoch.  grad_logstd (optional, float64 [ls_n]) is the log-std gradient as
+ * the head kernels accumulate it; it is written into grads[ls_off .. ls_off + ls_n) first.  stats may be NULL (no learning-rate rule, no
+ * bookkeeping).  ticket: one zero-initialised uint32 of device memory owned by the caller.  Deterministic (no float atomics). */
+int bg_optimizer_step(int32_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr_device, int32_t step, float beta1, float beta2,
+                      float eps, float max_grad_norm, double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats, double* stats_acc,
+                      double* stats_last, int32_t n_stats, int32_t kl_index, float kl_count, float desired_kl, float lr_min, float lr_max,
+                      uint32_t* ticket, void* stream);
 
 /* MLP backward helper for the ELU layers of utils/model.py:9-26: grad [B][C] <- grad * elu'(.) in place, expressed through the layer OUTPUT
  * act [B][C] (1 if act > 0 else act + 1; act == NULL: identity), and colsum [C] = column sums of the result (= bias gradient).
