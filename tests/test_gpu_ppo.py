@@ -144,6 +144,66 @@ def test_adapt_lr_rule():
     assert abs(fa.lr.item() - 1e-2) < 1e-9  # ceiling
 
 
+def test_fused_optimizer_step_equals_the_separate_launches():
+    """bg_optimizer_step (clip + Adam + KL learning-rate rule + statistics bookkeeping in one launch) against torch Adam with clip_grad_norm_, the
+    reference's learning-rate rule (runner.py:174-180) and plain sums; log-std gradient delivered as float64; deterministic bit for bit."""
+    from booster_gym_amd.utils.runner import FlatAdam
+
+    torch.manual_seed(3)
+    shapes = [(256, 47), (256,), (1, 12), (128, 130), (7,)]
+
+    def make():
+        torch.manual_seed(3)
+        ps = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+        return ps, FlatAdam(ps, lr=1e-3)
+
+    ps, fa = make()
+    qs = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    ref = torch.optim.Adam(qs, lr=1e-3)
+    ls_off = (ps[2].grad.data_ptr() - fa.grad.data_ptr()) // 4
+    stats = torch.zeros(5, dtype=torch.float64, device=DEV); acc = torch.zeros_like(stats); last = torch.zeros_like(stats)
+    gls = torch.zeros(12, dtype=torch.float64, device=DEV)
+    lr_ref, acc_ref = 1e-3, torch.zeros(5, dtype=torch.float64)
+    count, desired = 1000.0, 0.01
+    for it, kl_mean in enumerate((0.05, 0.001, 0.01, 0.0, 0.3)):
+        gs = [torch.randn_like(p) * (2.0 if it % 2 == 0 else 0.003) for p in ps]  # exercises clip and no-clip
+        for p, q, g in zip(ps, qs, gs):
+            p.grad.copy_(g); q.grad = g.clone()
+        ps[2].grad.fill_(123.0)  # must be overwritten from the float64 log-std gradient
+        gls.copy_(gs[2].reshape(-1).double())
+        st = torch.tensor([1.5 + it, -2.0, 0.25, 3.0, kl_mean * count], dtype=torch.float64)
+        stats.copy_(st)
+        for g_ in ref.param_groups:
+            g_["lr"] = lr_ref
+        torch.nn.utils.clip_grad_norm_(qs, 1.0)
+        ref.step()
+        fa.step_fused(stats, acc, last, 4, count, desired, grad_logstd=gls, ls_off=ls_off)
+        if kl_mean > desired * 2:
+            lr_ref = max(1e-5, lr_ref / 1.5)
+        elif kl_mean < desired / 2:
+            lr_ref = min(1e-2, lr_ref * 1.5)
+        acc_ref += st
+        for p, q in zip(ps, qs):
+            assert torch.allclose(p, q, rtol=2e-5, atol=2e-6), it
+        assert abs(fa.lr.item() - lr_ref) < 1e-9 * max(1.0, lr_ref / 1e-5), (it, fa.lr.item(), lr_ref)
+        assert torch.allclose(last.cpu(), st) and torch.allclose(acc.cpu(), acc_ref)
+        assert float(stats.abs().sum()) == 0.0 and float(gls.abs().sum()) == 0.0  # zeroed for the next mini-epoch
+    assert fa.step_count == 5
+    # deterministic: the same sequence again gives the same bits
+    ps2, fa2 = make()
+    torch.manual_seed(99)
+    g_a = [torch.randn_like(p) for p in ps2]
+    outs = []
+    for _ in range(2):
+        ps3, fa3 = make()
+        for p, g in zip(ps3, g_a):
+            p.grad.copy_(g)
+        fa3.step_fused(torch.zeros(5, dtype=torch.float64, device=DEV), torch.zeros(5, dtype=torch.float64, device=DEV),
+                       torch.zeros(5, dtype=torch.float64, device=DEV), 4, 10.0, 0.01)
+        outs.append(fa3.flat.clone())
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_full_update_matches_reference_loop():
     """Runner.update() (fused kernels, flat Adam, device-side LR) vs oracle/ppo_ref.ppo_update_reference (the reference loop op by op)
     from the same weights on the same rollout data: parameters after 3 mini-epochs agree, and so do the logged losses and the LR."""
