@@ -41,6 +41,11 @@ class AssetOptions(C.Structure):
     _fields_ = [("collapse_fixed_joints", C.c_int32), ("body_contacts", C.c_int32), ("foot_names", C.c_char_p * 2), ("feet_edge_pos", C.c_float * 3 * 4)]
 
 
+class WgradProblem(C.Structure):
+    _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("dW", C.c_void_p), ("scratch", C.c_void_p), ("M", C.c_int32), ("C_out", C.c_int32), ("C_in", C.c_int32),
+                ("C_in_real", C.c_int32), ("slices", C.c_int32)]
+
+
 class Rand(C.Structure):
     _fields_ = [("mode", C.c_int32), ("a", C.c_float), ("b", C.c_float)]
 
@@ -85,7 +90,7 @@ SYMBOLS = [
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
     "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
     "bg_env_forward_dynamics", "bg_sim_bind_state", "bg_sim_set_actuation", "bg_sim_apply_body_wrench_local", "bg_sim_simulate",
-    "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_optimizer_step", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward", "bg_mlp_weight_grad",
+    "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_optimizer_step", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward", "bg_mlp_weight_grad", "bg_mlp_weight_grad_group",
     "bg_critic_head_forward", "bg_actor_head", "bg_critic_head_backward",
     "bg_last_error", "bg_version",
 ]
@@ -149,6 +154,7 @@ def load():
         "bg_mlp_layer_forward": (i32, [i32, i32, i32, vp, vp, vp, vp, i32, vp]),
         "bg_mlp_layer_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "bg_mlp_weight_grad": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),
+        "bg_mlp_weight_grad_group": (i32, [C.POINTER(WgradProblem), i32, vp]),
         "bg_critic_head_forward": (i32, [i32, vp, vp, vp, vp, vp]),
         "bg_actor_head": (i32, [i32, i32] + [vp] * 10 + [f32, f32, f32] + [vp] * 9),
         "bg_critic_head_backward": (i32, [i32] + [vp] * 11),

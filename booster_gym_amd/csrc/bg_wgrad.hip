@@ -26,13 +26,13 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 // Split over the batch inside the launch: every wave owns a contiguous run of row pairs, the 4 waves of a workgroup add their tiles through
 // LDS, one partial tile per workgroup goes to `P[slice]`, and a second kernel adds the slices in a fixed order (deterministic; no atomics).
 // Workgroups that read the same rows (the tiles of one slice) are given block indices 8 apart, i.e. the same XCD and L2 (speed only).
+constexpr int WG_RED_FLOATS = 4 * 64 * 16 * 2 * 4;  // LDS of the in-workgroup reduction: 4 waves x 2 co-tiles x 16 registers x 64 lanes x TCI (<= 4) floats = 128 KB
 template <int TCI>  // 32-column C_in tiles per wave: 4 (128 input columns per workgroup) or 2 (64: the zero-padded first layers)
-__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(int M, int Cout, int Cin, const float* __restrict__ G, const float* __restrict__ A,
-                                                           float* __restrict__ P, int ntile_ci, int ntiles, int slices) {
+__device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int Cin, const float* __restrict__ G, const float* __restrict__ A,
+                                           float* __restrict__ P, int ntile_ci, int tile, int slice, int slices) {
     constexpr int D = 8;  // row pairs per register set: 2 sets x D x (4 + TCI) registers of loads in flight under D x 4 x TCI MFMAs
     typedef float avec __attribute__((ext_vector_type(TCI)));
-    __shared__ __attribute__((aligned(16))) float red[4][64 * 16 * 2 * TCI];
-    const int b = blockIdx.x, q = b >> 3, tile = q % ntiles, slice = (q / ntiles) * 8 + (b & 7);
+    float (*red)[64 * 16 * 2 * TCI] = reinterpret_cast<float (*)[64 * 16 * 2 * TCI]>(red_base);
     const int tco = tile / ntile_ci, tci = tile % ntile_ci;
     // wave-uniform values are forced into SGPRs: the loads then take the scalar-base + 32-bit lane offset form and the walk over the rows
     // is scalar arithmetic (per-lane 64-bit addresses for 2 x D x 2 loads in flight do not fit beside 256 accumulators)
@@ -124,6 +124,39 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(int M, int Cout, int 
     }
 }
 
+// one layer per launch: workgroups that read the same rows (the tiles of one slice) get block ids 8 apart, i.e. the same XCD and L2 (speed only)
+template <int TCI>
+__global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(int M, int Cout, int Cin, const float* __restrict__ G, const float* __restrict__ A,
+                                                           float* __restrict__ P, int ntile_ci, int ntiles, int slices) {
+    __shared__ __attribute__((aligned(16))) float red[WG_RED_FLOATS / 4 * TCI];
+    const int b = blockIdx.x, q = b >> 3, tile = q % ntiles, slice = (q / ntiles) * 8 + (b & 7);
+    wgrad_tile<TCI>(red, M, Cout, Cin, G, A, P, ntile_ci, tile, slice, slices);
+}
+
+// Several layers in ONE launch (bg_mlp_weight_grad_group): the weight gradients of all hidden layers of both networks, after both backward
+// chains, with every workgroup given the same amount of MFMA work -- the caller sizes each layer's slice count in proportion to its cost
+// (rows x tile width), so that one launch of ~256 workgroups keeps every CU busy for the same time instead of six launches with six
+// prologue / reduction / finish tails.  Up to WG_MAX_PROBLEMS layers; descriptors travel as a kernel argument.
+constexpr int WG_MAX_PROBLEMS = 8;
+struct WgradProblem {
+    const float* G; const float* A; float* P; float* dW;
+    int M, Cout, Cin, Cin_real, tci, ntile_ci, ntiles, slices, wg_begin, fin_begin, n4;
+};
+struct WgradGroup { int np; WgradProblem p[WG_MAX_PROBLEMS]; };
+
+__global__ __launch_bounds__(256, 1) void mlp_wgrad_group_kernel(WgradGroup grp) {
+    __shared__ __attribute__((aligned(16))) float red[WG_RED_FLOATS];
+    const int b = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < WG_MAX_PROBLEMS; j++)
+        if (j < grp.np && b >= grp.p[j].wg_begin) k = j;
+    const WgradProblem& pr = grp.p[k];
+    const int local = b - pr.wg_begin, tile = local % pr.ntiles, slice = local / pr.ntiles;
+    if (pr.tci == 4) wgrad_tile<4>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile, slice, pr.slices);
+    else wgrad_tile<2>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile, slice, pr.slices);
+}
+
 // dW[co][ci < Cin_real] = sum over slices of P[s][co][ci], slices added in a fixed order; 16 float4 columns x 16 slice groups per workgroup
 // (the slice loop is a chain of dependent-address loads: many short chains, not few long ones)
 __global__ __launch_bounds__(256) void mlp_wgrad_finish_kernel(int S, int Cin, int Cin_real, int n4, const float* __restrict__ P, float* __restrict__ dW) {
@@ -169,3 +202,64 @@ extern "C" int bg_mlp_weight_grad(int32_t M, int32_t C_out, int32_t C_in, int32_
     return 0;
 }
 
+
+__global__ __launch_bounds__(256) void mlp_wgrad_group_finish_kernel(WgradGroup grp) {
+    __shared__ f32x4 sm[16][16];
+    const int b = blockIdx.x;
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < WG_MAX_PROBLEMS; j++)
+        if (j < grp.np && b >= grp.p[j].fin_begin) k = j;
+    const WgradProblem& pr = grp.p[k];
+    const int c = threadIdx.x & 15, sg = threadIdx.x >> 4, e4 = (b - pr.fin_begin) * 16 + c, n4 = pr.n4, S = pr.slices, Cin = pr.Cin, Cin_real = pr.Cin_real;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (e4 < n4)
+        for (int s = sg; s < S; s += 16) acc += *reinterpret_cast<const f32x4*>(pr.P + ((size_t)s * n4 + e4) * 4);
+    sm[sg][c] = acc;
+    __syncthreads();
+    if (sg == 0 && e4 < n4) {
+        f32x4 v = sm[0][c];
+#pragma unroll
+        for (int j = 1; j < 16; j++) v += sm[j][c];
+        const int row = (e4 * 4) / Cin, col = (e4 * 4) % Cin;
+        if (Cin_real == Cin) {
+            *reinterpret_cast<f32x4*>(pr.dW + (size_t)row * Cin + col) = v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+                if (col + j < Cin_real) pr.dW[(size_t)row * Cin_real + col + j] = v[j];
+        }
+    }
+}
+
+extern "C" int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream) {
+    if (!problems || count <= 0 || count > WG_MAX_PROBLEMS) return bg_set_error(-1, "bg_mlp_weight_grad_group: 1 to 8 problems");
+    WgradGroup grp;
+    grp.np = count;
+    int wg = 0, fin = 0;
+    for (int k = 0; k < count; k++) {
+        const bg_wgrad_problem& q = problems[k];
+        if (q.M <= 0 || !q.G || !q.A || !q.dW || !q.scratch) return bg_set_error(-1, "bg_mlp_weight_grad_group: bad argument");
+        if ((((uintptr_t)q.G | (uintptr_t)q.A | (uintptr_t)q.scratch) & 15) != 0) return bg_set_error(-1, "bg_mlp_weight_grad_group: G, A, scratch must be 16-byte aligned");
+        if (q.C_in_real == q.C_in && (((uintptr_t)q.dW) & 15) != 0) return bg_set_error(-1, "bg_mlp_weight_grad_group: dW must be 16-byte aligned");
+        if (q.C_out % 128 != 0 || q.C_out > 1024) return bg_set_error(-4, "bg_mlp_weight_grad_group: unsupported C_out (multiples of 128 up to 1024)");
+        if (q.C_in != 64 && (q.C_in % 128 != 0 || q.C_in > 1024)) return bg_set_error(-4, "bg_mlp_weight_grad_group: unsupported C_in (64, or multiples of 128 up to 1024)");
+        if (q.C_in_real <= 0 || q.C_in_real > q.C_in) return bg_set_error(-1, "bg_mlp_weight_grad_group: C_in_real must be in [1, C_in]");
+        if (q.M % 2 != 0) return bg_set_error(-4, "bg_mlp_weight_grad_group: M must be even (rows are consumed in pairs)");
+        if (q.slices <= 0 || (long)q.slices * 8 > q.M) return bg_set_error(-4, "bg_mlp_weight_grad_group: slices must be in [1, M / 8]");
+        WgradProblem& p = grp.p[k];
+        p.G = q.G; p.A = q.A; p.P = q.scratch; p.dW = q.dW;
+        p.M = q.M; p.Cout = q.C_out; p.Cin = q.C_in; p.Cin_real = q.C_in_real; p.tci = q.C_in == 64 ? 2 : 4;
+        p.ntile_ci = q.C_in == 64 ? 1 : q.C_in / 128;
+        p.ntiles = (q.C_out / 128) * p.ntile_ci;
+        p.slices = q.slices;
+        p.wg_begin = wg; wg += p.ntiles * p.slices;
+        p.n4 = q.C_out * q.C_in / 4;
+        p.fin_begin = fin; fin += (p.n4 + 15) / 16;
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(mlp_wgrad_group_kernel, dim3(wg), dim3(256), 0, st, grp);
+    hipLaunchKernelGGL(mlp_wgrad_group_finish_kernel, dim3(fin), dim3(256), 0, st, grp);
+    HIP_OK(hipGetLastError());
+    return 0;
+}

@@ -23,6 +23,47 @@ def _mlp(n_in, hidden, n_out):
     return torch.nn.Sequential(*layers)
 
 
+def plan_wgrad_slices(shapes, rows, workgroups=256):
+    """Slices per layer for bg_mlp_weight_grad_group: `shapes` = [(C_out, C_in padded)], one workgroup per (128 x 128 or 128 x 64 output tile,
+    slice).  Every workgroup should do the same MFMA work: a tile's cost per row is proportional to its width, so a layer's slice count is
+    proportional to that width; the total stays within `workgroups` (one 512-register workgroup per CU).  Largest-remainder rounding."""
+    tiles = [(co // 128) * max(1, ci // 128) for co, ci in shapes]
+    cost = [0.5 if ci == 64 else 1.0 for _, ci in shapes]
+    units = sum(t * c for t, c in zip(tiles, cost))
+    ideal = [workgroups * c / units for c in cost]
+    cap = max(1, rows // 8)
+    s = [max(1, min(cap, int(x))) for x in ideal]
+    order = sorted(range(len(shapes)), key=lambda k: ideal[k] - int(ideal[k]), reverse=True)
+    for k in order:
+        if s[k] < cap and sum(t * v for t, v in zip(tiles, s)) + tiles[k] <= workgroups:
+            s[k] += 1
+    return s
+
+
+class GroupedWeightGrad:
+    """All deferred weight gradients of several MLPTrainers in one launch pair (bg_mlp_weight_grad_group)."""
+
+    def __init__(self, workgroups=None):
+        self.workgroups = workgroups or MLPTrainer.WGRAD_WORKGROUPS
+        self._key, self._arr, self._scratch = None, None, None
+
+    def run(self, trainers):
+        probs = [p for tr in trainers for p in tr.pending_wgrad_problems()]
+        if not probs:
+            return
+        key = tuple((g.data_ptr(), a.data_ptr(), dw.data_ptr(), g.shape[0], co, ci, cr) for g, a, dw, co, ci, cr in probs)
+        if key != self._key:  # buffers are static: built once
+            rows = probs[0][0].shape[0]
+            slices = plan_wgrad_slices([(co, ci) for _, _, _, co, ci, _ in probs], rows, self.workgroups)
+            self._scratch = [torch.empty(sl * co * ci, dtype=torch.float32, device=probs[0][0].device) for sl, (_, _, _, co, ci, _) in zip(slices, probs)]
+            arr = (_lib.WgradProblem * len(probs))()
+            for k, ((g, a, dw, co, ci, cr), sl) in enumerate(zip(probs, slices)):
+                arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = g.data_ptr(), a.data_ptr(), dw.data_ptr(), self._scratch[k].data_ptr()
+                arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices = g.shape[0], co, ci, cr, sl
+            self._key, self._arr, self.slices = key, arr, slices
+        _lib.check(_lib.load().bg_mlp_weight_grad_group(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
+
+
 class MLPTrainer:
     """Hand-scheduled forward / backward of one of the two ELU MLPs for the full-batch PPO update (replaces autograd for
     reference utils/runner.py:132,147,163).  Same arithmetic as torch's Linear/ELU autograd, different schedule:
@@ -72,13 +113,12 @@ class MLPTrainer:
         self.w0pad = torch.zeros(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if k_in != l0.weight.shape[1] else None
         self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
 
-    # Weight gradients: BG_FUSED_WGRAD=1 selects the hand-written kernel (bg_mlp_weight_grad), the default is the library path (split-K bmm + sum).
-    # Measured on MI355X at M = 98,304 (tools/wgrad_probe.py, tools/ab_wgrad.sh; round 2): stand-alone 111 vs 102 us (256x256), 67 vs 59 (128x256),
-    # 42 vs 34 (128x128), 39 vs 35 us (256x64) -- the MFMA loop itself runs at 80-90 % of the fp32 matrix rate, but a K-split over 256 workgroups
-    # writes and re-reads 16.8 MB of partial tiles per call where hipBLASLt's 32-slice batched GEMM moves 2-8 MB; in the training loop the
-    # update phase takes 26.6 ms with it against 24.6 ms with the library GEMMs (its 512-register workgroups cannot share a CU with the other
-    # stream's kernels).  So the faster path stays the default.
-    FUSED_WGRAD = __import__("os").environ.get("BG_FUSED_WGRAD", "0") == "1"
+    # Weight gradients (the dW part of loss.backward(), runner.py:163): hand-written fp32-MFMA kernel, ALL hidden layers of both networks in one
+    # launch pair after both backward chains (bg_mlp_weight_grad_group, GroupedWeightGrad; DEFER_WGRAD below).  Measured on MI355X, round 2
+    # (tools/ab_defer.sh, update phase per iteration): library split-K bmm + sum inside the chains 24.13 ms; the hand-written kernel one layer at a
+    # time inside the chains 26.46 ms (its 512-register, 128 KB-LDS workgroups cannot share a CU with the other stream's kernels); the library
+    # path deferred 24.39 ms; the grouped hand-written launch 23.01 ms = 3.77 M env-steps/s against 3.61 M.  BG_FUSED_WGRAD=0 selects the library path.
+    FUSED_WGRAD = __import__("os").environ.get("BG_FUSED_WGRAD", "1") == "1"
     WGRAD_WORKGROUPS = int(__import__("os").environ.get("BG_WGRAD_WORKGROUPS", "256"))  # one 4-wave workgroup per CU
 
     @classmethod
@@ -153,25 +193,60 @@ class MLPTrainer:
         layer's weight / bias gradients have already been written by the fused head kernel."""
         self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g)
 
+    # The backward chain computes only dL/dz; the weight gradients of all layers run afterwards, when both networks' chains are done and nothing
+    # else competes for the GPU (grouped launch, or `weight_grads()` layer by layer).  BG_DEFER_WGRAD=0: inside the chain, as in round 1.
+    DEFER_WGRAD = __import__("os").environ.get("BG_DEFER_WGRAD", "1") == "1"
+
+    def pending_wgrad_problems(self):
+        """(G, A, dW, C_out, C_in (padded), C_in_real) of every deferred weight gradient, and clears the list (for the grouped launch)."""
+        out = []
+        for i, g in self._pending_wgrad:
+            if not self.wg_slices[i]:  # shape outside the kernel's range: the library path, now
+                self._weight_grad(i, g)
+                continue
+            l = self.layers[i]
+            a_in = (self.acts[i - 1] if i > 0 else self.x)[: self._B]
+            out.append((g, a_in, l.weight.grad, l.weight.shape[0], a_in.shape[1], l.weight.shape[1]))
+        self._pending_wgrad = []
+        return out
+
+    def weight_grads(self):
+        """The deferred weight gradients of `_backward_from` (DEFER_WGRAD): layers in the order the chain visited them."""
+        for i, g in self._pending_wgrad:
+            self._weight_grad(i, g)
+        self._pending_wgrad = []
+
+    def _weight_grad(self, i, g):
+        lib, stream = _lib.load(), _lib.current_stream_ptr()
+        B, S = self._B, self._S
+        l = self.layers[i]
+        a_in = (self.acts[i - 1] if i > 0 else self.x)[:B]
+        C_out, C_in = l.weight.shape
+        if self.wg_slices[i]:
+            # dW = G^T A in one hand-written launch pair, written straight into the flat gradient buffer (padded input columns dropped)
+            _lib.check(lib.bg_mlp_weight_grad(B, C_out, a_in.shape[1], C_in, _lib.ptr(g), _lib.ptr(a_in), _lib.ptr(l.weight.grad), _lib.ptr(self.dw[i]),
+                                              self.wg_slices[i], stream), "bg_mlp_weight_grad")
+        elif i == 0 and self.w0pad is not None:  # padded input columns: their gradient columns are dropped
+            torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, self._kin), out=self.dw[0])
+            torch.sum(self.dw[0], dim=0, out=self.dw0sum)
+            l.weight.grad.copy_(self.dw0sum[:, :C_in])
+        else:
+            torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
+            torch.sum(self.dw[i], dim=0, out=l.weight.grad)
+
     def _backward_from(self, start, g):
         lib = _lib.load()
-        B, S = self._B, self._S
+        B = self._B
         stream = _lib.current_stream_ptr()
+        self._pending_wgrad = []
         for i in range(start, -1, -1):
             l = self.layers[i]
             a_in = (self.acts[i - 1] if i > 0 else self.x)[:B]
             C_out, C_in = l.weight.shape
-            if self.wg_slices[i]:
-                # dW = G^T A in one hand-written launch pair, written straight into the flat gradient buffer (padded input columns dropped)
-                _lib.check(lib.bg_mlp_weight_grad(B, C_out, a_in.shape[1], C_in, _lib.ptr(g), _lib.ptr(a_in), _lib.ptr(l.weight.grad), _lib.ptr(self.dw[i]),
-                                                  self.wg_slices[i], stream), "bg_mlp_weight_grad")
-            elif i == 0 and self.w0pad is not None:  # padded input columns: their gradient columns are dropped
-                torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, self._kin), out=self.dw[0])
-                torch.sum(self.dw[0], dim=0, out=self.dw0sum)
-                l.weight.grad.copy_(self.dw0sum[:, :C_in])
+            if self.DEFER_WGRAD:
+                self._pending_wgrad.append((i, g))
             else:
-                torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
-                torch.sum(self.dw[i], dim=0, out=l.weight.grad)
+                self._weight_grad(i, g)
             if i > 0:
                 below = self.layers[i - 1]
                 if self.FUSED and C_out in (128, 256) and C_in % 128 == 0:

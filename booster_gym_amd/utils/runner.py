@@ -31,7 +31,7 @@ from .. import _lib
 from ..envs import TASKS
 from .buffer import ExperienceBuffer
 from .config import load_cfg
-from .model import ActorCritic, MLPTrainer
+from .model import ActorCritic, GroupedWeightGrad, MLPTrainer
 from .parallel import DataParallel
 from .recorder import Recorder
 from .utils import (actor_head_forward, actor_head_loss_backward, critic_head_backward, critic_head_forward, gae, gaussian_logp, head_scratch,
@@ -187,6 +187,7 @@ class Runner:
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
         self._logstd_off = (self._logstd_grad_view.data_ptr() - self.optimizer.grad.data_ptr()) // 4  # position of logstd in the flat buffers
         self._actor_tr, self._critic_tr = MLPTrainer(self.model.actor), MLPTrainer(self.model.critic)
+        self._wgrad_group = GroupedWeightGrad()
         self._side_stream = torch.cuda.Stream(device=self.device)
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
         # library GEMMs + bg_ppo_loss for these layers (A/B comparisons).
@@ -353,6 +354,12 @@ class Runner:
                 if self.dp.active or not fused_tail:
                     self._logstd_grad_view.copy_(self._grad_logstd)  # into the flat bucket before the all-reduce
                 main.wait_stream(side)
+                if MLPTrainer.DEFER_WGRAD:  # all weight gradients after both backward chains, alone on the GPU
+                    if MLPTrainer.FUSED_WGRAD and MLPTrainer.FUSED:
+                        self._wgrad_group.run((self._critic_tr, self._actor_tr))  # one launch pair for the six layers
+                    else:
+                        self._critic_tr.weight_grads()
+                        self._actor_tr.weight_grads()
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
                 if fused_tail:
                     # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch

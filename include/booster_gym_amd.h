@@ -284,6 +284,18 @@ int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const float* G, const
 int bg_mlp_weight_grad(int32_t M, int32_t C_out, int32_t C_in, int32_t C_in_real, const float* G, const float* A, float* dW, float* scratch,
                        int32_t slices, void* stream);
 
+/* The weight gradients of several layers in ONE launch pair (the dW part of `loss.backward()` for all hidden layers of both networks, after both
+ * backward chains): same arithmetic and argument meaning per layer as bg_mlp_weight_grad; `slices` of a layer may be any value in [1, M/8] -- size
+ * them in proportion to the layers' cost (rows x tile width) so that every workgroup of the launch does the same amount of work.  count <= 8. */
+typedef struct {
+    const float* G;      /* [M][C_out] dL/dz of the layer */
+    const float* A;      /* [M][C_in] its input activations (feature dimension possibly zero-padded) */
+    float* dW;           /* [C_out][C_in_real] */
+    float* scratch;      /* slices * C_out * C_in floats */
+    int32_t M, C_out, C_in, C_in_real, slices;
+} bg_wgrad_problem;
+int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream);
+
 /* ---- output ("head") layers fused with the loss: the 128 -> 12 / 128 -> 1 Linear layers of utils/model.py:13,21 together with
  * runner.py:145-174.  h [rows][128] = activations of the last hidden (ELU) layer, 16-byte aligned.  One launch reads h once instead of
  * the seven library GEMM / elementwise passes these skinny layers otherwise take per network and mini-epoch.

@@ -108,3 +108,37 @@ def test_mlp_weight_grad_rejects_bad_arguments():
     assert lib.bg_mlp_weight_grad(32, 128, 128, 128, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 8, st) == -4    # slices * 8 > M
     assert lib.bg_mlp_weight_grad(256, 128, 128, 129, _lib.ptr(G), _lib.ptr(A), _lib.ptr(dW), _lib.ptr(sc), 8, st) == -1   # C_in_real
     assert lib.bg_mlp_weight_grad(256, 128, 128, 128, _lib.ptr(G), None, _lib.ptr(dW), _lib.ptr(sc), 8, st) == -1
+
+
+def test_mlp_weight_grad_group_matches_torch_fp64():
+    """bg_mlp_weight_grad_group: the six hidden-layer weight gradients of both networks in one launch pair, slices sized by plan_wgrad_slices
+    (uneven on purpose: 12 / 23 / 24 slices, runs that are not multiples of the kernel's 16-row-pair trip); each against torch float64."""
+    from booster_gym_amd import _lib
+    from booster_gym_amd.utils.model import plan_wgrad_slices
+
+    M = 98304
+    shapes = [(256, 64, 61), (256, 256, 256), (128, 256, 256), (256, 64, 47), (128, 256, 256), (128, 128, 128)]
+    slices = plan_wgrad_slices([(co, ci) for co, ci, _ in shapes], M, 256)
+    assert sum((co // 128) * max(1, ci // 128) * s for (co, ci, _), s in zip(shapes, slices)) <= 256 and min(slices) >= 8
+    torch.manual_seed(5)
+    arr = (_lib.WgradProblem * len(shapes))()
+    keep = []
+    for k, ((co, ci, cr), sl) in enumerate(zip(shapes, slices)):
+        G = torch.randn(M, co, device=DEV); A = torch.randn(M, ci, device=DEV); A[:, cr:] = 0.0
+        G[:, 3] *= 3.0; A[:, 1] += 0.5; G[0, co - 1] = 40.0; A[0, cr - 1] = -25.0
+        dW = torch.full((co, cr), float("nan"), device=DEV); sc = torch.empty(sl * co * ci, device=DEV)
+        keep.append((G, A, dW, sc))
+        arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = G.data_ptr(), A.data_ptr(), dW.data_ptr(), sc.data_ptr()
+        arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices = M, co, ci, cr, sl
+    _lib.check(_lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
+    for (co, ci, cr), (G, A, dW, sc) in zip(shapes, keep):
+        ref64 = G.double().t() @ A.double()[:, :cr]
+        ref32 = G.t() @ A[:, :cr]
+        err, err_t = (dW.double() - ref64).abs().max().item(), (ref32.double() - ref64).abs().max().item()
+        assert torch.isfinite(dW).all() and err <= max(4 * err_t, 1e-4), (co, ci, err, err_t)
+    first = [dW.clone() for _, _, dW, _ in keep]
+    _lib.check(_lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
+    assert all(torch.equal(a, dW) for a, (_, _, dW, _) in zip(first, keep))  # deterministic
+    assert _lib.load().bg_mlp_weight_grad_group(arr, 9, _lib.current_stream_ptr()) == -1
+    arr[0].slices = M  # more than M / 8
+    assert _lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()) == -4
