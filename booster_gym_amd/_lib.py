@@ -43,7 +43,7 @@ class AssetOptions(C.Structure):
 
 class WgradProblem(C.Structure):
     _fields_ = [("G", C.c_void_p), ("A", C.c_void_p), ("dW", C.c_void_p), ("scratch", C.c_void_p), ("M", C.c_int32), ("C_out", C.c_int32), ("C_in", C.c_int32),
-                ("C_in_real", C.c_int32), ("slices", C.c_int32)]
+                ("C_in_real", C.c_int32), ("slices", C.c_int32), ("tiles_per_workgroup", C.c_int32)]
 
 
 class Rand(C.Structure):

@@ -28,16 +28,21 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 // Workgroups that read the same rows (the tiles of one slice) are given block indices 8 apart, i.e. the same XCD and L2 (speed only).
 constexpr int WG_RED_FLOATS = 4 * 64 * 16 * 2 * 4;  // LDS of the in-workgroup reduction: 4 waves x 2 co-tiles x 16 registers x 64 lanes x TCI (<= 4) floats = 128 KB
 template <int TCI>  // 32-column C_in tiles per wave: 4 (128 input columns per workgroup) or 2 (64: the zero-padded first layers)
+// A workgroup's 4 waves cover `tw` output tiles (tile0 .. tile0 + tw - 1) x ks = 4 / tw sub-ranges of the slice's rows: tw = 1 is the pure split
+// over rows; with tw = 2 or 4 the waves that work on the SAME rows (different tiles) fetch each G / A row block once per CU instead of once per
+// tile -- at 32 flop per loaded byte a 128 x 128 tile per wave sits on the machine's flop / byte ridge, so layers with several tiles trade
+// partial-tile traffic (4 / ks times more of it) for input traffic (bg_mlp_weight_grad_group's planner picks tw per layer).
 __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int Cin, const float* __restrict__ G, const float* __restrict__ A,
-                                           float* __restrict__ P, int ntile_ci, int tile, int slice, int slices) {
+                                           float* __restrict__ P, int ntile_ci, int tile0, int tw, int slice, int slices) {
     constexpr int D = 8;  // row pairs per register set: 2 sets x D x (4 + TCI) registers of loads in flight under D x 4 x TCI MFMAs
     typedef float avec __attribute__((ext_vector_type(TCI)));
     float (*red)[64 * 16 * 2 * TCI] = reinterpret_cast<float (*)[64 * 16 * 2 * TCI]>(red_base);
-    const int tco = tile / ntile_ci, tci = tile % ntile_ci;
     // wave-uniform values are forced into SGPRs: the loads then take the scalar-base + 32-bit lane offset form and the walk over the rows
     // is scalar arithmetic (per-lane 64-bit addresses for 2 x D x 2 loads in flight do not fit beside 256 accumulators)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
-    const long KP = M >> 1, W = (long)slices * 4, widx = (long)slice * 4 + wave;
+    const int ks = 4 / tw, tl = wave % tw, ksub = wave / tw, tile = tile0 + tl;
+    const int tco = tile / ntile_ci, tci = tile % ntile_ci;
+    const long KP = M >> 1, W = (long)slices * ks, widx = (long)slice * ks + ksub;
     const int kp0 = (int)(KP * widx / W), kp1 = (int)(KP * (widx + 1) / W);
     const unsigned gofb = 4u * (h * Cout + tco * 128 + 4 * i), aofb = 4u * (h * Cin + tci * (32 * TCI) + TCI * i);  // byte offsets of this lane
     const char* Gb = reinterpret_cast<const char*>(G);
@@ -93,12 +98,13 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
         fma_set(g0, a0);
         fma_set(g1, a1);
     }
-    // Add the four waves' tiles through LDS in two rounds of two co-tiles (4 waves x 2 x 16 registers x 64 lanes x TCI floats = 128 KB at
-    // TCI = 4): every wave writes its half, then wave w sums the four copies of 8 registers of co-tile (w >> 1) of the round and stores them.
-    // The same code for every wave (no wave-conditional use of the accumulators), and the partial tile leaves through all four waves.
+    // Add the ks waves' copies of each tile through LDS in two rounds of two co-tiles (4 waves x 2 x 16 registers x 64 lanes x TCI floats = 128 KB
+    // at TCI = 4): every wave writes its half, then the ks waves of a tile split the round's 32 register groups among them, sum the ks copies and
+    // store.  The same code for every wave and every ks (no wave-conditional use of the accumulators; ks = 1 passes its own copy through LDS).
     // C layout of a 32 x 32 tile: column (B operand index) = lane & 31, row (A operand index) = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5).
     // Tile (t, u) of a wave holds output rows co = 4 * row + t and columns ci = TCI * col + u: a lane stores TCI consecutive columns.
     float* pt = P + (size_t)slice * Cout * Cin + (size_t)(tco * 128) * Cin + tci * (32 * TCI) + TCI * i;
+    const int ipw = 32 / ks;  // register groups per wave and round
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         if (half) __syncthreads();
@@ -112,13 +118,11 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
                 *reinterpret_cast<avec*>(&red[wave][((tt * 16 + r) * 64 + lane) * TCI]) = v;
             }
         __syncthreads();
-        const int tt = wave >> 1, t = 2 * half + tt;
-#pragma unroll
-        for (int r8 = 0; r8 < 8; r8++) {
-            const int r = 8 * (wave & 1) + r8, idx = ((tt * 16 + r) * 64 + lane) * TCI;
-            const avec v = (*reinterpret_cast<const avec*>(&red[0][idx]) + *reinterpret_cast<const avec*>(&red[1][idx])) +
-                           (*reinterpret_cast<const avec*>(&red[2][idx]) + *reinterpret_cast<const avec*>(&red[3][idx]));
-            const int row = (r & 3) + 8 * (r >> 2) + 4 * h;
+        for (int k = 0; k < ipw; k++) {
+            const int it = ksub * ipw + k, tt = it >> 4, r = it & 15, idx = ((tt * 16 + r) * 64 + lane) * TCI;
+            avec v = *reinterpret_cast<const avec*>(&red[tl][idx]);
+            for (int c = 1; c < ks; c++) v += *reinterpret_cast<const avec*>(&red[tl + tw * c][idx]);
+            const int row = (r & 3) + 8 * (r >> 2) + 4 * h, t = 2 * half + tt;
             *reinterpret_cast<avec*>(pt + (size_t)(4 * row + t) * Cin) = v;
         }
     }
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(int M, int Cout, int 
                                                            float* __restrict__ P, int ntile_ci, int ntiles, int slices) {
     __shared__ __attribute__((aligned(16))) float red[WG_RED_FLOATS / 4 * TCI];
     const int b = blockIdx.x, q = b >> 3, tile = q % ntiles, slice = (q / ntiles) * 8 + (b & 7);
-    wgrad_tile<TCI>(red, M, Cout, Cin, G, A, P, ntile_ci, tile, slice, slices);
+    wgrad_tile<TCI>(red, M, Cout, Cin, G, A, P, ntile_ci, tile, 1, slice, slices);
 }
 
 // Several layers in ONE launch (bg_mlp_weight_grad_group): the weight gradients of all hidden layers of both networks, after both backward
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(int M, int Cout, int 
 constexpr int WG_MAX_PROBLEMS = 8;
 struct WgradProblem {
     const float* G; const float* A; float* P; float* dW;
-    int M, Cout, Cin, Cin_real, tci, ntile_ci, ntiles, slices, wg_begin, fin_begin, n4;
+    int M, Cout, Cin, Cin_real, tci, ntile_ci, ntiles, tw, slices, wg_begin, fin_begin, n4;
 };
 struct WgradGroup { int np; WgradProblem p[WG_MAX_PROBLEMS]; };
 
@@ -152,9 +156,9 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_group_kernel(WgradGroup grp)
     for (int j = 1; j < WG_MAX_PROBLEMS; j++)
         if (j < grp.np && b >= grp.p[j].wg_begin) k = j;
     const WgradProblem& pr = grp.p[k];
-    const int local = b - pr.wg_begin, tile = local % pr.ntiles, slice = local / pr.ntiles;
-    if (pr.tci == 4) wgrad_tile<4>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile, slice, pr.slices);
-    else wgrad_tile<2>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile, slice, pr.slices);
+    const int groups = pr.ntiles / pr.tw, local = b - pr.wg_begin, tile0 = (local % groups) * pr.tw, slice = local / groups;
+    if (pr.tci == 4) wgrad_tile<4>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile0, pr.tw, slice, pr.slices);
+    else wgrad_tile<2>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile0, pr.tw, slice, pr.slices);
 }
 
 // dW[co][ci < Cin_real] = sum over slices of P[s][co][ci], slices added in a fixed order; 16 float4 columns x 16 slice groups per workgroup
@@ -252,8 +256,12 @@ extern "C" int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_
         p.M = q.M; p.Cout = q.C_out; p.Cin = q.C_in; p.Cin_real = q.C_in_real; p.tci = q.C_in == 64 ? 2 : 4;
         p.ntile_ci = q.C_in == 64 ? 1 : q.C_in / 128;
         p.ntiles = (q.C_out / 128) * p.ntile_ci;
+        p.tw = q.tiles_per_workgroup <= 0 ? 1 : q.tiles_per_workgroup;
+        if ((p.tw != 1 && p.tw != 2 && p.tw != 4) || p.ntiles % p.tw != 0)
+            return bg_set_error(-4, "bg_mlp_weight_grad_group: tiles_per_workgroup must be 1, 2 or 4 and divide the layer's tile count");
+        if ((long)q.slices * (4 / p.tw) * 2 > q.M) return bg_set_error(-4, "bg_mlp_weight_grad_group: too many slices for M");
         p.slices = q.slices;
-        p.wg_begin = wg; wg += p.ntiles * p.slices;
+        p.wg_begin = wg; wg += (p.ntiles / p.tw) * p.slices;
         p.n4 = q.C_out * q.C_in / 4;
         p.fin_begin = fin; fin += (p.n4 + 15) / 16;
     }

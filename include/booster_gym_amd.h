@@ -286,13 +286,16 @@ int bg_mlp_weight_grad(int32_t M, int32_t C_out, int32_t C_in, int32_t C_in_real
 
 /* The weight gradients of several layers in ONE launch pair (the dW part of `loss.backward()` for all hidden layers of both networks, after both
  * backward chains): same arithmetic and argument meaning per layer as bg_mlp_weight_grad; `slices` of a layer may be any value in [1, M/8] -- size
- * them in proportion to the layers' cost (rows x tile width) so that every workgroup of the launch does the same amount of work.  count <= 8. */
+ * them so that every workgroup of the launch does the same amount of work (booster_gym_amd/utils/model.py:plan_wgrad_slices).  One workgroup per
+ * (group of tiles_per_workgroup tiles, slice).  count <= 8. */
 typedef struct {
     const float* G;      /* [M][C_out] dL/dz of the layer */
     const float* A;      /* [M][C_in] its input activations (feature dimension possibly zero-padded) */
     float* dW;           /* [C_out][C_in_real] */
     float* scratch;      /* slices * C_out * C_in floats */
     int32_t M, C_out, C_in, C_in_real, slices;
+    int32_t tiles_per_workgroup; /* 1 (default for 0), 2 or 4, dividing the layer's count of 128-wide output tiles: the 4 waves of a workgroup cover
+                                  * this many tiles x 4 / this many sub-ranges of the slice's rows; waves on the same rows share the fetched rows */
 } bg_wgrad_problem;
 int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream);
 

@@ -110,7 +110,8 @@ def test_mlp_weight_grad_rejects_bad_arguments():
     assert lib.bg_mlp_weight_grad(256, 128, 128, 128, _lib.ptr(G), None, _lib.ptr(dW), _lib.ptr(sc), 8, st) == -1
 
 
-def test_mlp_weight_grad_group_matches_torch_fp64():
+@pytest.mark.parametrize("share_rows", [True, False])
+def test_mlp_weight_grad_group_matches_torch_fp64(share_rows):
     """bg_mlp_weight_grad_group: the six hidden-layer weight gradients of both networks in one launch pair, slices sized by plan_wgrad_slices
     (uneven on purpose: 12 / 23 / 24 slices, runs that are not multiples of the kernel's 16-row-pair trip); each against torch float64."""
     from booster_gym_amd import _lib
@@ -118,8 +119,9 @@ def test_mlp_weight_grad_group_matches_torch_fp64():
 
     M = 98304
     shapes = [(256, 64, 61), (256, 256, 256), (128, 256, 256), (256, 64, 47), (128, 256, 256), (128, 128, 128)]
-    slices = plan_wgrad_slices([(co, ci) for co, ci, _ in shapes], M, 256)
-    assert sum((co // 128) * max(1, ci // 128) * s for (co, ci, _), s in zip(shapes, slices)) <= 256 and min(slices) >= 8
+    slices, tw = plan_wgrad_slices([(co, ci) for co, ci, _ in shapes], M, 256, share_rows=share_rows)
+    assert sum((co // 128) * max(1, ci // 128) // w * s for (co, ci, _), s, w in zip(shapes, slices, tw)) <= 256 and min(slices) >= 8
+    assert tw == ([2, 4, 2, 2, 2, 1] if share_rows else [1] * 6)
     torch.manual_seed(5)
     arr = (_lib.WgradProblem * len(shapes))()
     keep = []
@@ -129,7 +131,7 @@ def test_mlp_weight_grad_group_matches_torch_fp64():
         dW = torch.full((co, cr), float("nan"), device=DEV); sc = torch.empty(sl * co * ci, device=DEV)
         keep.append((G, A, dW, sc))
         arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = G.data_ptr(), A.data_ptr(), dW.data_ptr(), sc.data_ptr()
-        arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices = M, co, ci, cr, sl
+        arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices, arr[k].tiles_per_workgroup = M, co, ci, cr, sl, tw[k]
     _lib.check(_lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
     for (co, ci, cr), (G, A, dW, sc) in zip(shapes, keep):
         ref64 = G.double().t() @ A.double()[:, :cr]
@@ -141,4 +143,6 @@ def test_mlp_weight_grad_group_matches_torch_fp64():
     assert all(torch.equal(a, dW) for a, (_, _, dW, _) in zip(first, keep))  # deterministic
     assert _lib.load().bg_mlp_weight_grad_group(arr, 9, _lib.current_stream_ptr()) == -1
     arr[0].slices = M  # more than M / 8
+    assert _lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()) == -4
+    arr[0].slices, arr[5].tiles_per_workgroup = slices[0], 2  # the 128 x 128 layer has one tile
     assert _lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()) == -4

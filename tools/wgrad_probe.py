@@ -43,4 +43,19 @@ for C_out, C_in, C_real in [(256, 64, 47), (128, 256, 256), (128, 128, 128), (25
     res["best_tflops"] = round(flop / best / 1e6, 1); res["frac_of_157.3"] = round(flop / best / 1e6 / 157.3, 3)
     out[f"{C_out}x{C_in}"] = res
     print(f"{C_out}x{C_in}: {res}", flush=True)
+# all six layers of both networks in one grouped launch (what the training loop runs)
+from booster_gym_amd.utils.model import plan_wgrad_slices
+shapes = [(256, 64, 61), (256, 256, 256), (128, 256, 256), (256, 64, 47), (128, 256, 256), (128, 128, 128)]
+for wgs, share in ((256, False), (256, True), (248, True), (512, True)):
+    sl, tw = plan_wgrad_slices([(co, ci) for co, ci, _ in shapes], M, wgs, share_rows=share)
+    arr = (_lib.WgradProblem * len(shapes))(); keep = []
+    for k, ((co, ci, cr), s_) in enumerate(zip(shapes, sl)):
+        G = torch.randn(M, co, device=dev); A = torch.randn(M, ci, device=dev); dW = torch.empty(co, cr, device=dev); sc = torch.empty(s_ * co * ci, device=dev)
+        keep.append((G, A, dW, sc))
+        arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = G.data_ptr(), A.data_ptr(), dW.data_ptr(), sc.data_ptr()
+        arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices, arr[k].tiles_per_workgroup = M, co, ci, cr, s_, tw[k]
+    us = timeit(lambda: _lib.check(lib.bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr())))
+    flop = sum(2.0 * M * co * ci for co, ci, _ in shapes)
+    out[f"grouped_{wgs}wg_share{int(share)}"] = {"us": round(us, 1), "slices": sl, "tiles_per_workgroup": tw, "tflops": round(flop / us / 1e6, 1), "frac_of_157.3": round(flop / us / 1e6 / 157.3, 3)}
+    print(f"grouped, {wgs} workgroups, share_rows={share}: {out[f'grouped_{wgs}wg_share{int(share)}']}", flush=True)
 json.dump({"M": M, "shapes": out}, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "wgrad_probe.json"), "w"), indent=1)
