@@ -213,6 +213,7 @@ def main():
     # critic layer 1 (256 -> 256): the single largest kernel of the update; critic layer 2 (256 -> 128): the symbol with the largest TOTAL time
     # (mlp_fwd_kernel<256,1,1>, shared with the actor's layer 1)
     runner._critic_tr.timed_layer = (1, 2)
+    runner._wgrad_group.timed_events = []  # the grouped weight-gradient launch: the kernel with the largest total time of the iteration
     if world > 1:
         runner.dp.timed_events = []  # HIP events around the gradient-bucket all-reduce of every mini-epoch
     barrier()
@@ -303,6 +304,25 @@ def main():
             solo_us = gemm_us
         gemm_flop = 2.0 * rows_g * kg * ng
         gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
+        layer_fwd = {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF,
+                     "traffic": pmc_traffic("mlp_fwd_kernel<256, 1, 2>") if rows_g == (T + 1) * 4096 else None, "traffic_source": PMC_SOURCE,
+                     "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop,
+                     "note": "timed inside the loop, where the actor's kernels run beside it on the second stream",
+                     "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,
+                                          "frac": gemm_flop / (solo_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}}
+        if args.no_extra:
+            layer_fwd.pop("alone_on_the_gpu", None)
+        wg_ev = runner._wgrad_group.timed_events or []
+        headline = layer_fwd
+        if wg_ev:  # the dominant kernel of the iteration by total time (profiles/r02_bench_kernel_stats.csv): all six hidden-layer weight gradients
+            wus = sum(a.elapsed_time(b) for a, b, *_ in wg_ev) / len(wg_ev) * 1e3
+            wfl = wg_ev[0][2]
+            headline = {"kernel": "mlp_wgrad_group_kernel (+ its fixed-order finish): dW = G^T A of all six hidden layers of both networks in one launch pair, " +
+                                  " + ".join(f"[{co}x{m}]x[{m}x{ci}]" for m, co, ci in wg_ev[0][3]) + ", fp32 MFMA 32x32x2 (hand-written HIP, bg_wgrad.hip)",
+                        "bound": "mfma", "achieved": wfl / (wus * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": wfl / (wus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("mlp_wgrad_group_kernel") if N == 4096 else None,
+                        "traffic_source": PMC_SOURCE, "avg_launch_us": wus, "algorithmic_flops_per_launch": wfl,
+                        "note": "launch pair (main kernel + finish) timed inside the loop with HIP events on its stream; it runs after both backward chains, alone on the GPU"}
         # HBM traffic per launch comes from PMC counters, which rocprofv3 collects in separate passes of the same command (tools/profile.sh
         # -> profiles/<PMC_TAG>_*_pmc.json, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes); the JSON line names the file it cites
         traffic = pmc_traffic("env_step_kernel", which="env") if N == 4096 else None
@@ -315,11 +335,8 @@ def main():
                        "envs_per_gpu": N, "parallelism": f"dp{world}"},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms, "all_reduce_ms": ar_ms},
-            "roofline": {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF,
-                         "traffic": pmc_traffic("mlp_fwd_kernel<256, 1, 2>") if rows_g == (T + 1) * 4096 else None, "traffic_source": PMC_SOURCE,
-                         "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop,
-                         "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,
-                                              "frac": gemm_flop / (solo_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}},
+            "roofline": headline,
+            "roofline_layer_forward": layer_fwd,
             "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",
                                   "achieved": sim_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS, "traffic": traffic,
                                   "traffic_source": PMC_SOURCE, "avg_launch_us": step_ms * 1e3, "algorithmic_bytes_per_launch": env_bytes,
@@ -331,8 +348,6 @@ def main():
         }
         if top_by_time is not None:
             out["roofline_top_by_time"] = top_by_time
-        if args.no_extra:
-            out["roofline"].pop("alone_on_the_gpu", None)
         if world == 1 and not args.no_extra:
             try:
                 del runner.env

@@ -55,6 +55,7 @@ class GroupedWeightGrad:
         # 0.3 ms slower per update in the loop (4x the partial-tile traffic for the 256 x 256 layer), so the pure split over rows stays the default
         self.share_rows = __import__("os").environ.get("BG_WGRAD_SHARE_ROWS", "0") == "1"
         self._key, self._arr, self._scratch = None, None, None
+        self.timed_events = None
 
     def run(self, trainers):
         probs = [p for tr in trainers for p in tr.pending_wgrad_problems()]
@@ -70,7 +71,14 @@ class GroupedWeightGrad:
                 arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = g.data_ptr(), a.data_ptr(), dw.data_ptr(), self._scratch[k].data_ptr()
                 arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices, arr[k].tiles_per_workgroup = g.shape[0], co, ci, cr, sl, tw[k]
             self._key, self._arr, self.slices, self.tw = key, arr, slices, tw
+        ev = self.timed_events
+        if ev is not None:  # bench.py: HIP events on the launch stream around the launch pair
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         _lib.check(_lib.load().bg_mlp_weight_grad_group(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
+        if ev is not None:
+            e1.record()
+            ev.append((e0, e1, sum(2.0 * g.shape[0] * co * ci for g, _, _, co, ci, _ in probs), [(g.shape[0], co, ci) for g, _, _, co, ci, _ in probs]))
 
 
 class MLPTrainer:
