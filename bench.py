@@ -187,8 +187,7 @@ def main():
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
-            dist.barrier()
+        runner.dp.barrier()
         torch.cuda.synchronize()
 
     def log(msg):

@@ -161,7 +161,11 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
                 if (EPI == 1) { v0 = elu_f(v0); v1 = elu_f(v1); v2 = elu_f(v2); v3 = elu_f(v3); }
                 quad_transpose(v0, v1, v2, v3, c4);
                 const int rr = rbase + 8 * g + 4 * h + c4;
+#ifdef BG_PROBE_NO_STORE  // tools/mlp_nostore_probe.py: how much of the kernel is its store tail?  (never defined in the product build)
+                if (rr < M && v0 == 12345.678f) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
+#else
                 if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
+#endif
             }
         }
     } else {

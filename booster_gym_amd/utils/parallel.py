@@ -87,7 +87,10 @@ class DataParallel:
 
     def barrier(self):
         if self.active:
-            dist.barrier()
+            if self.backend == "nccl":  # name the device: without it the backend guesses one from the global rank
+                dist.barrier(device_ids=[self.device_index])
+            else:
+                dist.barrier()
 
     def shutdown(self):
         if self.active and self.owns_group and dist.is_initialized():
