@@ -16,28 +16,7 @@ extern int bg_set_error(int code, const char* msg);
         if (_e != hipSuccess) return bg_set_error(-2, hipGetErrorString(_e));               \
     } while (0)
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's float4 struct blocked SROA here)
-
-// exp(x) - 1 through v_exp_f32: absolute error ~1e-7 on (-1, 0], far below fp32 activation noise; expm1f costs ~20 VALU per element
-__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
-
-// 4 x 4 transpose across the 4 lanes of a quad: in: lane c holds (v0..v3) = column c of a block M[k][c]; out: lane c holds row c, M[c][0..3].
-__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }  // quad_perm [1,0,3,2]
-__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }  // quad_perm [2,3,0,1]
-__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int c) {
-    const bool odd = c & 1, hi = c & 2;
-    // stage 1 (lanes c ^ 1): swap the off-diagonal elements of the 2 x 2 blocks (v0, v1) and (v2, v3)
-    float s01 = dpp_xor1(odd ? v0 : v1), s23 = dpp_xor1(odd ? v2 : v3);
-    if (odd) { v0 = s01; v2 = s23; } else { v1 = s01; v3 = s23; }
-    // stage 2 (lanes c ^ 2): swap the off-diagonal 2 x 2 blocks: (v0, v1) of the upper lanes with (v2, v3) of the lower ones
-    float t02 = dpp_xor2(hi ? v0 : v2), t13 = dpp_xor2(hi ? v1 : v3);
-    if (hi) { v0 = t02; v1 = t13; } else { v2 = t02; v3 = t13; }
-}
-
-constexpr int FW_BM = 128;   // rows per workgroup (4 waves x 32 rows)
-constexpr int FW_KC = 32;    // k-chunk staged in LDS
-constexpr int FW_LDW = 36;   // LDS row stride (floats): 16-byte aligned rows, spreads the 16-byte reads over the banks
+#include "bg_mlp_tile.h"
 
 // one k-chunk (32 k-values) of MFMAs for this wave: 4 sub-steps x NT column tiles x 4 MFMAs
 template <int NT>
@@ -70,11 +49,6 @@ __device__ __forceinline__ void store_w_chunk(const f32x4 (&wreg)[LD4], float* s
         *reinterpret_cast<f32x4*>(&sWbuf[n * FW_LDW + 4 * c4]) = wreg[u];
     }
 }
-__device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, int kc) {
-#pragma unroll
-    for (int s = 0; s < 4; s++) a4[s] = *reinterpret_cast<const f32x4*>(xrow + kc * FW_KC + s * 8);
-}
-
 // Software pipeline, two k-chunks per loop trip with two explicit register sets (no copies, no scratch): the global loads of chunk c+1 are
 // issued before the MFMAs of chunk c and first waited for after them, so HBM latency hides under 64 MFMAs (4096 cycles) of this wave alone.
 // Each workgroup computes 128 rows x 128 columns (blockIdx.y = column block): with N = 256 the two column blocks of a row slab run
@@ -145,65 +119,7 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
         if (kc + 2 < CH) store_w_chunk<LD4>(wA, sW[0]);
         __syncthreads();
     }
-    // epilogue: C layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-    const int rbase = bx * FW_BM + wave * 32;
-    if constexpr (EPI <= 1) {
-        // The C layout gives a lane ONE column and 4 consecutive rows per register group; a 4 x 4 transpose inside every lane quad (two DPP
-        // exchange stages) turns that into one row and 4 consecutive columns, so that the tile leaves as 16 wide stores of 16 bytes per lane
-        // (8 full 128-byte lines per instruction) instead of 64 dword stores: the store tail of these kernels is issue-bound.
-        const int c4 = lane & 3;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            const float bv = bias[t * 32 + i];
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float v0 = acc[t][4 * g] + bv, v1 = acc[t][4 * g + 1] + bv, v2 = acc[t][4 * g + 2] + bv, v3 = acc[t][4 * g + 3] + bv;
-                if (EPI == 1) { v0 = elu_f(v0); v1 = elu_f(v1); v2 = elu_f(v2); v3 = elu_f(v3); }
-                quad_transpose(v0, v1, v2, v3, c4);
-                const int rr = rbase + 8 * g + 4 * h + c4;
-#ifdef BG_PROBE_NO_STORE  // tools/mlp_nostore_probe.py: how much of the kernel is its store tail?  (never defined in the product build)
-                if (rr < M && v0 == 12345.678f) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
-#else
-                if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
-#endif
-            }
-        }
-    } else {
-        float* csum = &sW[0][0];  // reuse the weight staging buffer: [4 waves][128 columns]
-        __syncthreads();
-        const int c4 = lane & 3;
-#pragma unroll
-        for (int t = 0; t < NT; t++) {
-            f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // this lane's row contributions to columns t * 32 + (i & ~3) + 0..3
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float v0 = acc[t][4 * g], v1 = acc[t][4 * g + 1], v2 = acc[t][4 * g + 2], v3 = acc[t][4 * g + 3];
-                quad_transpose(v0, v1, v2, v3, c4);
-                const f32x4 a = auxq[t][g];
-                const int rr = rbase + 8 * g + 4 * h + c4;
-                if (rr < M) {
-                    const f32x4 v = {v0 * (a.x > 0.f ? 1.0f : a.x + 1.0f), v1 * (a.y > 0.f ? 1.0f : a.y + 1.0f),
-                                     v2 * (a.z > 0.f ? 1.0f : a.z + 1.0f), v3 * (a.w > 0.f ? 1.0f : a.w + 1.0f)};
-                    *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = v;
-                    cs += v;
-                }
-            }
-            // rows live in the 4 lanes of a quad and in the two lane halves: add them up, lane (c4 == 0, h == 0) of every quad writes 4 columns
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                float x = cs[k];
-                x += dpp_xor1(x);
-                x += dpp_xor2(x);
-                x += __shfl_xor(x, 32);
-                cs[k] = x;
-            }
-            if (h == 0 && c4 == 0) *reinterpret_cast<f32x4*>(&csum[wave * N + t * 32 + i]) = cs;
-        }
-        __syncthreads();
-        if (threadIdx.x < N)
-            colpart[(size_t)bx * ldy + by * N + threadIdx.x] =
-                csum[threadIdx.x] + csum[N + threadIdx.x] + csum[2 * N + threadIdx.x] + csum[3 * N + threadIdx.x];
-    }
+    layer_epilogue<EPI, NT>(acc, auxq, M, ldy, bx, by, wave, lane, i, h, bias, Y, colpart, &sW[0][0]);  // csum reuses the weight staging buffer
 }
 
 __global__ __launch_bounds__(256) void mlp_colsum_finish_kernel(int nb, int C, const float* __restrict__ partial, float* __restrict__ out) {
@@ -262,4 +178,10 @@ extern "C" int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const floa
     BG_BWD(128)
 #undef BG_BWD
     return bg_set_error(-4, "bg_mlp_layer_backward: unsupported K (128, 256)");
+}
+
+// launch of the fixed-order column-sum finish for bg_mlp_split.hip's backward layer
+int bg_colsum_finish_launch(int nb, int C, const float* partial, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(mlp_colsum_finish_kernel, dim3(C), dim3(256), 0, st, nb, C, partial, out);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -1,0 +1,100 @@
+// Pieces shared by the layer kernels of bg_mlp.hip (fp32 MFMA) and bg_mlp_split.hip (split bf16 MFMA): tile constants, the A-operand load, the
+// 4 x 4 quad transpose and the epilogues.  gfx950 only.
+#pragma once
+#include <hip/hip_runtime.h>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's float4 struct blocked SROA here)
+
+// exp(x) - 1 through v_exp_f32: absolute error ~1e-7 on (-1, 0], far below fp32 activation noise; expm1f costs ~20 VALU per element
+__device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
+
+// 4 x 4 transpose across the 4 lanes of a quad: in: lane c holds (v0..v3) = column c of a block M[k][c]; out: lane c holds row c, M[c][0..3].
+__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }  // quad_perm [1,0,3,2]
+__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }  // quad_perm [2,3,0,1]
+__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int c) {
+    const bool odd = c & 1, hi = c & 2;
+    // stage 1 (lanes c ^ 1): swap the off-diagonal elements of the 2 x 2 blocks (v0, v1) and (v2, v3)
+    float s01 = dpp_xor1(odd ? v0 : v1), s23 = dpp_xor1(odd ? v2 : v3);
+    if (odd) { v0 = s01; v2 = s23; } else { v1 = s01; v3 = s23; }
+    // stage 2 (lanes c ^ 2): swap the off-diagonal 2 x 2 blocks: (v0, v1) of the upper lanes with (v2, v3) of the lower ones
+    float t02 = dpp_xor2(hi ? v0 : v2), t13 = dpp_xor2(hi ? v1 : v3);
+    if (hi) { v0 = t02; v1 = t13; } else { v2 = t02; v3 = t13; }
+}
+
+constexpr int FW_BM = 128;   // rows per workgroup (4 waves x 32 rows)
+constexpr int FW_KC = 32;    // k-chunk staged in LDS
+constexpr int FW_LDW = 36;   // LDS row stride (floats): 16-byte aligned rows, spreads the 16-byte reads over the banks
+
+__device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, int kc) {
+#pragma unroll
+    for (int s = 0; s < 4; s++) a4[s] = *reinterpret_cast<const f32x4*>(xrow + kc * FW_KC + s * 8);
+}
+
+// Epilogue shared by the fp32-MFMA kernel and the split-bf16 kernel below (both leave the 32 x 32 tiles in the same C layout).
+// csum: >= 4 * 128 floats of LDS the caller no longer needs (EPI 2).
+template <int EPI, int NT>
+__device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&auxq)[EPI == 2 ? NT : 1][4], int M, int ldy, int bx, int by, int wave,
+                                               int lane, int i, int h, const float* __restrict__ bias, float* __restrict__ Y,
+                                               float* __restrict__ colpart, float* csum) {
+    constexpr int N = 128;
+    // epilogue: C layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+    const int rbase = bx * FW_BM + wave * 32;
+    if constexpr (EPI <= 1) {
+        // The C layout gives a lane ONE column and 4 consecutive rows per register group; a 4 x 4 transpose inside every lane quad (two DPP
+        // exchange stages) turns that into one row and 4 consecutive columns, so that the tile leaves as 16 wide stores of 16 bytes per lane
+        // (8 full 128-byte lines per instruction) instead of 64 dword stores: the store tail of these kernels is issue-bound.
+        const int c4 = lane & 3;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            const float bv = bias[t * 32 + i];
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float v0 = acc[t][4 * g] + bv, v1 = acc[t][4 * g + 1] + bv, v2 = acc[t][4 * g + 2] + bv, v3 = acc[t][4 * g + 3] + bv;
+                if (EPI == 1) { v0 = elu_f(v0); v1 = elu_f(v1); v2 = elu_f(v2); v3 = elu_f(v3); }
+                quad_transpose(v0, v1, v2, v3, c4);
+                const int rr = rbase + 8 * g + 4 * h + c4;
+#ifdef BG_PROBE_NO_STORE  // tools/mlp_nostore_probe.py: how much of the kernel is its store tail?  (never defined in the product build)
+                if (rr < M && v0 == 12345.678f) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
+#else
+                if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
+#endif
+            }
+        }
+    } else {
+        __syncthreads();
+        const int c4 = lane & 3;
+#pragma unroll
+        for (int t = 0; t < NT; t++) {
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // this lane's row contributions to columns t * 32 + (i & ~3) + 0..3
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                float v0 = acc[t][4 * g], v1 = acc[t][4 * g + 1], v2 = acc[t][4 * g + 2], v3 = acc[t][4 * g + 3];
+                quad_transpose(v0, v1, v2, v3, c4);
+                const f32x4 a = auxq[t][g];
+                const int rr = rbase + 8 * g + 4 * h + c4;
+                if (rr < M) {
+                    const f32x4 v = {v0 * (a.x > 0.f ? 1.0f : a.x + 1.0f), v1 * (a.y > 0.f ? 1.0f : a.y + 1.0f),
+                                     v2 * (a.z > 0.f ? 1.0f : a.z + 1.0f), v3 * (a.w > 0.f ? 1.0f : a.w + 1.0f)};
+                    *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = v;
+                    cs += v;
+                }
+            }
+            // rows live in the 4 lanes of a quad and in the two lane halves: add them up, lane (c4 == 0, h == 0) of every quad writes 4 columns
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                float x = cs[k];
+                x += dpp_xor1(x);
+                x += dpp_xor2(x);
+                x += __shfl_xor(x, 32);
+                cs[k] = x;
+            }
+            if (h == 0 && c4 == 0) *reinterpret_cast<f32x4*>(&csum[wave * N + t * 32 + i]) = cs;
+        }
+        __syncthreads();
+        if (threadIdx.x < N)
+            colpart[(size_t)bx * ldy + by * N + threadIdx.x] =
+                csum[threadIdx.x] + csum[N + threadIdx.x] + csum[2 * N + threadIdx.x] + csum[3 * N + threadIdx.x];
+    }
+}
+

@@ -96,6 +96,10 @@ class MLPTrainer:
     # (128x128) against hipBLASLt addmm + elu_.  BG_FUSED_MLP=0 falls back to the library GEMM + elementwise ELU.
     FUSED = __import__("os").environ.get("BG_FUSED_MLP", "1") == "1"
 
+    # Opt-in (BG_GEMM_SPLIT=9 or 6): the same layers on the bf16 matrix pipe, every fp32 operand split exactly into three bf16 numbers and all 9
+    # (or the 6 largest) cross products accumulated in fp32 (bg_mlp_split.hip).  0 = the fp32 MFMA kernels.
+    SPLIT = int(__import__("os").environ.get("BG_GEMM_SPLIT", "0"))
+
     @classmethod
     def _fusable(cls, k_in, n_out):
         return cls.FUSED and k_in in (64, 128, 256) and n_out % 128 == 0
@@ -126,6 +130,8 @@ class MLPTrainer:
         self.dw = [torch.empty(self.wg_slices[i] or self._S, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1], dtype=torch.float32, device=dev)
                    for i, l in enumerate(self.layers)]
         self.wt = [None] * len(self.layers)  # transposed weights for the fused backward kernel
+        self.planes = [None] * len(self.layers)  # SPLIT: bf16 planes of the weights (forward) ...
+        self.planes_t = [None] * len(self.layers)  # ... and of the transposed weights (backward)
         l0 = self.layers[0]
         self.w0pad = torch.zeros(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if k_in != l0.weight.shape[1] else None
         self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
@@ -168,6 +174,15 @@ class MLPTrainer:
                 break
             n_out, k_in = l.weight.shape
             w = l.weight
+            if self.SPLIT and i < last and self._fusable(self._kin if i == 0 else k_in, n_out):
+                kp = self._kin if i == 0 else k_in
+                if self.planes[i] is None:
+                    self.planes[i] = torch.empty(n_out * kp * 3, dtype=torch.int16, device=h.device)
+                _lib.check(lib.bg_mlp_split_weights(n_out, kp, _lib.ptr(l.weight), k_in, n_out, k_in, 0, _lib.ptr(self.planes[i]), stream), "bg_mlp_split_weights")
+                _lib.check(lib.bg_mlp_layer_forward_split(h.shape[0], kp, n_out, _lib.ptr(h), _lib.ptr(self.planes[i]), _lib.ptr(l.bias), _lib.ptr(self.acts[i]),
+                                                          1, self.SPLIT, stream), "bg_mlp_layer_forward_split")
+                h = self.acts[i]
+                continue
             if i == 0 and self.w0pad is not None:
                 self.w0pad[:, :k_in].copy_(l.weight)  # weights change every optimiser step; 16k floats
                 w, k_in = self.w0pad, self._kin
@@ -266,7 +281,15 @@ class MLPTrainer:
                 self._weight_grad(i, g)
             if i > 0:
                 below = self.layers[i - 1]
-                if self.FUSED and C_out in (128, 256) and C_in % 128 == 0:
+                if self.SPLIT and self.FUSED and C_out in (128, 256) and C_in % 128 == 0:
+                    if self.planes_t[i] is None:
+                        self.planes_t[i] = torch.empty(C_in * C_out * 3, dtype=torch.int16, device=g.device)
+                    _lib.check(lib.bg_mlp_split_weights(C_in, C_out, _lib.ptr(l.weight), C_in, C_out, C_in, 1, _lib.ptr(self.planes_t[i]), stream),
+                               "bg_mlp_split_weights")
+                    _lib.check(lib.bg_mlp_layer_backward_split(B, C_out, C_in, _lib.ptr(g), _lib.ptr(self.planes_t[i]), _lib.ptr(a_in), _lib.ptr(self.gin[i]),
+                                                               _lib.ptr(below.bias.grad), _lib.ptr(self.cs[i - 1]), self.SPLIT, stream),
+                               "bg_mlp_layer_backward_split")
+                elif self.FUSED and C_out in (128, 256) and C_in % 128 == 0:
                     if self.wt[i] is None:
                         self.wt[i] = torch.empty(C_in, C_out, dtype=torch.float32, device=g.device)
                     self.wt[i].copy_(l.weight.t())

@@ -274,6 +274,20 @@ int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const 
 int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const float* G, const float* Wt, const float* act_below, float* Gout,
                           float* bias_grad_below, float* scratch, void* stream);
 
+/* Split form of the two layer kernels above (opt-in; same inputs, outputs and epilogues): the fp32 x fp32 products run on the bf16 matrix
+ * pipe.  Every fp32 operand is EXACTLY the sum of three bf16 numbers (hi / mid / lo: 8 + 8 + 8 significant bits) and a bf16 x bf16 product
+ * is exact in the fp32 accumulator, so terms = 9 (all cross terms) accumulates the exact products x * w in fp32 -- no precision is given up
+ * against the fp32 MFMA form; terms = 6 drops mid*lo, lo*mid, lo*lo (<= 2^-23 of each product).  The weights come pre-split:
+ * bg_mlp_split_weights writes planes[n_out][k_out / 32][3][32] bf16 from W [src_rows][ldw] (transpose != 0: element (n, k) = W[k][n]);
+ * elements outside the source are zero (the zero-padded first layers), k_out a multiple of 32, 6 bytes per element.
+ * Same shape limits and error codes as bg_mlp_layer_forward / _backward. */
+int bg_mlp_split_weights(int32_t n_out, int32_t k_out, const float* W, int32_t ldw, int32_t src_rows, int32_t src_cols, int32_t transpose,
+                         uint16_t* planes, void* stream);
+int bg_mlp_layer_forward_split(int32_t M, int32_t K, int32_t N, const float* X, const uint16_t* planes, const float* bias, float* Y, int32_t elu,
+                               int32_t terms, void* stream);
+int bg_mlp_layer_backward_split(int32_t M, int32_t K, int32_t N, const float* G, const uint16_t* planes_t, const float* act_below, float* Gout,
+                                float* bias_grad_below, float* scratch, int32_t terms, void* stream);
+
 /* Weight gradient of one Linear layer over the batch (the dW part of `loss.backward()`, utils/runner.py:163, for model.py:9-26's layers):
  * dW [C_out][C_in_real] = G [M][C_out]^T . A [M][C_in][:, :C_in_real], fp32 MFMA, the sum over the M rows split over `slices` x 4 waves
  * inside the launch and finished in a fixed order (deterministic, no atomics).  G = dL/dz of the layer, A = its input activations with

@@ -1,0 +1,29 @@
+#!/bin/bash
+# SQ / LDS / memory-path counters of the split-bf16 layer kernel against the fp32-MFMA kernel (256 x 256 forward, alone on the GPU).
+set -e
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/prof_split_pmc
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+i=0
+for set in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE" \
+           "SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_VMEM SQ_WAIT_INST_LDS SQ_ACTIVE_INST_LDS SQ_INST_CYCLES_VMEM" \
+           "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_LDS_ADDR_CONFLICT SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_INSTS_SALU" \
+           "TA_BUSY_avr TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TA_DATA_STALL_CYCLES_sum"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/p$i -- python3 $R/tools/mlp_split_pmc_run.py > $OUT.p$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - <<'PY'
+import collections, csv, glob, json, os
+R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
+acc = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(f"{R}/gpurun_out/prof_split_pmc/*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        n = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        if "mlp_fwd" in n or "mlp_split" in n:
+            acc[n][r["Counter_Name"]].append(float(r["Counter_Value"]))
+out = {k: {c: sum(v) / len(v) for c, v in cs.items()} for k, cs in acc.items()}
+json.dump(out, open(f"{R}/gpurun_out/split_pmc.json", "w"), indent=1)
+for k, cs in sorted(out.items()):
+    print(k, {c: round(v) for c, v in cs.items()})
+PY
