@@ -349,6 +349,35 @@ def main():
             out["roofline_top_by_time"] = top_by_time
         if world == 1 and not args.no_extra:
             try:
+                # Opt-in form of the layer kernels, measured beside the headline and NOT part of `value`: BG_GEMM_SPLIT (bg_mlp_split.hip) runs the
+                # fp32 x fp32 products of the hidden-layer forward / backward GEMMs on the bf16 matrix pipe, every fp32 operand split EXACTLY into
+                # three bf16 numbers (all 9 cross products: no rounding of the products, fp32 accumulation; 6: the three smallest dropped).
+                # The weight-gradient launch stays on the fp32 MFMA kernel in both.  Same loop, same workload, same timing as `value`.
+                from booster_gym_amd.utils.model import MLPTrainer
+
+                runner.rollout, runner.update, runner.env.step_to = orig_rollout, orig_update, orig_step_to
+                runner._critic_tr.timed_layer, runner._wgrad_group.timed_events = None, None
+                split, it0 = {}, args.warmup + args.steps
+                for terms in (9, 6):
+                    MLPTrainer.SPLIT = terms
+                    for _ in range(2):
+                        runner.train_iteration(it0); it0 += 1
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for _ in range(args.steps):
+                        runner.train_iteration(it0); it0 += 1
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - ts
+                    split[f"products_{terms}"] = {"value": N * T * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3}
+                MLPTrainer.SPLIT = 0
+                runner._flush_log()
+                split["note"] = ("opt-in (BG_GEMM_SPLIT=9|6), not the headline: hidden-layer forward / backward GEMMs as exact hi/mid/lo bf16 splits of the "
+                                 "fp32 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate; tests/test_gpu_mlp_split.py holds the error against float64 "
+                                 "beside the fp32-MFMA kernel's")
+                out["opt_in_split_bf16_layers"] = split
+            except Exception as ex:
+                out["opt_in_split_bf16_layers"] = {"error": repr(ex)}
+            try:
                 del runner.env
                 out["roofline_aba"] = aba_roofline()
             except Exception as ex:
