@@ -2,8 +2,10 @@
 // Own translation unit: built with the default machine scheduler (Makefile) -- under -amdgpu-sched-strategy=max-ilp, which the lane-per-env
 // simulator kernels need, the 256-accumulator MFMA loop below was spilled to scratch.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 
 #include "../../include/booster_gym_amd.h"
+#include "bg_wgrad.h"
 
 extern int bg_set_error(int code, const char* msg);
 #define HIP_OK(expr)                                                                        \
@@ -141,13 +143,6 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_kernel(int M, int Cout, int 
 // chains, with every workgroup given the same amount of MFMA work -- the caller sizes each layer's slice count in proportion to its cost
 // (rows x tile width), so that one launch of ~256 workgroups keeps every CU busy for the same time instead of six launches with six
 // prologue / reduction / finish tails.  Up to WG_MAX_PROBLEMS layers; descriptors travel as a kernel argument.
-constexpr int WG_MAX_PROBLEMS = 8;
-struct WgradProblem {
-    const float* G; const float* A; float* P; float* dW;
-    int M, Cout, Cin, Cin_real, tci, ntile_ci, ntiles, tw, slices, wg_begin, fin_begin, n4;
-};
-struct WgradGroup { int np; WgradProblem p[WG_MAX_PROBLEMS]; };
-
 __global__ __launch_bounds__(256, 1) void mlp_wgrad_group_kernel(WgradGroup grp) {
     __shared__ __attribute__((aligned(16))) float red[WG_RED_FLOATS];
     const int b = blockIdx.x;
@@ -236,21 +231,23 @@ __global__ __launch_bounds__(256) void mlp_wgrad_group_finish_kernel(WgradGroup 
     }
 }
 
-extern "C" int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream) {
-    if (!problems || count <= 0 || count > WG_MAX_PROBLEMS) return bg_set_error(-1, "bg_mlp_weight_grad_group: 1 to 8 problems");
-    WgradGroup grp;
+// validation + descriptor build shared with bg_wgrad_split.hip; `who` prefixes the error messages
+int bg_wgrad_group_fill(const bg_wgrad_problem* problems, int32_t count, WgradGroup& grp, int& wg, int& fin, const char* who) {
+    static thread_local char msg[160];
+    auto fail = [&](int code, const char* what) { snprintf(msg, sizeof msg, "%s: %s", who, what); return bg_set_error(code, msg); };
+    if (!problems || count <= 0 || count > WG_MAX_PROBLEMS) return fail(-1, "1 to 8 problems");
     grp.np = count;
-    int wg = 0, fin = 0;
+    wg = 0; fin = 0;
     for (int k = 0; k < count; k++) {
         const bg_wgrad_problem& q = problems[k];
-        if (q.M <= 0 || !q.G || !q.A || !q.dW || !q.scratch) return bg_set_error(-1, "bg_mlp_weight_grad_group: bad argument");
-        if ((((uintptr_t)q.G | (uintptr_t)q.A | (uintptr_t)q.scratch) & 15) != 0) return bg_set_error(-1, "bg_mlp_weight_grad_group: G, A, scratch must be 16-byte aligned");
-        if (q.C_in_real == q.C_in && (((uintptr_t)q.dW) & 15) != 0) return bg_set_error(-1, "bg_mlp_weight_grad_group: dW must be 16-byte aligned");
-        if (q.C_out % 128 != 0 || q.C_out > 1024) return bg_set_error(-4, "bg_mlp_weight_grad_group: unsupported C_out (multiples of 128 up to 1024)");
-        if (q.C_in != 64 && (q.C_in % 128 != 0 || q.C_in > 1024)) return bg_set_error(-4, "bg_mlp_weight_grad_group: unsupported C_in (64, or multiples of 128 up to 1024)");
-        if (q.C_in_real <= 0 || q.C_in_real > q.C_in) return bg_set_error(-1, "bg_mlp_weight_grad_group: C_in_real must be in [1, C_in]");
-        if (q.M % 2 != 0) return bg_set_error(-4, "bg_mlp_weight_grad_group: M must be even (rows are consumed in pairs)");
-        if (q.slices <= 0 || (long)q.slices * 8 > q.M) return bg_set_error(-4, "bg_mlp_weight_grad_group: slices must be in [1, M / 8]");
+        if (q.M <= 0 || !q.G || !q.A || !q.dW || !q.scratch) return fail(-1, "bad argument");
+        if ((((uintptr_t)q.G | (uintptr_t)q.A | (uintptr_t)q.scratch) & 15) != 0) return fail(-1, "G, A, scratch must be 16-byte aligned");
+        if (q.C_in_real == q.C_in && (((uintptr_t)q.dW) & 15) != 0) return fail(-1, "dW must be 16-byte aligned");
+        if (q.C_out % 128 != 0 || q.C_out > 1024) return fail(-4, "unsupported C_out (multiples of 128 up to 1024)");
+        if (q.C_in != 64 && (q.C_in % 128 != 0 || q.C_in > 1024)) return fail(-4, "unsupported C_in (64, or multiples of 128 up to 1024)");
+        if (q.C_in_real <= 0 || q.C_in_real > q.C_in) return fail(-1, "C_in_real must be in [1, C_in]");
+        if (q.M % 2 != 0) return fail(-4, "M must be even (rows are consumed in pairs)");
+        if (q.slices <= 0 || (long)q.slices * 8 > q.M) return fail(-4, "slices must be in [1, M / 8]");
         WgradProblem& p = grp.p[k];
         p.G = q.G; p.A = q.A; p.P = q.scratch; p.dW = q.dW;
         p.M = q.M; p.Cout = q.C_out; p.Cin = q.C_in; p.Cin_real = q.C_in_real; p.tci = q.C_in == 64 ? 2 : 4;
@@ -258,13 +255,25 @@ extern "C" int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_
         p.ntiles = (q.C_out / 128) * p.ntile_ci;
         p.tw = q.tiles_per_workgroup <= 0 ? 1 : q.tiles_per_workgroup;
         if ((p.tw != 1 && p.tw != 2 && p.tw != 4) || p.ntiles % p.tw != 0)
-            return bg_set_error(-4, "bg_mlp_weight_grad_group: tiles_per_workgroup must be 1, 2 or 4 and divide the layer's tile count");
-        if ((long)q.slices * (4 / p.tw) * 2 > q.M) return bg_set_error(-4, "bg_mlp_weight_grad_group: too many slices for M");
+            return fail(-4, "tiles_per_workgroup must be 1, 2 or 4 and divide the layer's tile count");
+        if ((long)q.slices * (4 / p.tw) * 2 > q.M) return fail(-4, "too many slices for M");
         p.slices = q.slices;
         p.wg_begin = wg; wg += (p.ntiles / p.tw) * p.slices;
         p.n4 = q.C_out * q.C_in / 4;
         p.fin_begin = fin; fin += (p.n4 + 15) / 16;
     }
+    return 0;
+}
+int bg_wgrad_group_finish_launch(const WgradGroup& grp, int fin, hipStream_t st) {
+    hipLaunchKernelGGL(mlp_wgrad_group_finish_kernel, dim3(fin), dim3(256), 0, st, grp);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+extern "C" int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream) {
+    WgradGroup grp;
+    int wg = 0, fin = 0;
+    const int rc = bg_wgrad_group_fill(problems, count, grp, wg, fin, "bg_mlp_weight_grad_group");
+    if (rc) return rc;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(mlp_wgrad_group_kernel, dim3(wg), dim3(256), 0, st, grp);
     hipLaunchKernelGGL(mlp_wgrad_group_finish_kernel, dim3(fin), dim3(256), 0, st, grp);

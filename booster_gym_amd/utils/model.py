@@ -61,10 +61,12 @@ class GroupedWeightGrad:
         probs = [p for tr in trainers for p in tr.pending_wgrad_problems()]
         if not probs:
             return
-        key = tuple((g.data_ptr(), a.data_ptr(), dw.data_ptr(), g.shape[0], co, ci, cr) for g, a, dw, co, ci, cr in probs)
+        key = (MLPTrainer.SPLIT,) + tuple((g.data_ptr(), a.data_ptr(), dw.data_ptr(), g.shape[0], co, ci, cr) for g, a, dw, co, ci, cr in probs)
         if key != self._key:  # buffers are static: built once
             rows = probs[0][0].shape[0]
-            slices, tw = plan_wgrad_slices([(co, ci) for _, _, _, co, ci, _ in probs], rows, self.workgroups, share_rows=self.share_rows)
+            # split mode (bg_mlp_weight_grad_group_split): the waves of a workgroup share their rows through LDS, all tiles of a layer in one workgroup
+            self.split = MLPTrainer.SPLIT if rows % 32 == 0 and all((co, ci) in ((256, 256), (128, 256), (128, 128), (256, 64)) for _, _, _, co, ci, _ in probs) else 0
+            slices, tw = plan_wgrad_slices([(co, ci) for _, _, _, co, ci, _ in probs], rows, self.workgroups, share_rows=self.share_rows or bool(self.split))
             self._scratch = [torch.empty(sl * co * ci, dtype=torch.float32, device=probs[0][0].device) for sl, (_, _, _, co, ci, _) in zip(slices, probs)]
             arr = (_lib.WgradProblem * len(probs))()
             for k, ((g, a, dw, co, ci, cr), sl) in enumerate(zip(probs, slices)):
@@ -75,7 +77,10 @@ class GroupedWeightGrad:
         if ev is not None:  # bench.py: HIP events on the launch stream around the launch pair
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        _lib.check(_lib.load().bg_mlp_weight_grad_group(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
+        if self.split:
+            _lib.check(_lib.load().bg_mlp_weight_grad_group_split(self._arr, len(probs), self.split, _lib.current_stream_ptr()), "bg_mlp_weight_grad_group_split")
+        else:
+            _lib.check(_lib.load().bg_mlp_weight_grad_group(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
         if ev is not None:
             e1.record()
             ev.append((e0, e1, sum(2.0 * g.shape[0] * co * ci for g, _, _, co, ci, _ in probs), [(g.shape[0], co, ci) for g, _, _, co, ci, _ in probs]))

@@ -312,6 +312,11 @@ typedef struct {
                                   * this many tiles x 4 / this many sub-ranges of the slice's rows; waves on the same rows share the fetched rows */
 } bg_wgrad_problem;
 int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream);
+/* Split form of the grouped launch (opt-in, see bg_mlp_layer_forward_split): the same sums with every fp32 operand split exactly into three bf16
+ * numbers on the bf16 matrix pipe, terms = 9 or 6.  The waves of a workgroup that work on the same rows share them through LDS, so here
+ * tiles_per_workgroup must equal the layer's tile count (1, 2 or 4).  Shapes: 256 x 256, 128 x 256, 128 x 128, 256 x 64 (C_out x C_in padded), M a
+ * multiple of 32; anything else returns -4 and the caller uses bg_mlp_weight_grad_group.  Same scratch layout and fixed-order finish. */
+int bg_mlp_weight_grad_group_split(const bg_wgrad_problem* problems, int32_t count, int32_t terms, void* stream);
 
 /* ---- output ("head") layers fused with the loss: the 128 -> 12 / 128 -> 1 Linear layers of utils/model.py:13,21 together with
  * runner.py:145-174.  h [rows][128] = activations of the last hidden (ELU) layer, 16-byte aligned.  One launch reads h once instead of

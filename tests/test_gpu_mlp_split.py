@@ -143,3 +143,47 @@ def test_full_update_in_split_mode_matches_reference_loop(terms):
         assert abs(summ["lr"] - lr_ref) < 1e-9
     finally:
         MLPTrainer.SPLIT = old
+
+
+@pytest.mark.parametrize("terms", [9, 6])
+@pytest.mark.parametrize("M", [98304, 4096 + 32 * 7])
+def test_split_weight_grad_group_matches_float64_as_well_as_the_fp32_kernel(M, terms):
+    """bg_mlp_weight_grad_group_split: the six hidden-layer weight gradients in one launch pair, rows shared through LDS (tiles_per_workgroup = the
+    layer's tile count), against torch float64 and beside the fp32-MFMA launch on the same inputs; deterministic; refusals."""
+    from booster_gym_amd import _lib
+    from booster_gym_amd.utils.model import plan_wgrad_slices
+
+    lib, st = _lib.load(), _lib.current_stream_ptr()
+    shapes = [(256, 64, 61), (256, 256, 256), (128, 256, 256), (256, 64, 47), (128, 256, 256), (128, 128, 128)]
+    slices, tw = plan_wgrad_slices([(co, ci) for co, ci, _ in shapes], M, 256, share_rows=True)
+    torch.manual_seed(5)
+    arr = (_lib.WgradProblem * len(shapes))()
+    keep = []
+    for k, ((co, ci, cr), sl) in enumerate(zip(shapes, slices)):
+        G = torch.randn(M, co, device=DEV); A = torch.randn(M, ci, device=DEV); A[:, cr:] = 0.0
+        G[:, 3] *= 3.0; A[:, 1] += 0.5; G[0, co - 1] = 40.0; A[0, cr - 1] = -25.0; G[M - 1, 0] = 17.0; A[M - 1, 0] = 2.0
+        dW = torch.full((co, cr), float("nan"), device=DEV); sc = torch.empty(sl * co * ci, device=DEV)
+        keep.append((G, A, dW, sc))
+        arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = G.data_ptr(), A.data_ptr(), dW.data_ptr(), sc.data_ptr()
+        arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices, arr[k].tiles_per_workgroup = M, co, ci, cr, sl, tw[k]
+    _lib.check(lib.bg_mlp_weight_grad_group(arr, len(shapes), st), "bg_mlp_weight_grad_group")
+    fp32 = [dW.clone() for _, _, dW, _ in keep]
+    for _, _, dW, _ in keep:
+        dW.fill_(float("nan"))
+    _lib.check(lib.bg_mlp_weight_grad_group_split(arr, len(shapes), terms, st), "bg_mlp_weight_grad_group_split")
+    for (co, ci, cr), (G, A, dW, sc), d32 in zip(shapes, keep, fp32):
+        ref64 = G.double().t() @ A.double()[:, :cr]
+        rms, rms32 = (dW.double() - ref64).pow(2).mean().sqrt().item(), (d32.double() - ref64).pow(2).mean().sqrt().item()
+        err, err32 = (dW.double() - ref64).abs().max().item(), (d32.double() - ref64).abs().max().item()
+        # sums over 98,304 rows: the rounding of the ACCUMULATOR dominates here (9 or 6 accumulator updates per 16 rows against the fp32 kernel's 8),
+        # not the products: the bound is a band around the fp32 kernel's error, not "at least as good"
+        slack = 1.5 if terms == 9 else 2.5
+        assert torch.isfinite(dW).all() and rms <= slack * rms32 + 1e-7 and err <= 2.5 * err32 + 1e-6, (co, ci, rms, rms32, err, err32)
+    first = [dW.clone() for _, _, dW, _ in keep]
+    _lib.check(lib.bg_mlp_weight_grad_group_split(arr, len(shapes), terms, st), "bg_mlp_weight_grad_group_split")
+    assert all(torch.equal(a, dW) for a, (_, _, dW, _) in zip(first, keep))  # deterministic
+    assert lib.bg_mlp_weight_grad_group_split(arr, len(shapes), 4, st) == -4
+    arr[1].tiles_per_workgroup = 1  # the 256 x 256 layer's four tiles must share a workgroup here
+    assert lib.bg_mlp_weight_grad_group_split(arr, len(shapes), terms, st) == -4 and b"tiles_per_workgroup" in lib.bg_last_error()
+    arr[1].tiles_per_workgroup, arr[1].M = 4, M + 16
+    assert lib.bg_mlp_weight_grad_group_split(arr, len(shapes), terms, st) == -4 and b"multiple of 32" in lib.bg_last_error()
