@@ -182,6 +182,8 @@ def main():
 
     from booster_gym_amd.utils.recorder import Recorder
 
+    from booster_gym_amd.utils.model import MLPTrainer as _MT
+    split_mode = _MT.SPLIT  # 0 unless the caller exported BG_GEMM_SPLIT: then the headline loop itself runs in split mode, and the line says so
     cfg["runner"]["save_interval"] = 10 ** 9  # no checkpoint inside the timed region (the reference saves every 100 iterations)
     runner.begin_training(Recorder(cfg, root=tempfile.mkdtemp(prefix="bench_logs_"), rank=rank))
 
@@ -331,7 +333,9 @@ def main():
             "ms_per_step": wall / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic (random-init policy, seeded domain randomisation)",
             "config": {"workload": f"T1 {args.terrain} terrain, {N} envs/GPU, horizon {T}, {E} mini-epochs, full batch (BASELINE.json configs[1])",
-                       "envs_per_gpu": N, "parallelism": f"dp{world}"},
+                       "envs_per_gpu": N, "parallelism": f"dp{world}",
+                       "gemm_arithmetic": {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 9: "fp32 operands as exact 3-way bf16 splits, 9 products, fp32 accumulate (BG_GEMM_SPLIT=9)",
+                                           6: "fp32 operands as exact 3-way bf16 splits, 6 largest products, fp32 accumulate (BG_GEMM_SPLIT=6)"}[split_mode]},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms, "all_reduce_ms": ar_ms},
             "roofline": headline,
@@ -351,8 +355,8 @@ def main():
             try:
                 # Opt-in form of the layer kernels, measured beside the headline and NOT part of `value`: BG_GEMM_SPLIT (bg_mlp_split.hip) runs the
                 # fp32 x fp32 products of the hidden-layer forward / backward GEMMs on the bf16 matrix pipe, every fp32 operand split EXACTLY into
-                # three bf16 numbers (all 9 cross products: no rounding of the products, fp32 accumulation; 6: the three smallest dropped).
-                # The weight-gradient launch stays on the fp32 MFMA kernel in both.  Same loop, same workload, same timing as `value`.
+                # three bf16 numbers (all 9 cross products: no rounding of the products, fp32 accumulation; 6: the three smallest dropped);
+                # so does the grouped weight-gradient launch (bg_wgrad_split.hip).  Same loop, same workload, same timing as `value`.
                 from booster_gym_amd.utils.model import MLPTrainer
 
                 runner.rollout, runner.update, runner.env.step_to = orig_rollout, orig_update, orig_step_to
@@ -369,11 +373,11 @@ def main():
                     torch.cuda.synchronize()
                     dt = time.perf_counter() - ts
                     split[f"products_{terms}"] = {"value": N * T * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3}
-                MLPTrainer.SPLIT = 0
+                MLPTrainer.SPLIT = split_mode
                 runner._flush_log()
-                split["note"] = ("opt-in (BG_GEMM_SPLIT=9|6), not the headline: hidden-layer forward / backward GEMMs as exact hi/mid/lo bf16 splits of the "
-                                 "fp32 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate; tests/test_gpu_mlp_split.py holds the error against float64 "
-                                 "beside the fp32-MFMA kernel's")
+                split["note"] = ("opt-in (BG_GEMM_SPLIT=9|6), not the headline: hidden-layer forward / backward / weight-gradient GEMMs as exact hi/mid/lo "
+                                 "bf16 splits of the fp32 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate; tests/test_gpu_mlp_split.py holds the error "
+                                 "against float64 beside the fp32-MFMA kernels'")
                 out["opt_in_split_bf16_layers"] = split
             except Exception as ex:
                 out["opt_in_split_bf16_layers"] = {"error": repr(ex)}
