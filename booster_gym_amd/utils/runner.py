@@ -187,6 +187,11 @@ class Runner:
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
         self._logstd_off = (self._logstd_grad_view.data_ptr() - self.optimizer.grad.data_ptr()) // 4  # position of logstd in the flat buffers
         self._actor_tr, self._critic_tr = MLPTrainer(self.model.actor), MLPTrainer(self.model.critic)
+        gs = (self.cfg.get("parallel", {}) or {}).get("gemm_split", 0)
+        if gs:  # yaml switch for the split-bf16 GEMMs (process-wide, like the environment variable)
+            if int(gs) not in (6, 9):
+                raise ValueError(f"parallel.gemm_split must be 0, 6 or 9, got {gs!r}")
+            MLPTrainer.SPLIT = int(gs)
         self._wgrad_group = GroupedWeightGrad()
         # the critic's stream goes ahead of the actor's in workgroup dispatch: its chain is the longer one and the actor's loss waits for its GAE
         # (update 23.17 -> 23.06 ms, tools/ab_prio.sh; BG_SIDE_PRIORITY=0: equal priorities)

@@ -187,3 +187,19 @@ def test_split_weight_grad_group_matches_float64_as_well_as_the_fp32_kernel(M, t
     assert lib.bg_mlp_weight_grad_group_split(arr, len(shapes), terms, st) == -4 and b"tiles_per_workgroup" in lib.bg_last_error()
     arr[1].tiles_per_workgroup, arr[1].M = 4, M + 16
     assert lib.bg_mlp_weight_grad_group_split(arr, len(shapes), terms, st) == -4 and b"multiple of 32" in lib.bg_last_error()
+
+
+def test_yaml_switch_selects_split_mode():
+    """parallel.gemm_split: 9 / 6 turn the split GEMMs on for the process (like BG_GEMM_SPLIT), anything else but 0 is refused."""
+    from booster_gym_amd.utils.config import load_cfg
+    from booster_gym_amd.utils.model import MLPTrainer
+    from booster_gym_amd.utils.runner import Runner
+
+    old = MLPTrainer.SPLIT
+    try:
+        Runner(cfg=load_cfg("T1", {"env.num_envs": 64, "terrain.type": "plane", "parallel.gemm_split": 6}))
+        assert MLPTrainer.SPLIT == 6
+        with pytest.raises(ValueError, match="gemm_split"):
+            Runner(cfg=load_cfg("T1", {"env.num_envs": 64, "terrain.type": "plane", "parallel.gemm_split": 3}))
+    finally:
+        MLPTrainer.SPLIT = old
