@@ -14,6 +14,13 @@ extern int bg_set_error(int code, const char* msg);
         if (_e != hipSuccess) return bg_set_error(-2, hipGetErrorString(_e));               \
     } while (0)
 
+#ifdef BG_PROBE_TIMELINE  // tools/wgrad_timeline_probe.py: shader-clock stamps of every wave at the phase boundaries (never defined in the product build)
+__device__ long long bg_wg_timeline[1024 * 4 * 8];
+#define BG_STAMP(SLOT) do { if ((threadIdx.x & 63) == 0) bg_wg_timeline[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (SLOT)] = clock64(); } while (0)
+extern "C" int bg_probe_read_wgrad_timeline(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bg_wg_timeline), bytes); }
+#else
+#define BG_STAMP(SLOT) do { } while (0)
+#endif
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stays in registers (HIP's float4 struct blocked SROA here)
 
@@ -44,8 +51,11 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     const int ks = 4 / tw, tl = wave % tw, ksub = wave / tw, tile = tile0 + tl;
     const int tco = tile / ntile_ci, tci = tile % ntile_ci;
-    const long KP = M >> 1, W = (long)slices * ks, widx = (long)slice * ks + ksub;
-    const int kp0 = (int)(KP * widx / W), kp1 = (int)(KP * (widx + 1) / W);
+    // runs are cut at multiples of 2 * D row pairs (one double set of the steady-state loop), the last one takes what is left: only that run has a
+    // tail.  (Cut at arbitrary row pairs every wave ran the guarded tail -- two sets of mostly zero rows behind loads that are waited for one by
+    // one: 22.8 k of a wave's 637 k cycles, tools/wgrad_timeline_probe.py.)
+    const long KP = M >> 1, W = (long)slices * ks, widx = (long)slice * ks + ksub, KG = KP / 16;
+    const int kp0 = 16 * (int)(KG * widx / W), kp1 = widx == W - 1 ? (int)KP : 16 * (int)(KG * (widx + 1) / W);
     const unsigned gofb = 4u * (h * Cout + tco * 128 + 4 * i), aofb = 4u * (h * Cin + tci * (32 * TCI) + TCI * i);  // byte offsets of this lane
     const char* Gb = reinterpret_cast<const char*>(G);
     const char* Ab = reinterpret_cast<const char*>(A);
@@ -83,6 +93,7 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
     // scheduler sinks every load to just before its first use and the HBM latency is exposed in front of each MFMA group.
     const int nfull = (kp1 - kp0) / (2 * D);
     int kp = kp0;
+    BG_STAMP(0);
     load(g0, a0, kp, false);
     for (int it = 0; it < nfull; it++, kp += 2 * D) {
         __builtin_amdgcn_sched_barrier(0);
@@ -94,6 +105,7 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
         __builtin_amdgcn_sched_barrier(0);
         fma_set(g1, a1);
     }
+    BG_STAMP(1);
     if (kp < kp1) {  // tail of fewer than 2 * D row pairs (batch sizes that do not divide evenly)
         load(g0, a0, kp, true);
         load(g1, a1, kp + D, true);
@@ -107,6 +119,7 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
     // Tile (t, u) of a wave holds output rows co = 4 * row + t and columns ci = TCI * col + u: a lane stores TCI consecutive columns.
     float* pt = P + (size_t)slice * Cout * Cin + (size_t)(tco * 128) * Cin + tci * (32 * TCI) + TCI * i;
     const int ipw = 32 / ks;  // register groups per wave and round
+    BG_STAMP(2);
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         if (half) __syncthreads();
@@ -128,6 +141,7 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
             *reinterpret_cast<avec*>(pt + (size_t)(4 * row + t) * Cin) = v;
         }
     }
+    BG_STAMP(3);
 }
 
 // one layer per launch: workgroups that read the same rows (the tiles of one slice) get block ids 8 apart, i.e. the same XCD and L2 (speed only)
