@@ -16,6 +16,14 @@ extern int bg_set_error(int code, const char* msg);
         if (_e != hipSuccess) return bg_set_error(-2, hipGetErrorString(_e));               \
     } while (0)
 
+#ifdef BG_PROBE_TIMELINE  // tools/mlp_timeline_probe.py: shader-clock stamps of every wave at the phase boundaries (never defined in the product build)
+__device__ long long bg_timeline_buf[2048 * 4 * 16];
+#define BG_STAMP(SLOT) do { if ((threadIdx.x & 63) == 0) bg_timeline_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (SLOT)] = clock64(); } while (0)
+#define BG_EPI_STAMP(SLOT) BG_STAMP(SLOT)
+extern "C" int bg_probe_read_timeline(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bg_timeline_buf), bytes); }
+#else
+#define BG_STAMP(SLOT) do { } while (0)
+#endif
 #include "bg_mlp_tile.h"
 
 // one k-chunk (32 k-values) of MFMAs for this wave: 4 sub-steps x NT column tiles x 4 MFMAs
@@ -86,10 +94,19 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
         for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
     f32x4 wA[LD4], wB[LD4], aA[4], aB[4];
     f32x4 auxq[EPI == 2 ? NT : 1][4];  // elu' operand of the backward epilogue in the TRANSPOSED (row, 4 columns) layout of the stores
+    BG_STAMP(0);
+#ifdef BG_PROBE_TIMELINE  // slot 15: where the wave runs (HW_ID: cu [11:8], sh [12], se [15:13]; XCC_ID [3:0]), slot 11: launch-wide realtime clock
+    if ((threadIdx.x & 63) == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4), xcc = __builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20);
+        bg_timeline_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 15] = (long long)hw | ((long long)xcc << 32);
+        bg_timeline_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 11] = wall_clock64();
+    }
+#endif
     load_w_chunk<K, LD4>(wA, W, 0);
     load_a_chunk(aA, xrow, 0);
     store_w_chunk<LD4>(wA, sW[0]);
     __syncthreads();
+    BG_STAMP(1);
     const float* sw0 = &sW[0][i * FW_LDW + 4 * h];
     const float* sw1 = &sW[1][i * FW_LDW + 4 * h];
     for (int kc = 0; kc < CH; kc += 2) {
@@ -117,9 +134,12 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
         }
         mfma_chunk<NT>(acc, aB, sw1);
         if (kc + 2 < CH) store_w_chunk<LD4>(wA, sW[0]);
+        BG_STAMP(2 + kc / 2);  // own work on a pair of chunks, before the barrier
         __syncthreads();
     }
+    BG_STAMP(2 + CH / 2);
     layer_epilogue<EPI, NT>(acc, auxq, M, ldy, bx, by, wave, lane, i, h, bias, Y, colpart, &sW[0][0]);  // csum reuses the weight staging buffer
+    BG_STAMP(3 + CH / 2);
 }
 
 __global__ __launch_bounds__(256) void mlp_colsum_finish_kernel(int nb, int C, const float* __restrict__ partial, float* __restrict__ out) {

@@ -31,6 +31,9 @@ __device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, 
     for (int s = 0; s < 4; s++) a4[s] = *reinterpret_cast<const f32x4*>(xrow + kc * FW_KC + s * 8);
 }
 
+#ifndef BG_EPI_STAMP  // timeline probe builds define it
+#define BG_EPI_STAMP(SLOT) do { } while (0)
+#endif
 // Epilogue shared by the fp32-MFMA kernel and the split-bf16 kernel below (both leave the 32 x 32 tiles in the same C layout).
 // csum: >= 4 * 128 floats of LDS the caller no longer needs (EPI 2).
 template <int EPI, int NT>
@@ -60,6 +63,7 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&
                 if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
 #endif
             }
+            if (t < 3) BG_EPI_STAMP(12 + t);
         }
     } else {
         __syncthreads();
