@@ -35,7 +35,7 @@ __device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, 
 #define BG_EPI_STAMP(SLOT) do { } while (0)
 #endif
 // Epilogue shared by the fp32-MFMA kernel and the split-bf16 kernel below (both leave the 32 x 32 tiles in the same C layout).
-// csum: >= 4 * 128 floats of LDS the caller no longer needs (EPI 2).
+// csum: LDS the caller no longer needs: 4 x 32 x 36 floats (18 KB) for the forward epilogues' transposition, 4 x 128 floats for EPI 2.
 template <int EPI, int NT>
 __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&auxq)[EPI == 2 ? NT : 1][4], int M, int ldy, int bx, int by, int wave,
                                                int lane, int i, int h, const float* __restrict__ bias, float* __restrict__ Y,
@@ -44,23 +44,33 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&
     // epilogue: C layout of the 32x32 tile: col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
     const int rbase = bx * FW_BM + wave * 32;
     if constexpr (EPI <= 1) {
-        // The C layout gives a lane ONE column and 4 consecutive rows per register group; a 4 x 4 transpose inside every lane quad (two DPP
-        // exchange stages) turns that into one row and 4 consecutive columns, so that the tile leaves as 16 wide stores of 16 bytes per lane
-        // (8 full 128-byte lines per instruction) instead of 64 dword stores: the store tail of these kernels is issue-bound.
-        const int c4 = lane & 3;
+        // The C layout gives a lane ONE column and 4 consecutive rows per register group; the stores want one row and 4 consecutive columns per lane
+        // (16 bytes per lane, 8 full 128-byte lines per instruction: with 64 dword stores per lane the store tail was issue-bound).  The tile goes
+        // through a wave-private 32 x 32 block of LDS (the weight staging buffer, free after the loop's last barrier): 16 ds_write_b32 in the C
+        // layout, 4 ds_read_b128 by rows -- 20 LDS instructions where the 4 x 4 quad transposes (DPP) of the first version cost 64 VALU per tile in
+        // an epilogue that is VALU-issue bound (tools/mlp_timeline_probe.py).  Row stride 36 floats: 16-byte aligned, spreads both access patterns.
+        constexpr int LS = 36;
+        float* wl = csum + wave * (32 * LS);
+        const int r8 = lane >> 3, c8 = (lane & 7) * 4;  // read side: row r8 + 8 k of the block, columns c8 .. c8 + 3
+        // all bias values first, complete before the first store (loads and stores share vmcnt and return out of order against each other: a load
+        // issued behind stores is only known done when the stores are)
+        f32x4 b4[NT];
+#pragma unroll
+        for (int t = 0; t < NT; t++) b4[t] = *reinterpret_cast<const f32x4*>(bias + t * 32 + c8);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            const float bv = bias[t * 32 + i];
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float v0 = acc[t][4 * g] + bv, v1 = acc[t][4 * g + 1] + bv, v2 = acc[t][4 * g + 2] + bv, v3 = acc[t][4 * g + 3] + bv;
-                if (EPI == 1) { v0 = elu_f(v0); v1 = elu_f(v1); v2 = elu_f(v2); v3 = elu_f(v3); }
-                quad_transpose(v0, v1, v2, v3, c4);
-                const int rr = rbase + 8 * g + 4 * h + c4;
+            for (int r = 0; r < 16; r++) wl[((r & 3) + 8 * (r >> 2) + 4 * h) * LS + i] = acc[t][r];
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                f32x4 v = *reinterpret_cast<const f32x4*>(&wl[(r8 + 8 * k) * LS + c8]) + b4[t];
+                if (EPI == 1) { v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w); }
+                const int rr = rbase + r8 + 8 * k;
 #ifdef BG_PROBE_NO_STORE  // tools/mlp_nostore_probe.py: how much of the kernel is its store tail?  (never defined in the product build)
-                if (rr < M && v0 == 12345.678f) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
+                if (rr < M && v.x == 12345.678f) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + c8) = v;
 #else
-                if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = f32x4{v0, v1, v2, v3};
+                if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + c8) = v;
 #endif
             }
             if (t < 3) BG_EPI_STAMP(12 + t);
