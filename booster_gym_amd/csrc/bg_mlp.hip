@@ -127,9 +127,9 @@ __global__ __launch_bounds__(256, 3) void mlp_fwd_kernel(int M, int ldy, const f
 #pragma unroll
             for (int t = 0; t < NT; t++)
 #pragma unroll
-                for (int g = 0; g < 4; g++) {
-                    const int rr = rb + 8 * g + 4 * h + (lane & 3);
-                    auxq[t][g] = *reinterpret_cast<const f32x4*>(auxp + (size_t)(rr < M ? rr : M - 1) * ldy + t * 32 + (i & ~3));
+                for (int g = 0; g < 4; g++) {  // the epilogue's row layout: row (lane >> 3) + 8 g, columns 4 (lane & 7) ..
+                    const int rr = rb + 8 * g + (lane >> 3);
+                    auxq[t][g] = *reinterpret_cast<const f32x4*>(auxp + (size_t)(rr < M ? rr : M - 1) * ldy + t * 32 + 4 * (lane & 7));
                 }
         }
         mfma_chunk<NT>(acc, aB, sw1);

@@ -192,9 +192,9 @@ __global__ __launch_bounds__(256, 2) void mlp_split_kernel(int M, int ldy, const
 #pragma unroll
         for (int t = 0; t < NT; t++)
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const int rr = rb + 8 * g + 4 * h + (lane & 3);
-                auxq[t][g] = *reinterpret_cast<const f32x4*>(auxp + (size_t)(rr < M ? rr : M - 1) * ldy + t * 32 + (i & ~3));
+            for (int g = 0; g < 4; g++) {  // the epilogue's row layout: row (lane >> 3) + 8 g, columns 4 (lane & 7) ..
+                const int rr = rb + 8 * g + (lane >> 3);
+                auxq[t][g] = *reinterpret_cast<const f32x4*>(auxp + (size_t)(rr < M ? rr : M - 1) * ldy + t * 32 + 4 * (lane & 7));
             }
     }
     read_b3(b0, s10);

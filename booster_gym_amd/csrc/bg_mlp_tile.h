@@ -35,7 +35,7 @@ __device__ __forceinline__ void load_a_chunk(f32x4 (&a4)[4], const float* xrow, 
 #define BG_EPI_STAMP(SLOT) do { } while (0)
 #endif
 // Epilogue shared by the fp32-MFMA kernel and the split-bf16 kernel below (both leave the 32 x 32 tiles in the same C layout).
-// csum: LDS the caller no longer needs: 4 x 32 x 36 floats (18 KB) for the forward epilogues' transposition, 4 x 128 floats for EPI 2.
+// csum: LDS the caller no longer needs: 4 x 32 x 36 floats (18 KB) for the transposition + 4 x 128 floats for the column sums of EPI 2.
 template <int EPI, int NT>
 __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&auxq)[EPI == 2 ? NT : 1][4], int M, int ldy, int bx, int by, int wave,
                                                int lane, int i, int h, const float* __restrict__ bias, float* __restrict__ Y,
@@ -76,39 +76,44 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&
             if (t < 3) BG_EPI_STAMP(12 + t);
         }
     } else {
-        __syncthreads();
-        const int c4 = lane & 3;
+        // backward: the same transposition through the wave's LDS block, then x elu'(aux) (aux arrives in the row layout: auxq[t][k] = 4 columns c8 .. of
+        // row r8 + 8 k, fetched by the caller under its last MFMAs), the store, and the column sums: over the 4 rows of a lane, then over the 8 lanes
+        // that share its columns (lane bits 3..5)
+        constexpr int LS = 36;
+        float* wl = csum + wave * (32 * LS);
+        float* cpart = csum + 4 * 32 * LS;  // [4 waves][128 columns], behind the transposition blocks
+        const int r8 = lane >> 3, c8 = (lane & 7) * 4;
 #pragma unroll
         for (int t = 0; t < NT; t++) {
-            f32x4 cs = {0.f, 0.f, 0.f, 0.f};  // this lane's row contributions to columns t * 32 + (i & ~3) + 0..3
 #pragma unroll
-            for (int g = 0; g < 4; g++) {
-                float v0 = acc[t][4 * g], v1 = acc[t][4 * g + 1], v2 = acc[t][4 * g + 2], v3 = acc[t][4 * g + 3];
-                quad_transpose(v0, v1, v2, v3, c4);
-                const f32x4 a = auxq[t][g];
-                const int rr = rbase + 8 * g + 4 * h + c4;
+            for (int r = 0; r < 16; r++) wl[((r & 3) + 8 * (r >> 2) + 4 * h) * LS + i] = acc[t][r];
+            f32x4 cs = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const f32x4 a = auxq[t][k];
+                f32x4 v = *reinterpret_cast<const f32x4*>(&wl[(r8 + 8 * k) * LS + c8]);
+                const int rr = rbase + r8 + 8 * k;
                 if (rr < M) {
-                    const f32x4 v = {v0 * (a.x > 0.f ? 1.0f : a.x + 1.0f), v1 * (a.y > 0.f ? 1.0f : a.y + 1.0f),
-                                     v2 * (a.z > 0.f ? 1.0f : a.z + 1.0f), v3 * (a.w > 0.f ? 1.0f : a.w + 1.0f)};
-                    *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + (i & ~3)) = v;
+                    v = f32x4{v.x * (a.x > 0.f ? 1.0f : a.x + 1.0f), v.y * (a.y > 0.f ? 1.0f : a.y + 1.0f),
+                              v.z * (a.z > 0.f ? 1.0f : a.z + 1.0f), v.w * (a.w > 0.f ? 1.0f : a.w + 1.0f)};
+                    *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + c8) = v;
                     cs += v;
                 }
             }
-            // rows live in the 4 lanes of a quad and in the two lane halves: add them up, lane (c4 == 0, h == 0) of every quad writes 4 columns
 #pragma unroll
             for (int k = 0; k < 4; k++) {
                 float x = cs[k];
-                x += dpp_xor1(x);
-                x += dpp_xor2(x);
+                x += __shfl_xor(x, 8);
+                x += __shfl_xor(x, 16);
                 x += __shfl_xor(x, 32);
                 cs[k] = x;
             }
-            if (h == 0 && c4 == 0) *reinterpret_cast<f32x4*>(&csum[wave * N + t * 32 + i]) = cs;
+            if (r8 == 0) *reinterpret_cast<f32x4*>(&cpart[wave * N + t * 32 + c8]) = cs;
         }
         __syncthreads();
         if (threadIdx.x < N)
             colpart[(size_t)bx * ldy + by * N + threadIdx.x] =
-                csum[threadIdx.x] + csum[N + threadIdx.x] + csum[2 * N + threadIdx.x] + csum[3 * N + threadIdx.x];
+                cpart[threadIdx.x] + cpart[N + threadIdx.x] + cpart[2 * N + threadIdx.x] + cpart[3 * N + threadIdx.x];
     }
 }
 
