@@ -1,5 +1,5 @@
-// Pieces shared by the layer kernels of bg_mlp.hip (fp32 MFMA) and bg_mlp_split.hip (split bf16 MFMA): tile constants, the A-operand load, the
-// 4 x 4 quad transpose and the epilogues.  gfx950 only.
+// Pieces shared by the layer kernels of bg_mlp.hip (fp32 MFMA) and bg_mlp_split.hip (split bf16 MFMA): tile constants, the A-operand load and
+// the epilogues.  gfx950 only.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -8,19 +8,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));  // native vector: stay
 
 // exp(x) - 1 through v_exp_f32: absolute error ~1e-7 on (-1, 0], far below fp32 activation noise; expm1f costs ~20 VALU per element
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
-
-// 4 x 4 transpose across the 4 lanes of a quad: in: lane c holds (v0..v3) = column c of a block M[k][c]; out: lane c holds row c, M[c][0..3].
-__device__ __forceinline__ float dpp_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true)); }  // quad_perm [1,0,3,2]
-__device__ __forceinline__ float dpp_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true)); }  // quad_perm [2,3,0,1]
-__device__ __forceinline__ void quad_transpose(float& v0, float& v1, float& v2, float& v3, int c) {
-    const bool odd = c & 1, hi = c & 2;
-    // stage 1 (lanes c ^ 1): swap the off-diagonal elements of the 2 x 2 blocks (v0, v1) and (v2, v3)
-    float s01 = dpp_xor1(odd ? v0 : v1), s23 = dpp_xor1(odd ? v2 : v3);
-    if (odd) { v0 = s01; v2 = s23; } else { v1 = s01; v3 = s23; }
-    // stage 2 (lanes c ^ 2): swap the off-diagonal 2 x 2 blocks: (v0, v1) of the upper lanes with (v2, v3) of the lower ones
-    float t02 = dpp_xor2(hi ? v0 : v2), t13 = dpp_xor2(hi ? v1 : v3);
-    if (hi) { v0 = t02; v1 = t13; } else { v2 = t02; v3 = t13; }
-}
 
 constexpr int FW_BM = 128;   // rows per workgroup (4 waves x 32 rows)
 constexpr int FW_KC = 32;    // k-chunk staged in LDS
