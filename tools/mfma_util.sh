@@ -21,7 +21,7 @@ for r in csv.DictReader(open(f)):
 line = json.loads([l for l in open(f"{R}/gpurun_out/prof_{tag}_mfma.log") if l.startswith("{")][-1])
 iters = 7
 total_busy = sum(busy.values()) / iters
-upd_ms = line["phase_ms"]["update"]
+upd_ms = float(os.environ.get("BG_UNPROFILED_UPDATE_MS", line["phase_ms"]["update"]))  # the counter pass serialises kernels: pass the update time of an unprofiled run
 # effective clock from the counters of the MFMA kernels themselves: GRBM_GUI_ACTIVE is summed over the 8 XCDs
 out = {"command": "tools/mfma_util.sh (rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE -- python3 bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra)",
        "iterations_profiled": iters, "update_ms_per_iteration_in_this_run": upd_ms,
