@@ -34,11 +34,12 @@ class ModelDesc(C.Structure):
         ("feet_edge_pos", C.c_float * 3 * 4),
         ("num_body_spheres", C.c_int32), ("sphere_body", C.c_int32 * MAX_BODY_SPHERES), ("sphere_pos", C.c_float * 3 * MAX_BODY_SPHERES),
         ("sphere_radius", C.c_float * MAX_BODY_SPHERES),
+        ("self_capsule_a", C.c_float * 3 * 2 * 2), ("self_capsule_b", C.c_float * 3 * 2 * 2), ("self_capsule_r", C.c_float * 2 * 2),
     ]
 
 
 class AssetOptions(C.Structure):
-    _fields_ = [("collapse_fixed_joints", C.c_int32), ("body_contacts", C.c_int32), ("foot_names", C.c_char_p * 2), ("feet_edge_pos", C.c_float * 3 * 4)]
+    _fields_ = [("collapse_fixed_joints", C.c_int32), ("body_contacts", C.c_int32), ("self_collisions", C.c_int32), ("foot_names", C.c_char_p * 2), ("feet_edge_pos", C.c_float * 3 * 4)]
 
 
 class WgradProblem(C.Structure):
@@ -79,6 +80,7 @@ class EnvCfg(C.Structure):
         ("state_fp16", C.c_int32),
         ("body_gate_height", C.c_float), ("penalized_body_mask", C.c_int32), ("terminate_body_mask", C.c_int32),
         ("exact_still_count", C.c_int32), ("same_step_curriculum", C.c_int32),
+        ("self_collisions", C.c_int32), ("self_k", C.c_float), ("self_d", C.c_float), ("self_mu", C.c_float), ("self_visc", C.c_float),
     ]
 
 

@@ -23,6 +23,7 @@ namespace bg {
 constexpr int LEG_LINKS = 6;
 // Hip_Pitch y, Hip_Roll x, Hip_Yaw z, Knee_Pitch y, Ankle_Pitch y, Ankle_Roll x  (T1_locomotion.xml:56-79)
 constexpr int LEG_AXIS[LEG_LINKS] = {2, 1, 3, 2, 2, 1};
+constexpr int SELF_SHANK = 3, SELF_FOOT = 5;  // the leg links that carry a self-collision capsule
 
 struct LinkConst {   // one rigid body, per-env randomisation already applied
     V3 pos;          // origin in the parent frame
@@ -38,6 +39,9 @@ struct Phys {
     int clamp_qd;
     // non-foot body contacts (explicit penalty on the contact spheres of the trunk box / hip-yaw and shank cylinders)
     float body_gate, body_kn, body_dn, body_mu;
+    // leg against leg (explicit penalty between the shank / foot capsules of the two legs)
+    int self_on;
+    float self_k, self_d, self_mu, self_visc;
 };
 
 struct TerrainDev {
@@ -58,6 +62,8 @@ struct ModelDev {  // nominal (un-randomised) model, shared by all envs; filled 
     int sph_n;
     int sph_first[13], sph_cnt[13];
     float sph_pos[16][3], sph_r[16];
+    // self-collision capsules [leg][0 = shank (leg link 3, axis z), 1 = foot (leg link 5, axis x)]: centre, half length along the axis, radius
+    float cap_c[2][2][3], cap_h[2][2], cap_r[2][2];
 };
 
 struct LegParams {
@@ -129,6 +135,13 @@ struct LegWorkT {  // what the inward sweep leaves behind for the outward sweep
     Store st;
     float dinv[LEG_LINKS], u[LEG_LINKS];
     M3 Rfoot;          // foot -> world
+    M3 Rsh; V3 psh;    // shank -> world, shank origin relative to the trunk origin (for the leg-against-leg contacts; dead after them)
+    // leg-against-leg contacts: wrench on this leg's shank / foot about the link origin in link coordinates, their world-frame forces,
+    // the lateral clearance between the two legs (negative = capsules can meet), and "left to the second kernel" (SELF_DEFER)
+    SV self_fx[2];
+    V3 self_shank, self_foot;
+    float self_gap;
+    bool self_deferred;
     SI Bc;             // contact impedance on the foot
     SV f0c;            // contact wrench at the current state (foot coords)
     bool contact;
@@ -285,6 +298,7 @@ BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M
             R.e[r][K] = -s * Rpar.e[r][J] + c * Rpar.e[r][K];
         }
     }
+    if constexpr (I == SELF_SHANK) { w.Rsh = R; w.psh = p; }
     if constexpr (I + 1 < LEG_LINKS) {
         leg_outward<I + 1>(lp, ls, w, v, R, p, vfoot, pfoot);
     } else {
@@ -294,6 +308,138 @@ BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M
     }
 }
 
+// ---------------------------------------------------------------- leg against leg (self-collision)
+// The reference runs PhysX with self-collision enabled (envs/T1.yaml:69 `self_collisions: 0`, passed to create_actor at envs/t1.py:128).
+// Here: the shank cylinder and the foot box of each leg are capsules (ModelDev::cap_*), every capsule of the left leg can meet every capsule
+// of the right leg, and a pair that overlaps repels with an explicit penalty force along the line between the closest points of the two
+// segments, with regularised Coulomb friction, applied with opposite signs to the two links at ONE point (the middle of the overlap), so
+// momentum is conserved.  oracle/dyn_ref.c:self_contacts states the same model in float64.
+//
+// Lane structure: a lane owns one leg.  Cheap part, every substep: the lateral extent (trunk y axis) of the own two capsules, one value
+// swapped with the partner lane; the legs are on opposite sides of the trunk, so capsules can only meet when the left leg's lowest y is below
+// the right leg's highest y.  Only then (both lanes of the env take the branch together: the test is symmetric) the lanes exchange their
+// segments (26 values) and each evaluates the four pairs for the forces on ITS links.
+constexpr float SELF_REG = 1e-2f;   // Tikhonov term of the closest-point problem: unique, continuous answer for parallel segments
+struct SelfSeg { V3 A, B, w, vA; float r; };  // world frame: end points, angular velocity, velocity of the point A, radius
+
+template <int AX>
+BG_HD SelfSeg self_segment(const M3& R, V3 p, SV v, V3 c, float h, float r) {
+    const V3 ax = v3(R.e[0][AX], R.e[1][AX], R.e[2][AX]);
+    const V3 mid = p + mul(R, c);
+    SelfSeg s;
+    s.A = mid - h * ax; s.B = mid + h * ax;
+    V3 a_loc = c; a_loc.e[AX] -= h;
+    s.w = mul(R, v.a);
+    s.vA = mul(R, v.l + cross(v.a, a_loc));
+    s.r = r;
+    return s;
+}
+// lateral extent of a capsule towards the other leg, as a signed margin: left leg (leg 0, +y side) = its lowest y, right leg = minus its highest y
+template <int AX>
+BG_HD float self_inner_extent(int leg, const M3& R, V3 p, V3 c, float h, float r, V3 ey, V3 p0) {
+    const float ym = dot(ey, p + mul(R, c) - p0);
+    const float yh = fabsf(h * (ey.e[0] * R.e[0][AX] + ey.e[1] * R.e[1][AX] + ey.e[2] * R.e[2][AX]));
+    return leg == 0 ? ym - yh - r : -(ym + yh + r);
+}
+BG_HD float clamp01(float x) { return fminf(fmaxf(x, 0.f), 1.f); }
+// own segment o against the partner leg's segment q: world-frame force on the own link and its point of application
+BG_HD bool self_pair(const Phys& ph, const SelfSeg& o, const SelfSeg& q, V3* F, V3* x) {
+    const V3 d1 = o.B - o.A, d2 = q.B - q.A, r = o.A - q.A;
+    const float a = dot(d1, d1), e = dot(d2, d2), b = dot(d1, d2), c = dot(d1, r), f = dot(d2, r);
+    const float ap = a * (1.0f + SELF_REG) + 1e-30f, ep = e * (1.0f + SELF_REG) + 1e-30f, cp = c - 0.5f * SELF_REG * a, fp = f + 0.5f * SELF_REG * e;
+    float s = clamp01((b * fp - cp * ep) * bg_rcp(ap * ep - b * b));
+    float t = (b * s + fp) * bg_rcp(ep);
+    if (t < 0.f) { t = 0.f; s = clamp01(-cp * bg_rcp(ap)); }
+    else if (t > 1.f) { t = 1.f; s = clamp01((b - cp) * bg_rcp(ap)); }
+    const V3 cj = q.A + t * d2, dv = o.A + s * d1 - cj;
+    const float dd = dot(dv, dv), rs = o.r + q.r;
+    if (!(dd < rs * rs)) return false;
+    const float dist = bg_sqrt(dd), pen = rs - dist;
+    const V3 n = bg_rcp(dist + 1e-9f) * dv;  // from the partner's link to the own one
+    const V3 xc = cj + (q.r - 0.5f * pen) * n;
+    const V3 vrel = (o.vA + cross(o.w, xc - o.A)) - (q.vA + cross(q.w, xc - q.A));
+    const float vn = dot(vrel, n);
+    const float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
+    const float fn = ph.self_k * pen - ph.self_d * ramp * vn;
+    if (!(fn > 0.f)) return false;
+    const V3 vt = vrel - vn * n;
+    const float c_t = fminf(ph.self_visc, ph.self_mu * fn * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
+    *F = fn * n - c_t * vt;
+    *x = xc;
+    return true;
+}
+BG_HD float sel2(int leg, float left, float right) { return leg == 0 ? left : right; }
+struct SelfCaps { V3 cs, cf; float hs, hf, rs, rf; };  // this leg's shank / foot capsule: centre, half length, radius (link coordinates)
+BG_HD SelfCaps self_caps(const ModelDev& M, int leg) {
+    SelfCaps c;
+    for (int a = 0; a < 3; a++) { c.cs.e[a] = sel2(leg, M.cap_c[0][0][a], M.cap_c[1][0][a]); c.cf.e[a] = sel2(leg, M.cap_c[0][1][a], M.cap_c[1][1][a]); }
+    c.hs = sel2(leg, M.cap_h[0][0], M.cap_h[1][0]); c.hf = sel2(leg, M.cap_h[0][1], M.cap_h[1][1]);
+    c.rs = sel2(leg, M.cap_r[0][0], M.cap_r[1][0]); c.rf = sel2(leg, M.cap_r[0][1], M.cap_r[1][1]);
+    return c;
+}
+// Lateral clearance between the capsules of the two legs along the trunk's y axis (the legs hang on opposite sides of the trunk: capsules can
+// only meet when it is negative).  Positions are relative to the trunk origin.  The sum is the same bits on both lanes of the env.
+template <class X>
+BG_HD float self_clearance(const SelfCaps& c, int leg, const M3& Rsh, V3 psh, const M3& Rft, V3 pft, const M3& R0, X& x) {
+    const V3 ey = v3(R0.e[0][1], R0.e[1][1], R0.e[2][1]), o = v3(0.f, 0.f, 0.f);
+    const float mine = fminf(self_inner_extent<2>(leg, Rsh, psh, c.cs, c.hs, c.rs, ey, o), self_inner_extent<0>(leg, Rft, pft, c.cf, c.hf, c.rf, ey, o));
+    return mine + x.swap(mine);
+}
+// The narrow phase: both lanes of the env exchange their two segments (26 values) and each evaluates the four pairs for the forces on ITS
+// links.  Poses relative to the trunk origin, velocities in link coordinates.  fx[0 / 1] = wrench on the shank / foot about the link origin,
+// link coordinates; fw_shank / fw_foot = world-frame forces (contact-force tensor rows, t1.py:219).  Both lanes of an env must call it together.
+template <class X>
+BG_HD void self_narrow_phase(const Phys& ph, const SelfCaps& c, const M3& Rsh, V3 psh, SV vsh, const M3& Rft, V3 pft, SV vft, X& x, SV* fx,
+                             V3* fw_shank, V3* fw_foot) {
+    SelfSeg own[2], oth[2];
+    own[0] = self_segment<2>(Rsh, psh, vsh, c.cs, c.hs, c.rs);
+    own[1] = self_segment<0>(Rft, pft, vft, c.cf, c.hf, c.rf);
+    for (int k = 0; k < 2; k++) {
+        for (int a = 0; a < 3; a++) {
+            oth[k].A.e[a] = x.swap(own[k].A.e[a]); oth[k].B.e[a] = x.swap(own[k].B.e[a]);
+            oth[k].w.e[a] = x.swap(own[k].w.e[a]); oth[k].vA.e[a] = x.swap(own[k].vA.e[a]);
+        }
+        oth[k].r = x.swap(own[k].r);
+    }
+    for (int k = 0; k < 2; k++) {
+        V3 Fs = v3(0.f, 0.f, 0.f), Ts = v3(0.f, 0.f, 0.f);
+        const V3 org = k == 0 ? psh : pft;
+        for (int l = 0; l < 2; l++) {
+            V3 F, xc;
+            if (self_pair(ph, own[k], oth[l], &F, &xc)) { Fs = Fs + F; Ts = Ts + cross(xc - org, F); }
+        }
+        const M3& R = k == 0 ? Rsh : Rft;
+        fx[k].l = mulT(R, Fs); fx[k].a = mulT(R, Ts);
+        if (k == 0) *fw_shank = Fs; else *fw_foot = Fs;
+    }
+}
+// How a kernel runs the leg-against-leg contacts.  The narrow phase is ~500 instructions that almost no env needs in a given substep; the
+// clearance test alone costs the fused env step 1.7 %, the branch around the narrow phase another 7.5 % although it is hardly ever taken
+// (register allocation around a large block in the middle of the sweeps), and it makes the two-waves-per-SIMD ABA kernel spill:
+//   SELF_INLINE  clearance test and narrow phase between the outward and the inward sweep (fused env step, granular simulate, second kernels)
+//   SELF_DEFER   clearance test only; an env whose legs can meet is marked (w.self_deferred) and left to the launch's second kernel (ABA kernel)
+// (Also measured for the fused env step: looking for the contacts at the TOP of the substep loop instead, from a kinematics-only walk, only when
+// the clearance of the substep before was small: 111.8 us per env step against 107.8 for SELF_INLINE and 98.5 without the contacts.  Not kept.)
+enum { SELF_INLINE = 0, SELF_DEFER = 1 };
+
+template <int MODE, class W, class X>
+BG_HD void self_contacts(const Phys& ph, const ModelDev& M, int leg, W& w, const M3& R0, V3 pfoot_rel, SV vfoot, X& x) {
+    w.self_fx[0] = sv_zero(); w.self_fx[1] = sv_zero();
+    w.self_shank = v3(0.f, 0.f, 0.f); w.self_foot = v3(0.f, 0.f, 0.f);
+    w.self_deferred = false;
+    w.self_gap = 1.0f;
+    if (!ph.self_on) return;
+    const SelfCaps c = self_caps(M, leg);
+    w.self_gap = self_clearance(c, leg, w.Rsh, w.psh, w.Rfoot, pfoot_rel, R0, x);
+    if constexpr (MODE == SELF_DEFER) {
+        w.self_deferred = w.self_gap < 0.f;
+    } else if constexpr (MODE == SELF_INLINE) {
+#ifndef BG_SELF_NORARE   // (timing experiment: the per-substep part only)
+        if (w.self_gap < 0.f)
+            self_narrow_phase(ph, c, w.Rsh, w.psh, w.st.template get_v<SELF_SHANK>(), w.Rfoot, pfoot_rel, vfoot, x, w.self_fx, &w.self_shank, &w.self_foot);
+#endif
+    }
+}
 // ---------------------------------------------------------------- foot contact (4 sole corners)
 template <class W>
 BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& lp, W& w, SV vfoot, V3 pfoot, V3* force_w0) {
@@ -393,17 +539,23 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
 // Everything a lane does before the pair exchange: kinematics, contact, inward sweep.
 // gb = gravity in base coordinates.  Returns this leg's contribution at the trunk.
 // fext (optional): applied wrench on each link about its own origin, link coordinates (a = torque, l = force).
-template <class W>
-BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const LegParams& lp, const LegState& ls, const float* tau,
-                                  const BaseState& bs, M3 R0, SV v0, W& w, V3* foot_force_w0, const SV* fext = nullptr) {
+template <int SELF, class W, class X>
+BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int leg, const LegParams& lp, const LegState& ls, const float* tau,
+                                  const BaseState& bs, M3 R0, SV v0, W& w, X& x, V3* foot_force_w0, const SV* fext_in = nullptr) {
     SV vfoot;
-    V3 pfoot;
-    leg_outward<0>(lp, ls, w, v0, R0, bs.pos, &vfoot, &pfoot);
+    V3 pfoot_rel;  // link origins are carried RELATIVE to the trunk origin: the leg-against-leg distances must not lose digits to the world position
+    leg_outward<0>(lp, ls, w, v0, R0, v3(0.f, 0.f, 0.f), &vfoot, &pfoot_rel);
+    const V3 pfoot = bs.pos + pfoot_rel;
+    self_contacts<SELF>(ph, M, leg, w, R0, pfoot_rel, vfoot, x);
+    SV fext[LEG_LINKS];  // applied wrenches per link: the caller's, plus the leg-against-leg contacts on the shank and the foot
+    for (int i = 0; i < LEG_LINKS; i++) fext[i] = fext_in ? fext_in[i] : sv_zero();
+    fext[SELF_SHANK] = fext[SELF_SHANK] + w.self_fx[0];
+    fext[SELF_FOOT] = fext[SELF_FOOT] + w.self_fx[1];
     foot_contact(ph, tr, lp, w, vfoot, pfoot, foot_force_w0);
     const LinkConst fk = w.st.template link<LEG_LINKS - 1>(lp);
     SI IA = rigid_inertia(fk);
     SV pA = crf(vfoot, mul_rigid(fk, vfoot));
-    if (fext) pA = pA - fext[LEG_LINKS - 1];
+    pA = pA - fext[LEG_LINKS - 1];
     if (w.contact) {
         // f_ext = f0 - B a_true = (f0 - B ag) - B a'   with a' = a_true - ag  (gravity field in foot coords)
         SV ag; ag.a = v3(0.f, 0.f, 0.f); ag.l = mulT(w.Rfoot, ph.g);
@@ -598,8 +750,9 @@ using SubstepCtxLdsLink = SubstepCtxT<LegWorkT<LdsLinkStore>>;
 // World-frame contact forces of the non-foot bodies of one lane's half of the env (net_contact_force rows; reward `collision`, t1.py:627-629)
 struct BodyContactOut {
     bool active;          // the trunk was low enough for the spheres to be evaluated
-    V3 trunk;             // this lane's share of the trunk's force (sum the two lanes)
-    V3 link[LEG_LINKS];   // this leg's links
+    V3 trunk;             // this lane's share of the trunk's force (sum the two lanes); zero when not active
+    V3 link[LEG_LINKS];   // this leg's links: terrain contacts of their spheres (when active) + the shank's share of the leg-against-leg contacts;
+                          // the foot's entry stays zero (its force comes out of substep_solve)
 };
 
 // Are the non-foot body contacts evaluated for this env?  Only while the trunk origin is less than ph.body_gate above the terrain: from a
@@ -613,15 +766,21 @@ BG_HD bool body_contacts_active(const Phys& ph, const TerrainDev& tr, const Mode
 // fext (optional): applied wrench on each link about its own origin, link coordinates.  BODY: also evaluate the contact spheres of the
 // non-foot bodies (M / leg: model constants and which leg this lane owns); their wrenches join `fext`, the trunk's share is subtracted from
 // this lane's contribution at the trunk.
-template <bool BODY, class Ctx>
+template <bool BODY, int SELF = SELF_INLINE, class Ctx, class X>
 BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int leg, const LegParams& lp, const LegState& ls,
-                                   const float* tau, const BaseState& bs, Ctx& cx, const SV* fext = nullptr, BodyContactOut* bo = nullptr) {
+                                   const float* tau, const BaseState& bs, Ctx& cx, X& x, const SV* fext = nullptr, BodyContactOut* bo = nullptr) {
     cx.R0 = quat_to_mat(bs.quat);
     cx.v0 = base_body_velocity(cx.R0, bs);
     V3 unused;
     if (bo) bo->active = BODY;
     if constexpr (!BODY) {
-        return leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused, fext);
+        BaseContribution out = leg_phase1<SELF>(ph, tr, M, leg, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, x, &unused, fext);
+        if (bo) {
+            bo->trunk = v3(0.f, 0.f, 0.f);
+            for (int i = 0; i < LEG_LINKS; i++) bo->link[i] = v3(0.f, 0.f, 0.f);
+            bo->link[SELF_SHANK] = cx.w.self_shank;
+        }
+        return out;
     } else {
         SV fx[LEG_LINKS];
         V3 fw[LEG_LINKS];
@@ -629,11 +788,12 @@ BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const M
         leg_contact_prepass<0>(ph, tr, M, 1 + leg * LEG_LINKS, cx.w.st, lp, ls, cx.v0, cx.R0, bs.pos, fx, fw);
         V3 ft = v3(0.f, 0.f, 0.f);
         const SV wt = body_contact_wrench(ph, tr, M, 0, leg, cx.R0, bs.pos, cx.v0, &ft);
+        BaseContribution out = leg_phase1<SELF>(ph, tr, M, leg, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, x, &unused, fx);
         if (bo) {
             bo->trunk = ft;
             for (int i = 0; i < LEG_LINKS; i++) bo->link[i] = fw[i];
+            bo->link[SELF_SHANK] = bo->link[SELF_SHANK] + cx.w.self_shank;
         }
-        BaseContribution out = leg_phase1(ph, tr, lp, ls, tau, bs, cx.R0, cx.v0, cx.w, &unused, fx);
         out.p = out.p - wt;
         return out;
     }
@@ -654,7 +814,7 @@ BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& l
         V3 fb = cx.w.f0c.l - (mulT(cx.w.Bc.H, at.a) + mul(cx.w.Bc.M, at.l));
         fw = mul(cx.w.Rfoot, fb);
     }
-    *foot_force_w = fw;
+    *foot_force_w = fw + cx.w.self_foot;  // net contact force on the foot: terrain (over the step) + the other leg
 }
 BG_HD void substep_integrate(const Phys& ph, const LegParams& lp, LegState& ls, BaseState& bs, const float* qdd, V3 lin_w, V3 ang_w) {
     integrate_leg(ph, lp, ls, qdd);

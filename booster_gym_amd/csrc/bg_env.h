@@ -165,6 +165,7 @@ BG_HD Phys make_phys(const bg_env_cfg& c) {
     // non-foot shapes: default material (friction 1, restitution 0) averaged with the terrain's, nominal stiffness / damping
     ph.body_gate = c.body_gate_height; ph.body_kn = c.contact_k; ph.body_dn = c.contact_d * (1.0f - 0.5f * c.terrain_restitution);
     ph.body_mu = 0.5f * (1.0f + c.terrain_mu);
+    ph.self_on = c.self_collisions; ph.self_k = c.self_k; ph.self_d = c.self_d; ph.self_mu = c.self_mu; ph.self_visc = c.self_visc;
     return ph;
 }
 BG_HD ContactCfg make_contact_cfg(const bg_env_cfg& c) {
@@ -275,7 +276,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
                 tmean[i] += tau[i];
             }
             BodyContactOut bo;
-            BaseContribution mine = substep_pre<BODY>(ph, E.terrain, M, leg, lp, ls, tau, bs, cx, (const SV*)nullptr, &bo);
+            BaseContribution mine = substep_pre<BODY>(ph, E.terrain, M, leg, lp, ls, tau, bs, cx, x, (const SV*)nullptr, &bo);
             // contact forces of the LAST substep are the ones the task logic sees (contact_collection: last substep, T1.yaml:56): how many
             // penalised / terminating non-foot bodies of this leg carry more than 1 N (t1.py:553,629); the trunk is counted once (leg 0)
             body_pen = 0.f; body_term = 0.f;
@@ -291,6 +292,11 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
                     if (C.penalized_body_mask & bit) body_pen += hit;
                     if (C.terminate_body_mask & bit) body_term += hit;
                 }
+            } else {  // trunk high: the only non-foot contact there can be is the shank against the other leg
+                const float hit = dot(bo.link[SELF_SHANK], bo.link[SELF_SHANK]) > 1.0f ? 1.f : 0.f;
+                const int bit = 1 << (1 + j0 + SELF_SHANK);
+                body_pen = (C.penalized_body_mask & bit) ? hit : 0.f;
+                body_term = (C.terminate_body_mask & bit) ? hit : 0.f;
             }
             BaseContribution both;
             for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }

@@ -34,7 +34,11 @@ struct bg_env {
     float* f = nullptr;
     bg_half_bits* h = nullptr;  // fp16 slab of the dynamic state (cfg.state_fp16), else null
     int* rs_counts = nullptr;     // [blocks of RS_BLOCK envs] envs resampled in this step (exact-resampling modes), else null
-    unsigned* lowmask = nullptr;  // [blocks of 32 envs] envs left to the body-contact kernel (two-kernel scheme), null = no body spheres
+    unsigned* lowmask = nullptr;  // [blocks of 32 envs] envs a launch's kernel A leaves to its kernel B (two-kernel schemes); null = never needed
+    bool body_two_kernel = false; // the non-foot body contacts can occur (body spheres and body_gate_height > terminate_height)
+    unsigned* fd_mask = nullptr;  // [blocks of 32 envs] envs the ABA kernel leaves to its second kernel (legs can meet / trunk low)
+    int* fd_list = nullptr;       // [n] the same envs as a compact list (aba_compact_kernel)
+    unsigned* fd_count = nullptr; // [2] entries in fd_list, finished workgroups of the second kernel
     int32_t* i = nullptr;
     float* stats = nullptr;
     float* curr = nullptr;
@@ -218,8 +222,8 @@ __global__ __launch_bounds__(RS_BLOCK) void resample_apply_kernel(EnvDev E, cons
 // them per wave.  With everything in registers the kernel needs 282 and one wave fits per SIMD (77 % VALU-busy, the rest is exposed load
 // and dependency latency).  Keeping the per-env link constants (13 floats x 6 links per lane, computed once per launch) in LDS brings it to
 // 248 registers with no spill, two waves share a SIMD and cover each other's stalls: 88 % VALU-busy, +14 % throughput at 1M envs.
-template <bool BODY>
-__device__ __forceinline__ void forward_dynamics_lane(const EnvDev& E, int e, bool valid, float* s_work, const float* __restrict__ root,
+template <bool BODY, int SELF>
+__device__ __forceinline__ bool forward_dynamics_lane(const EnvDev& E, int e, bool valid, float* s_work, const float* __restrict__ root,
                                                       const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ tau,
                                                       const float* __restrict__ wrench, float* __restrict__ qacc) {
     const int lane = threadIdx.x, leg = lane & 1;
@@ -245,62 +249,98 @@ __device__ __forceinline__ void forward_dynamics_lane(const EnvDev& E, int e, bo
     SubstepCtxLdsLink cx;
     cx.w.st.p = (lds_f32*)(s_work + lane);
     cx.w.st.stash(lp);
-    BaseContribution mine = substep_pre<BODY>(ph, E.terrain, *E.model, leg, lp, ls, t6, bs, cx), both;
+    BaseContribution mine = substep_pre<BODY, SELF>(ph, E.terrain, *E.model, leg, lp, ls, t6, bs, cx, x), both;
+    if constexpr (SELF == SELF_DEFER) { if (cx.w.self_deferred) return true; }  // the legs can meet: the second kernel's env (both lanes agree)
     for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
     for (int k = 0; k < 3; k++) { both.p.a.e[k] = mine.p.a.e[k] + x.swap(mine.p.a.e[k]); both.p.l.e[k] = mine.p.l.e[k] + x.swap(mine.p.l.e[k]); }
     float qdd[LEG_LINKS];
     V3 lin_w, ang_w, fw;
     substep_solve(ph, bk, lp, ls, cx, both, wr, qdd, &lin_w, &ang_w, &fw);
-    if (!valid) return;
+    if (!valid) return false;
     float* o = qacc + (size_t)e * 18;
     if (leg == 0) for (int a = 0; a < 3; a++) { o[a] = lin_w.e[a]; o[3 + a] = ang_w.e[a]; }
     for (int i = 0; i < LEG_LINKS; i++) o[6 + leg * 6 + i] = qdd[i];
     for (int a = 0; a < 3; a++) E.f[(size_t)(F_CONTACT + 3 * leg + a) * n + e] = fw.e[a];
+    return false;
 }
-// GATED = false: no env of this launch can need the body contacts (lowmask is null): the plain kernel.  GATED = true: kernel A of the
-// two-kernel scheme (see env_step_kernel).
+// Kernel A of the ABA launch.  An env is LEFT to kernel B when its legs can meet (lateral clearance test inside the sweeps, SELF_DEFER: the
+// leg-against-leg narrow phase never enters this kernel) or, GATED only, when its trunk is low (non-foot body contacts).  Kernel A records
+// such envs in a 32-bit mask per block; aba_compact_kernel turns the masks into a compact env list, so that kernel B's cost follows the
+// NUMBER of such envs and not the number of 32-env blocks that contain one (joint angles drawn around the standing pose with sigma = 0.1 rad
+// cross the legs of 8 % of the envs: 93 % of the blocks).  (One atomic per wave straight into the list was tried first: 30 k returning
+// atomics on one address doubled this kernel's time.)  left_mask may be null when nothing can be left (no self-collision geometry, GATED = false).
 template <bool GATED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
                                                               const float* __restrict__ qd, const float* __restrict__ tau,
                                                               const float* __restrict__ wrench, float* __restrict__ qacc,
-                                                              unsigned* __restrict__ lowmask) {
+                                                              unsigned* __restrict__ left_mask) {
     __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
     const int lane = threadIdx.x;
     int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
     const bool valid = e < E.n;
     if (!valid) e = E.n - 1;
-    if constexpr (!GATED) {
-        forward_dynamics_lane<false>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
-    } else {
-        __shared__ unsigned s_low;
-        if (lane == 0) s_low = 0u;
-        __syncthreads();
+    bool left = false;
+    if constexpr (GATED) {
         const float* r = root + (size_t)e * 13;
-        if (body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]))) {
-            if (valid && !(lane & 1)) atomicOr(&s_low, 1u << (lane >> 1));
-        } else {
-            forward_dynamics_lane<false>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+        left = body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]));
+    }
+    if (!left) left = forward_dynamics_lane<false, SELF_DEFER>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+    if (left_mask) {
+        const unsigned long long m = __ballot(left && valid && !(lane & 1));  // bit 2k = env k of the block
+        if (lane == 0) {
+            unsigned packed = 0u;
+            for (int k = 0; k < ENVS_PER_BLOCK; k++) packed |= (unsigned)((m >> (2 * k)) & 1ull) << k;
+            left_mask[blockIdx.x] = packed;
         }
-        __syncthreads();
-        if (lane == 0) lowmask[blockIdx.x] = s_low;
     }
 }
-// kernel B of the two-kernel scheme (see env_step_kernel): the envs whose trunk is low, with the non-foot body contacts
+// masks of kernel A -> compact list of env indices (count in left_count[0]); one atomic per 256 blocks
+__global__ __launch_bounds__(256) void aba_compact_kernel(const unsigned* __restrict__ left_mask, int nblocks, int* __restrict__ left_list, unsigned* __restrict__ left_count) {
+    __shared__ unsigned s_scan[256];
+    __shared__ unsigned s_base;
+    const int b = blockIdx.x * 256 + threadIdx.x;
+    const unsigned m = b < nblocks ? left_mask[b] : 0u;
+    const unsigned c = (unsigned)__popc(m);
+    s_scan[threadIdx.x] = c;
+    __syncthreads();
+    for (int d = 1; d < 256; d <<= 1) {
+        const unsigned v = (int)threadIdx.x >= d ? s_scan[threadIdx.x - d] : 0u;
+        __syncthreads();
+        s_scan[threadIdx.x] += v;
+        __syncthreads();
+    }
+    if (threadIdx.x == 255) s_base = s_scan[255] ? atomicAdd(left_count, s_scan[255]) : 0u;
+    __syncthreads();
+    unsigned o = s_base + s_scan[threadIdx.x] - c, mm = m;
+    while (mm) {
+        const int k = __ffs((int)mm) - 1;
+        mm &= mm - 1u;
+        left_list[o++] = b * ENVS_PER_BLOCK + k;
+    }
+}
+// kernel B of the ABA launch: the envs kernel A left, 32 per wave from the compact list, with the leg-against-leg narrow phase and (trunk low)
+// the non-foot body contacts.  The last workgroup to finish empties the list for the next launch.  left_count: [0] entries, [1] finished workgroups.
 __global__ __launch_bounds__(64) void forward_dynamics_body_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
                                                                    const float* __restrict__ qd, const float* __restrict__ tau,
                                                                    const float* __restrict__ wrench, float* __restrict__ qacc,
-                                                                   const unsigned* __restrict__ lowmask, int nblocks) {
+                                                                   const int* __restrict__ left_list, unsigned* __restrict__ left_count) {
     __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
     const int lane = threadIdx.x;
-    for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
-        const unsigned lowm = lowmask[b];
-        if (lowm == 0u) continue;
-        int e = b * ENVS_PER_BLOCK + (lane >> 1);
-        const bool valid = e < E.n;
-        if (!valid) e = E.n - 1;
-        if ((lowm >> (lane >> 1)) & 1u) forward_dynamics_lane<true>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+    const int cnt = (int)__builtin_nontemporal_load(left_count);
+    for (int w = blockIdx.x; w * ENVS_PER_BLOCK < cnt; w += gridDim.x) {
+        const int idx = w * ENVS_PER_BLOCK + (lane >> 1);
+        const bool valid = idx < cnt;
+        const int e = left_list[valid ? idx : cnt - 1];
+        // the body spheres only for an env whose trunk is low (the same rule as kernel A's and the oracle's)
+        const float* r = root + (size_t)e * 13;
+        if (E.cfg.body_gate_height > E.cfg.terminate_height && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2])))
+            forward_dynamics_lane<true, SELF_INLINE>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+        else
+            forward_dynamics_lane<false, SELF_INLINE>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
     }
+    __syncthreads();
+    if (lane == 0 && atomicAdd(left_count + 1, 1u) == gridDim.x - 1u) { left_count[0] = 0u; left_count[1] = 0u; }
 }
 
 // ------------------------------------------------------------------ granular simulator calls on caller-owned Isaac-layout tensors
@@ -362,7 +402,7 @@ __device__ __forceinline__ void sim_substep_lane(const EnvDev& E, int e, bool va
     DppSwap x;
     SubstepCtx cx;
     BodyContactOut bo;
-    BaseContribution mine = substep_pre<BODY>(ph, E.terrain, *E.model, leg, L.lp, L.ls, t6, L.bs, cx, has_w ? fext : nullptr, &bo), both;
+    BaseContribution mine = substep_pre<BODY>(ph, E.terrain, *E.model, leg, L.lp, L.ls, t6, L.bs, cx, x, has_w ? fext : nullptr, &bo), both;
     for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
     for (int k = 0; k < 3; k++) { both.p.a.e[k] = mine.p.a.e[k] + x.swap(mine.p.a.e[k]); both.p.l.e[k] = mine.p.l.e[k] + x.swap(mine.p.l.e[k]); }
@@ -382,11 +422,11 @@ __device__ __forceinline__ void sim_substep_lane(const EnvDev& E, int e, bool va
     }
     if (contact) {  // net contact force per body, world frame (t1.py:219): sole corners of the feet + contact spheres of the other shapes
         float* c = contact + (size_t)e * 39;
-        V3 tf = bo.active ? bo.trunk : v3(0.f, 0.f, 0.f);
+        V3 tf = bo.trunk;
         for (int a = 0; a < 3; a++) tf.e[a] += x.swap(tf.e[a]);
         if (leg == 0) for (int a = 0; a < 3; a++) c[a] = tf.e[a];
         for (int i = 0; i < LEG_LINKS - 1; i++)
-            for (int a = 0; a < 3; a++) c[3 * (1 + leg * LEG_LINKS + i) + a] = bo.active ? bo.link[i].e[a] : 0.f;
+            for (int a = 0; a < 3; a++) c[3 * (1 + leg * LEG_LINKS + i) + a] = bo.link[i].e[a];
         for (int a = 0; a < 3; a++) c[3 * (LEG_LINKS + leg * LEG_LINKS) + a] = fw.e[a];
     }
     if (body) sim_write_body(L, e, leg, body);
@@ -513,6 +553,14 @@ int bg_model_validate(const bg_model_desc* d) {
         if (k > 0 && b < d->sphere_body[k - 1]) return fail(-1, "bg_model: contact spheres must be sorted by body");
         if (!(d->sphere_radius[k] >= 0.f)) return fail(-1, "bg_model: negative sphere radius");
     }
+    for (int leg = 0; leg < 2; leg++)
+        for (int k = 0; k < 2; k++) {
+            if (!(d->self_capsule_r[leg][k] >= 0.f)) return fail(-1, "bg_model: negative self-collision capsule radius");
+            const int ax = k == 0 ? 2 : 0;  // shank capsule along z, foot capsule along x (the per-lane code is written for these axes)
+            for (int a = 0; a < 3; a++)
+                if (a != ax && d->self_capsule_a[leg][k][a] != d->self_capsule_b[leg][k][a])
+                    return fail(-1, "bg_model: self-collision capsules must lie along z (shank) / x (foot) of their link");
+        }
     return 0;
 }
 extern "C" int bg_model_create(const bg_model_desc* d, bg_model** out) {
@@ -581,6 +629,16 @@ static int env_create_fill(bg_env* e, const bg_env_cfg* cfg, const bg_model* mod
         md.sph_r[k] = model->desc.sphere_radius[k];
         for (int a = 0; a < 3; a++) md.sph_pos[k][a] = model->desc.sphere_pos[k][a];
     }
+    bool caps = true;
+    for (int leg = 0; leg < 2; leg++)
+        for (int k = 0; k < 2; k++) {
+            const int ax = k == 0 ? 2 : 0;
+            for (int a = 0; a < 3; a++) md.cap_c[leg][k][a] = 0.5f * (model->desc.self_capsule_a[leg][k][a] + model->desc.self_capsule_b[leg][k][a]);
+            md.cap_h[leg][k] = 0.5f * (model->desc.self_capsule_b[leg][k][ax] - model->desc.self_capsule_a[leg][k][ax]);
+            md.cap_r[leg][k] = model->desc.self_capsule_r[leg][k];
+            caps = caps && md.cap_r[leg][k] > 0.f;
+        }
+    if (!caps) e->cfg.self_collisions = 0;  // a model without self-collision geometry
     HIP_OK(hipMemcpy(e->model_dev, &md, sizeof(md), hipMemcpyHostToDevice));
     e->terrain.type = 0; e->terrain.rows = e->terrain.cols = e->terrain.border_px = 0; e->terrain.inv_hscale = 1.f; e->terrain.vscale = 0.f; e->terrain.hf = nullptr;
     memset(&e->bound, 0, sizeof(e->bound));
@@ -595,7 +653,14 @@ static int env_create_fill(bg_env* e, const bg_env_cfg* cfg, const bg_model* mod
     // Non-foot body contacts are evaluated for envs whose trunk starts a step below body_gate_height.  When the task resets every env that ends
     // a step below terminate_height >= body_gate_height (the shipped T1.yaml: 0.45 / 0.45) no env can ever start a step that low, and the whole
     // two-kernel scheme (mask bookkeeping + the second launch) is left out: the launch sequence is then exactly that of a model without spheres.
-    if (model->desc.num_body_spheres > 0 && cfg->body_gate_height > cfg->terminate_height) {
+    e->body_two_kernel = model->desc.num_body_spheres > 0 && cfg->body_gate_height > cfg->terminate_height;
+    if (e->body_two_kernel || e->cfg.self_collisions) {  // the ABA launch's second kernel also takes the envs whose legs can meet
+        HIP_OK(hipMalloc(&e->fd_mask, sizeof(unsigned) * ((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK)));
+        HIP_OK(hipMalloc(&e->fd_list, sizeof(int) * n));
+        HIP_OK(hipMalloc(&e->fd_count, sizeof(unsigned) * 2));
+        HIP_OK(hipMemset(e->fd_count, 0, sizeof(unsigned) * 2));
+    }
+    if (e->body_two_kernel) {
         const size_t nb = (n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
         HIP_OK(hipMalloc(&e->lowmask, sizeof(unsigned) * nb));
         HIP_OK(hipMemset(e->lowmask, 0, sizeof(unsigned) * nb));
@@ -633,7 +698,7 @@ extern "C" int bg_env_create(const bg_env_cfg* cfg, const bg_model* model, bg_en
 extern "C" void bg_env_destroy(bg_env* e) {
     if (!e) return;
     (void)hipFree(e->sim_tau); (void)hipFree(e->sim_bforce); (void)hipFree(e->sim_btorque);
-    (void)hipFree(e->f); (void)hipFree(e->h); (void)hipFree(e->lowmask); (void)hipFree(e->rs_counts); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
+    (void)hipFree(e->f); (void)hipFree(e->h); (void)hipFree(e->lowmask); (void)hipFree(e->fd_mask); (void)hipFree(e->fd_list); (void)hipFree(e->fd_count); (void)hipFree(e->rs_counts); (void)hipFree(e->i); (void)hipFree(e->stats); (void)hipFree(e->model_dev); (void)hipFree(e->hf); (void)hipFree(e->curr); (void)hipFree(e->curr_read);
     delete e;
 }
 
@@ -684,14 +749,14 @@ static int launch_step(bg_env* e, const float* actions, int mode, const StepOut&
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
     hipStream_t st = (hipStream_t)stream;
     const uint32_t cnt = (uint32_t)e->step_count;
-    if (e->lowmask) {
+    if (e->body_two_kernel) {
         if (e->h) hipLaunchKernelGGL((env_step_kernel<true, true>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
         else hipLaunchKernelGGL((env_step_kernel<false, true>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, e->lowmask);
     } else {
         if (e->h) hipLaunchKernelGGL((env_step_kernel<true, false>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, (unsigned*)nullptr);
         else hipLaunchKernelGGL((env_step_kernel<false, false>), grid, block, 0, st, env_dev(e), actions, cnt, mode, out, (unsigned*)nullptr);
     }
-    if (e->lowmask && mode == 0) {  // kernel B: the envs whose trunk was low at the start of the step (usually none)
+    if (e->body_two_kernel && mode == 0) {  // kernel B: the envs whose trunk was low at the start of the step (usually none)
         const int nb = (int)grid.x;
         dim3 gb(nb < BODY_GRID ? nb : BODY_GRID);
         if (e->h) hipLaunchKernelGGL(env_step_body_kernel<true>, gb, block, 0, st, env_dev(e), actions, cnt, out, (const unsigned*)e->lowmask, nb);
@@ -819,12 +884,14 @@ extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float
                                        float* qacc, void* stream) {
     if (!e || !root || !q || !qd || !tau || !qacc) return fail(-1, "bg_env_forward_dynamics: null argument");
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
-    if (!e->lowmask) hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, (unsigned*)nullptr);
+    if (!e->fd_list) hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, (unsigned*)nullptr);
     else {
-        hipLaunchKernelGGL(forward_dynamics_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->lowmask);
-        const int nb = (int)grid.x;
-        hipLaunchKernelGGL(forward_dynamics_body_kernel, dim3(nb < BODY_GRID ? nb : BODY_GRID), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
-                           wrench, qacc, (const unsigned*)e->lowmask, nb);
+        if (e->body_two_kernel) hipLaunchKernelGGL(forward_dynamics_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->fd_mask);
+        else hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->fd_mask);
+        const int nb = (int)grid.x;  // one wave per SIMD: 1024 resident workgroups walk the list
+        hipLaunchKernelGGL(aba_compact_kernel, dim3((nb + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned*)e->fd_mask, nb, e->fd_list, e->fd_count);
+        hipLaunchKernelGGL(forward_dynamics_body_kernel, dim3(nb < 1024 ? nb : 1024), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
+                           wrench, qacc, (const int*)e->fd_list, e->fd_count);
     }
     HIP_OK(hipGetLastError());
     return 0;
@@ -869,8 +936,9 @@ extern "C" int bg_sim_simulate(bg_env* e, void* stream) {
     dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
     const bool w = e->sim_wrench_pending;
     hipLaunchKernelGGL(sim_substep_kernel, grid, block, 0, (hipStream_t)stream, env_dev(e), e->sim_root, e->sim_dof, (const float*)e->sim_tau,
-                       w ? (const float*)e->sim_bforce : nullptr, w ? (const float*)e->sim_btorque : nullptr, e->sim_contact, e->sim_body, e->lowmask);
-    if (e->lowmask) {
+                       w ? (const float*)e->sim_bforce : nullptr, w ? (const float*)e->sim_btorque : nullptr, e->sim_contact, e->sim_body,
+                       e->body_two_kernel ? e->lowmask : (unsigned*)nullptr);
+    if (e->body_two_kernel) {
         const int nb = (int)grid.x;
         hipLaunchKernelGGL(sim_substep_body_kernel, dim3(nb < BODY_GRID ? nb : BODY_GRID), block, 0, (hipStream_t)stream, env_dev(e), e->sim_root, e->sim_dof,
                            (const float*)e->sim_tau, w ? (const float*)e->sim_bforce : nullptr, w ? (const float*)e->sim_btorque : nullptr, e->sim_contact,

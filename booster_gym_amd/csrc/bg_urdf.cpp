@@ -358,6 +358,27 @@ extern "C" int bg_model_load_urdf(const char* path, const bg_asset_options* opt,
                 }
             }
         }
+        // self-collision capsules (create_actor(..., self_collisions), envs/t1.py:128): per leg the shank = the link two above the foot (the capsule
+        // inscribed in its z-axis cylinder) and the foot (its box, L >= W >= H along x, y, z: radius W / 2, half length L / 2 - H about the box centre)
+        if (opt->self_collisions && foot[0] >= 0 && foot[1] >= 0) {
+            for (int leg = 0; leg < 2; leg++) {
+                const int fb = foot[leg], ank = d.parent[fb], shank = ank >= 0 ? d.parent[ank] : -1;
+                if (shank < 0) throw std::runtime_error("self-collision capsules: the foot needs a link two above it");
+                const Shape *cyl = nullptr, *box = nullptr;
+                for (const Shape& s : body_link[shank]->shapes) if (s.type == 1) { if (cyl) throw std::runtime_error("self-collision capsules: more than one cylinder on a shank"); cyl = &s; }
+                for (const Shape& s : body_link[fb]->shapes) if (s.type == 0) { if (box) throw std::runtime_error("self-collision capsules: more than one box on a foot"); box = &s; }
+                if (!cyl || !box) throw std::runtime_error("self-collision capsules need one cylinder on each shank and one box on each foot");
+                if (!is_identity(cyl->rot) || !is_identity(box->rot)) throw std::runtime_error("self-collision capsules: rotated collision primitives are unsupported");
+                if (!(box->size[0] >= box->size[1] && box->size[1] >= box->size[2])) throw std::runtime_error("self-collision capsules: the foot box must be longest along x and thinnest along z");
+                const double hs = std::fmax(0.5 * cyl->size[1] - cyl->size[0], 0.0), hf = std::fmax(0.5 * box->size[0] - box->size[2], 0.0);
+                for (int a = 0; a < 3; a++) {
+                    d.self_capsule_a[leg][0][a] = (float)(cyl->pos.e[a] - (a == 2 ? hs : 0.0)); d.self_capsule_b[leg][0][a] = (float)(cyl->pos.e[a] + (a == 2 ? hs : 0.0));
+                    d.self_capsule_a[leg][1][a] = (float)(box->pos.e[a] - (a == 0 ? hf : 0.0)); d.self_capsule_b[leg][1][a] = (float)(box->pos.e[a] + (a == 0 ? hf : 0.0));
+                }
+                d.self_capsule_r[leg][0] = (float)cyl->size[0];
+                d.self_capsule_r[leg][1] = (float)(0.5 * box->size[1]);
+            }
+        }
         const int rc = bg_model_validate(&d);
         if (rc) return rc;
         *out = m.release();

@@ -258,6 +258,12 @@ class T1(BaseTask):
             raise ValueError(f"sim.state_dtype must be fp32 or fp16, got {sd!r}")
         c.state_fp16 = int(sd in ("fp16", "float16", "half"))
         c.body_gate_height = float(cfg.get("contact", {}).get("body_gate_height", 0.45))
+        # asset.self_collisions is Isaac Gym's collision-filter bitmask (create_actor, t1.py:128): 0 = the actor's shapes collide with each other
+        c.self_collisions = int(int(cfg["asset"].get("self_collisions", 0)) == 0)
+        c.self_k = float(ct.get("self_stiffness", 4.0e4))
+        c.self_d = float(ct.get("self_damping", 150.0))
+        c.self_mu = float(ct.get("self_friction", 1.0))
+        c.self_visc = float(ct.get("self_friction_viscosity", 100.0))
         c.penalized_body_mask = sum(1 << int(b) for b in set(self.penalized_contact_indices.tolist()))
         c.terminate_body_mask = sum(1 << int(b) for b in set(self.termination_contact_indices.tolist()))
         return c
@@ -290,6 +296,13 @@ class T1(BaseTask):
             d.sphere_body[k], d.sphere_radius[k] = b, r
             for a in range(3):
                 d.sphere_pos[k][a] = c[a]
+        # self-collision capsules (shank cylinders, foot boxes); asset.self_collisions != 0 filters them out as in Isaac Gym
+        if int(self.cfg["asset"].get("self_collisions", 0)) == 0:
+            for leg, caps in enumerate(m.self_collision_capsules(self.feet_indices.tolist())):
+                for k, (_, a, b, r) in enumerate(caps):
+                    d.self_capsule_r[leg][k] = r
+                    for ax in range(3):
+                        d.self_capsule_a[leg][k][ax], d.self_capsule_b[leg][k][ax] = a[ax], b[ax]
         return d
 
     def _create_native(self):

@@ -125,6 +125,30 @@ class FlatModel:
                 out += [(b, (px, py, pz + sgn * max(half - r, 0.0)), r) for sgn in (-1.0, 1.0)]
         return sorted(out, key=lambda t: t[0])
 
+    def self_collision_capsules(self, foot_bodies):
+        """Self-collision capsules of the legs (reference: `self_collisions` passed to create_actor, envs/t1.py:128, envs/T1.yaml:69), per foot body
+        `[shank, foot]`, each `(body, a, b, radius)` with the segment end points in link coordinates.  Shank = the link two above the foot: the
+        capsule inscribed in its z-axis cylinder (the segment between the centres of the end spheres that `contact_spheres` returns).  Foot box
+        (L >= W >= H along x, y, z): radius W / 2, the box's half width, and half length L / 2 - H about the box centre, so that feet side by side
+        touch where the boxes do and the round ends start one sole thickness inside the box ends."""
+        out = []
+        for fb in foot_bodies:
+            shank = int(self.parent[int(self.parent[fb])])
+            cyl = [sh for sh in self.shapes if int(sh["body"]) == shank and sh["type"] == "cylinder"]
+            box = [sh for sh in self.shapes if int(sh["body"]) == int(fb) and sh["type"] == "box"]
+            if len(cyl) != 1 or len(box) != 1:
+                raise ValueError("self-collision capsules need one cylinder on each shank and one box on each foot (URDF <collision>)")
+            (px, py, pz), (r, length) = (float(v) for v in cyl[0]["pos"]), (float(v) for v in cyl[0]["size"])
+            h = max(0.5 * length - r, 0.0)
+            caps = [(shank, (px, py, pz - h), (px, py, pz + h), r)]
+            (px, py, pz), (lx, ly, lz) = (float(v) for v in box[0]["pos"]), (float(v) for v in box[0]["size"])
+            if not lx >= ly >= lz:
+                raise ValueError("self-collision capsules: the foot box must be longest along x and thinnest along z")
+            h = max(0.5 * lx - lz, 0.0)
+            caps.append((int(fb), (px - h, py, pz), (px + h, py, pz), 0.5 * ly))
+            out.append(caps)
+        return out
+
     def to_json(self):
         return {
             "format": "booster_gym_amd.flat_model.v1",

@@ -48,6 +48,11 @@ typedef struct {
     int32_t sphere_body[BG_MAX_BODY_SPHERES];
     float sphere_pos[BG_MAX_BODY_SPHERES][3];
     float sphere_radius[BG_MAX_BODY_SPHERES];
+    /* Self-collision capsules (gym.create_actor(..., self_collisions), envs/t1.py:128; asset.self_collisions, envs/T1.yaml:69): [leg][0] the shank
+     * (4th link of the leg chain; the capsule inscribed in its URDF cylinder, axis z), [leg][1] the foot (last link; a capsule along x standing in
+     * for the URDF box).  Segment end points a / b in link coordinates and the radius; radius 0 on any of them = the model has no self-collision
+     * geometry.  Left-leg capsules meet right-leg capsules; links of one chain never meet each other. */
+    float self_capsule_a[2][2][3], self_capsule_b[2][2][3], self_capsule_r[2][2];
 } bg_model_desc;
 
 /* randomisation / noise entry (utils/utils.py:5-30): mode 0 none, 1 gaussian additive,
@@ -122,6 +127,11 @@ typedef struct {
      * grid AFTER this step's resets have updated it (t1.py:305 before :365) instead of the grid as of the start of the step.  Either one moves
      * the cross-env part of _resample_commands into two small follow-up launches per env step (count, apply); not available with state_fp16. */
     int32_t exact_still_count, same_step_curriculum;
+    /* Leg-against-leg contacts (asset.self_collisions: 0 in envs/T1.yaml:69 is Isaac Gym's "collide with everything", passed to create_actor at
+     * envs/t1.py:128): 1 = the shank / foot capsules of the two legs repel each other with an explicit penalty force:
+     * normal stiffness [N/m] and damping [N s/m], Coulomb coefficient, and the viscous cap [N s/m] of the regularised friction. */
+    int32_t self_collisions;
+    float self_k, self_d, self_mu, self_visc;
 } bg_env_cfg;
 
 /* ---- model (replaces gym.load_asset and the asset queries, t1.py:54-108) */
@@ -134,6 +144,7 @@ int bg_model_create(const bg_model_desc* desc, bg_model** out);
 typedef struct {
     int32_t collapse_fixed_joints;  /* envs/T1.yaml:67 */
     int32_t body_contacts;          /* 0: no contact spheres (feet-only contact) */
+    int32_t self_collisions;        /* 0: no self-collision capsules */
     const char* foot_names[2];      /* envs/T1.yaml:78 */
     float feet_edge_pos[4][3];      /* envs/T1.yaml:79-82 */
 } bg_asset_options;

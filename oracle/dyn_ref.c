@@ -67,6 +67,11 @@ typedef struct {
     int32_t sph_body[16];
     double sph_pos[16][3];
     double sph_r[16];
+    /* self-collision capsules (asset.self_collisions, envs/T1.yaml:69; create_actor(..., self_collisions) envs/t1.py:128): sphere-swept segments
+     * standing in for the shank cylinders and the foot boxes of the URDF <collision> elements, in link coordinates */
+    int32_t n_cap;
+    int32_t cap_body[4];
+    double cap_a[4][3], cap_b[4][3], cap_r[4];
 } ref_model_t;
 
 typedef struct {
@@ -81,6 +86,10 @@ typedef struct {
     int32_t clamp_qd;
     int32_t pad;
     double body_gate_height; /* m: the spheres above are evaluated only while the trunk origin is lower than this above the terrain */
+    /* leg-against-leg contacts: explicit penalty between the capsules of the left and of the right leg */
+    double self_k, self_d, self_mu, self_visc; /* N/m, N s/m, Coulomb coefficient, N s/m cap of the regularised friction */
+    int32_t self_collisions;                   /* 1 = modelled (asset.self_collisions: 0 in the yaml, Isaac Gym's "no filter") */
+    int32_t pad2;
 } ref_phys_t;
 
 typedef struct {
@@ -387,6 +396,104 @@ static void body_contacts(const ref_model_t *m, const ref_phys_t *p, const ref_t
     }
 }
 
+/* ------------------------------------------------------------------ self-collision: leg against leg.
+ * Every capsule of a left-leg link against every capsule of a right-leg link (the reference enables PhysX self-collision, envs/T1.yaml:69,
+ * envs/t1.py:128; links of the same chain never meet).  Closest points of the two segments, penetration = r1 + r2 - distance, explicit
+ * penalty force along the line of centres with regularised Coulomb friction, applied with opposite signs to the two bodies at ONE point
+ * (the middle of the overlap), so linear and angular momentum are conserved exactly.
+ *
+ * Closest points: minimise |P1(s) - P2(t)|^2 + SELF_REG (a (s - 1/2)^2 + e (t - 1/2)^2) over the unit square, a, e = squared segment lengths.
+ * The small quadratic term makes the minimiser unique and continuous when the segments are parallel (feet side by side, shanks side by
+ * side: the unregularised problem has a whole interval of minimisers there and the contact point would jump along the link under
+ * rounding-size changes); it moves the closest distance only to second order.  Solved exactly as for the plain problem (clamp s, solve t,
+ * clamp t, re-solve s: C. Ericson, Real-Time Collision Detection, 5.1.9) with a' = a (1 + REG), e' = e (1 + REG), c' = c - a REG / 2,
+ * f' = f + e REG / 2. */
+#define SELF_REG 1e-2
+static double clamp01(double x) { return x < 0 ? 0 : (x > 1 ? 1 : x); }
+static void segment_closest(const double A1[3], const double B1[3], const double A2[3], const double B2[3], double *s_out, double *t_out) {
+    double d1[3], d2[3], r[3];
+    for (int a = 0; a < 3; a++) { d1[a] = B1[a] - A1[a]; d2[a] = B2[a] - A2[a]; r[a] = A1[a] - A2[a]; }
+    double a = d1[0] * d1[0] + d1[1] * d1[1] + d1[2] * d1[2], e = d2[0] * d2[0] + d2[1] * d2[1] + d2[2] * d2[2];
+    double b = d1[0] * d2[0] + d1[1] * d2[1] + d1[2] * d2[2];
+    double c = d1[0] * r[0] + d1[1] * r[1] + d1[2] * r[2], f = d2[0] * r[0] + d2[1] * r[1] + d2[2] * r[2];
+    double ap = a * (1 + SELF_REG) + REF_TINY, ep = e * (1 + SELF_REG) + REF_TINY, cp = c - 0.5 * SELF_REG * a, fp = f + 0.5 * SELF_REG * e;
+    double denom = ap * ep - b * b;
+    double s = clamp01((b * fp - cp * ep) / denom);
+    double t = (b * s + fp) / ep;
+    if (t < 0) { t = 0; s = clamp01(-cp / ap); }
+    else if (t > 1) { t = 1; s = clamp01((b - cp) / ap); }
+    *s_out = s; *t_out = t;
+}
+/* test hook: the regularised closest points of two segments given as 12 numbers (A1, B1, A2, B2) */
+void ref_segment_closest(const double *seg, double *st) { segment_closest(seg, seg + 3, seg + 6, seg + 9, st, st + 1); }
+/* spatial velocity of body b (body coords) -> world-frame velocity of the body-fixed point at world position x */
+static void point_velocity_w(const kin_t *k, int b, const double x[3], double vw[3]) {
+    double rel[3], rb[3], wxr[3], vb[3];
+    for (int a = 0; a < 3; a++) rel[a] = x[a] - k->pw[b][a];
+    m3t_vec(k->Rw[b], rel, rb);
+    cross(k->v[b], rb, wxr);
+    for (int a = 0; a < 3; a++) vb[a] = k->v[b][3 + a] + wxr[a];
+    m3_vec(k->Rw[b], vb, vw);
+}
+static void self_contacts(const ref_model_t *m, const ref_phys_t *p, const kin_t *k, double wrench[NB][6], double fw_body[NB][3]) {
+    if (!p->self_collisions) return;
+    for (int i = 0; i < m->n_cap; i++)
+        for (int j = i + 1; j < m->n_cap; j++) {
+            const int bi = m->cap_body[i], bj = m->cap_body[j];
+            if ((bi <= 6) == (bj <= 6)) continue; /* same leg (bodies 1..6 = left chain, 7..12 = right chain) */
+            double Ai[3], Bi[3], Aj[3], Bj[3], t3[3];
+            m3_vec(k->Rw[bi], m->cap_a[i], t3); for (int a = 0; a < 3; a++) Ai[a] = k->pw[bi][a] + t3[a];
+            m3_vec(k->Rw[bi], m->cap_b[i], t3); for (int a = 0; a < 3; a++) Bi[a] = k->pw[bi][a] + t3[a];
+            m3_vec(k->Rw[bj], m->cap_a[j], t3); for (int a = 0; a < 3; a++) Aj[a] = k->pw[bj][a] + t3[a];
+            m3_vec(k->Rw[bj], m->cap_b[j], t3); for (int a = 0; a < 3; a++) Bj[a] = k->pw[bj][a] + t3[a];
+            double s, t, ci[3], cj[3], dv[3];
+            segment_closest(Ai, Bi, Aj, Bj, &s, &t);
+            for (int a = 0; a < 3; a++) { ci[a] = Ai[a] + s * (Bi[a] - Ai[a]); cj[a] = Aj[a] + t * (Bj[a] - Aj[a]); dv[a] = ci[a] - cj[a]; }
+            const double d2 = dv[0] * dv[0] + dv[1] * dv[1] + dv[2] * dv[2], rs = m->cap_r[i] + m->cap_r[j];
+            if (d2 >= rs * rs) continue;
+            const double dist = sqrt(d2), pen = rs - dist;
+            double n[3], x[3], vi[3], vj[3];
+            const double inv = 1.0 / (dist + 1e-9); /* coincident axes: no direction, (almost) no force */
+            for (int a = 0; a < 3; a++) { n[a] = dv[a] * inv; x[a] = cj[a] + n[a] * (m->cap_r[j] - 0.5 * pen); } /* n points from j to i */
+            point_velocity_w(k, bi, x, vi);
+            point_velocity_w(k, bj, x, vj);
+            double vrel[3], vt[3];
+            for (int a = 0; a < 3; a++) vrel[a] = vi[a] - vj[a];
+            const double vn = vrel[0] * n[0] + vrel[1] * n[1] + vrel[2] * n[2];
+            const double ramp = pen < p->contact_ramp ? pen / p->contact_ramp : 1.0;
+            const double fn = p->self_k * pen - p->self_d * ramp * vn;
+            if (fn <= 0) continue;
+            for (int a = 0; a < 3; a++) vt[a] = vrel[a] - vn * n[a];
+            const double vtn = sqrt(vt[0] * vt[0] + vt[1] * vt[1] + vt[2] * vt[2]);
+            double c_t = p->self_visc;
+            const double cap = p->self_mu * fn / (vtn + 1e-6);
+            if (cap < c_t) c_t = cap;
+            double F[3]; /* on body i; body j gets -F */
+            for (int a = 0; a < 3; a++) F[a] = fn * n[a] - c_t * vt[a];
+            for (int side = 0; side < 2; side++) {
+                const int b = side ? bj : bi;
+                const double sg = side ? -1.0 : 1.0;
+                double rel[3], rb[3], fb[3], tq[3];
+                for (int a = 0; a < 3; a++) rel[a] = x[a] - k->pw[b][a];
+                m3t_vec(k->Rw[b], rel, rb);
+                m3t_vec(k->Rw[b], F, fb);
+                for (int a = 0; a < 3; a++) fb[a] *= sg;
+                cross(rb, fb, tq);
+                for (int a = 0; a < 3; a++) { wrench[b][a] += tq[a]; wrench[b][3 + a] += fb[a]; fw_body[b][a] += sg * F[a]; }
+            }
+        }
+}
+
+/* test hook: world-frame forces of the leg-against-leg contacts alone on every body, for one state: out [NB][3] */
+void ref_self_contact_forces(const ref_model_t *m, const ref_phys_t *p, const double *root, const double *q, const double *qd, double *out) {
+    static __thread kin_t k;
+    static __thread double wr[NB][6];
+    kinematics(m, p, 0, 0, root, q, qd, &k);
+    memset(wr, 0, sizeof(wr));
+    memset(out, 0, sizeof(double) * NB * 3);
+    self_contacts(m, p, &k, wr, (double(*)[3])out);
+}
+
 /* joint-limit spring/damper, implicit in the joint velocity:  tau = t0 - bl * qdd */
 static void joint_limits(const ref_model_t *m, const ref_phys_t *p, const double *q, const double *qd, double *t0, double *bl) {
     for (int j = 0; j < ND; j++) {
@@ -466,6 +573,7 @@ static int forward_core(const ref_model_t *m, const ref_phys_t *p, const ref_ter
     }
     static __thread double bw[NB][6], bfw[NB][3];
     body_contacts(m, p, t, root, &k, bw, bfw);
+    self_contacts(m, p, &k, bw, bfw);
     for (int i = 0; i < m->nb; i++) for (int a = 0; a < 6; a++) pA[i][a] -= bw[i][a];
     for (int f = 0; f < 2; f++) {
         int b = m->foot_body[f];
@@ -527,7 +635,7 @@ static int forward_core(const ref_model_t *m, const ref_phys_t *p, const ref_ter
     if (a_body)
         for (int i = 0; i < m->nb; i++) for (int a = 0; a < 6; a++) a_body[6 * i + a] = ap[i][a] + k.ag[i][a];
     if (contact_force_w) {
-        memcpy(contact_force_w, bfw, NB * 3 * sizeof(double)); /* explicit body contacts; the feet rows are overwritten below */
+        memcpy(contact_force_w, bfw, NB * 3 * sizeof(double)); /* explicit contacts: body spheres against the terrain, leg against leg */
         for (int f = 0; f < 2; f++) {
             /* report the force that actually acted over the step: f0 - B a, rotated to world */
             int b = m->foot_body[f];
@@ -535,7 +643,9 @@ static int forward_core(const ref_model_t *m, const ref_phys_t *p, const ref_ter
             for (int a = 0; a < 6; a++) at[a] = ap[b][a] + k.ag[b][a];
             m6_vec(ct.B[f], at, Ba);
             for (int a = 0; a < 3; a++) fb[a] = ct.f0[f][3 + a] - Ba[3 + a];
-            m3_vec(k.Rw[b], fb, contact_force_w + 3 * b);
+            double fww[3];
+            m3_vec(k.Rw[b], fb, fww);
+            for (int a = 0; a < 3; a++) contact_force_w[3 * b + a] += fww[a]; /* + the foot's share of the leg-against-leg contacts */
         }
     }
     return 0;

@@ -33,6 +33,11 @@ def _structs(ct):
             ("sph_body", C.c_int32 * 16),
             ("sph_pos", ct * 3 * 16),
             ("sph_r", ct * 16),
+            ("n_cap", C.c_int32),
+            ("cap_body", C.c_int32 * 4),
+            ("cap_a", ct * 3 * 4),
+            ("cap_b", ct * 3 * 4),
+            ("cap_r", ct * 4),
         ]
 
     class RefPhys(C.Structure):
@@ -50,6 +55,12 @@ def _structs(ct):
             ("clamp_qd", C.c_int32),
             ("pad", C.c_int32),
             ("body_gate_height", ct),
+            ("self_k", ct),
+            ("self_d", ct),
+            ("self_mu", ct),
+            ("self_visc", ct),
+            ("self_collisions", C.c_int32),
+            ("pad2", C.c_int32),
         ]
 
     class RefTerrain(C.Structure):
@@ -104,6 +115,8 @@ def _f64(a):
 DEFAULT_PHYS = dict(
     dt=0.002, g=(0.0, 0.0, -9.81), contact_k=4.0e4, contact_d=600.0, contact_ramp=1.0e-3, friction_visc=1.0e4,
     limit_k=2000.0, limit_d=20.0, terrain_mu=1.0, terrain_restitution=0.0, clamp_qd=1, body_gate_height=0.45,
+    # leg against leg (asset.self_collisions: 0 = on, envs/T1.yaml:69): explicit penalty between the shank / foot capsules of the two legs
+    self_collisions=1, self_k=4.0e4, self_d=150.0, self_mu=1.0, self_visc=100.0,
 )
 
 
@@ -124,6 +137,30 @@ def contact_spheres(flat_model, foot_bodies):
             r, length = size[0], size[1]
             for sz in (-1.0, 1.0):
                 out.append((b, (pos[0], pos[1], pos[2] + sz * max(0.5 * length - r, 0.0)), r))
+    return out
+
+
+def self_capsules(flat_model, foot_bodies):
+    """Self-collision capsules [(body, a, b, radius)] in link coordinates, per leg the shank then the foot (URDF <collision>,
+    resources/T1/T1_locomotion.xml:71,80,104,113).  Shank (the link two above the foot): the capsule inscribed in its z-axis cylinder, i.e. the
+    segment between the centres of the two end spheres that also meet the terrain.  Foot box (length L >= width W >= height H, L along x): radius
+    W / 2 (the box's half width, so feet side by side touch where the boxes do), segment of half length L / 2 - H about the box centre: the
+    round ends start one sole thickness inside the box ends and overhang them by W / 2 - H on the centre line (2 cm for the T1)."""
+    out = []
+    for fb in foot_bodies:
+        shank = int(flat_model.parent[int(flat_model.parent[fb])])
+        cyl = [sh for sh in flat_model.shapes if int(sh["body"]) == shank and sh["type"] == "cylinder"]
+        box = [sh for sh in flat_model.shapes if int(sh["body"]) == fb and sh["type"] == "box"]
+        if len(cyl) != 1 or len(box) != 1:
+            raise ValueError("self-collision capsules: expected one cylinder on each shank and one box on each foot")
+        pos, (r, length) = [float(v) for v in cyl[0]["pos"]], [float(v) for v in cyl[0]["size"]]
+        h = max(0.5 * length - r, 0.0)
+        out.append((shank, (pos[0], pos[1], pos[2] - h), (pos[0], pos[1], pos[2] + h), r))
+        pos, (lx, ly, lz) = [float(v) for v in box[0]["pos"]], [float(v) for v in box[0]["size"]]
+        if not (lx >= ly >= lz):
+            raise ValueError("self-collision capsules: the foot box must be longest along x and thinnest along z")
+        h = max(0.5 * lx - lz, 0.0)
+        out.append((fb, (pos[0] - h, pos[1], pos[2]), (pos[0] + h, pos[1], pos[2]), 0.5 * ly))
     return out
 
 
@@ -168,6 +205,14 @@ class DynRef:
             m.sph_r[k] = r
             for a in range(3):
                 m.sph_pos[k][a] = c[a]
+        caps = self_capsules(flat_model, [m.foot_body[0], m.foot_body[1]])
+        m.n_cap = len(caps)
+        for k, (b, a, bb, r) in enumerate(caps):
+            m.cap_body[k] = b
+            m.cap_r[k] = r
+            for ax in range(3):
+                m.cap_a[k][ax] = a[ax]
+                m.cap_b[k][ax] = bb[ax]
         self.model = m
         ph = dict(DEFAULT_PHYS)
         ph.update(phys or {})
@@ -179,6 +224,9 @@ class DynRef:
             setattr(p, k, float(ph[k]))
         p.clamp_qd = int(ph["clamp_qd"])
         p.body_gate_height = float(ph["body_gate_height"])
+        for k in ("self_k", "self_d", "self_mu", "self_visc"):
+            setattr(p, k, float(ph[k]))
+        p.self_collisions = int(ph["self_collisions"])
         self.phys = p
         self.set_terrain(terrain)
 
@@ -228,6 +276,19 @@ class DynRef:
 
     def terrain_height(self, x, y):
         return float(self._l.ref_terrain_height(C.byref(self.terrain), float(x), float(y)))
+
+    def segment_closest(self, a1, b1, a2, b2):
+        """(s, t) of the regularised closest points of two segments (the self-collision narrow phase)."""
+        seg = self._in(np.concatenate([a1, b1, a2, b2]))
+        st = self._out(2)
+        self._l.ref_segment_closest(_p(seg), _p(st))
+        return float(st[0]), float(st[1])
+
+    def self_contact_forces(self, root, q, qd):
+        """World-frame forces [13,3] of the leg-against-leg contacts alone in the given state."""
+        out = self._out(NB, 3)
+        self._l.ref_self_contact_forces(C.byref(self.model), C.byref(self.phys), _p(self._in(root)), _p(self._in(q)), _p(self._in(qd)), _p(out))
+        return self._wide(out)
 
     def forward(self, root, q, qd, tau, base_wrench=None, mass_scale=None, com_off=None, foot_mat=None, want_body_acc=False):
         i = self._in

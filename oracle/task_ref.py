@@ -555,7 +555,7 @@ class T1Ref:
         terms = reward_terms(s, rw, self.dt, self.limits, self.terrain)
         rew, scaled = total_reward(terms, self.scales, rw["only_positive_rewards"])
         derived = {"feet_pos": feet_pos, "feet_roll": roll, "feet_yaw": yaw, "feet_contact": contact, "torques": tmean, "base_lin_vel": base_lin,
-                   "base_ang_vel": base_ang, "projected_gravity": proj_g, "contact": cf[:, [6, 12], :]}
+                   "base_ang_vel": base_ang, "projected_gravity": proj_g, "contact": cf[:, [6, 12], :], "contact_all": cf}
         # ---- reset / teleport / resample / observe (t1.py:485-490)
         obs, priv, feet_store = self._reset_and_observe(step, 0, reset, base_lin, base_ang, proj_g, feet_pos, True)
         # ---- history (t1.py:492-495)

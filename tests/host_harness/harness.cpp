@@ -7,13 +7,24 @@ using namespace bg;
 
 extern "C" {
 
-struct hh_cfg { float dt, g[3], contact_k, contact_d, contact_ramp, friction_visc, limit_k, limit_d, terrain_mu, terrain_restitution; int clamp_qd; float body_gate; };
+struct hh_cfg { float dt, g[3], contact_k, contact_d, contact_ramp, friction_visc, limit_k, limit_d, terrain_mu, terrain_restitution; int clamp_qd; float body_gate;
+                int self_on; float self_k, self_d, self_mu, self_visc; };
+
+// Lane-pair exchange for a host that runs the two legs one after the other: every swap() records the value it is given and returns what the
+// partner recorded at the same position in the PREVIOUS pass (0 if there is none).  The caller repeats the two-leg pass until the tapes no
+// longer change (the exchange pattern depends on exchanged values only through the symmetric gate of the leg-against-leg contacts: 3 passes).
+struct TapeSwap {
+    float mine[128]; int n = 0;
+    const float* theirs = nullptr; int n_theirs = 0;
+    float swap(float v) { const int k = n++; if (k < 128) mine[k] = v; return (theirs && k < n_theirs) ? theirs[k] : 0.f; }
+};
 
 static void setup(const hh_cfg* c, Phys& ph, ContactCfg& cc) {
     ph.dt = c->dt; ph.g = v3(c->g[0], c->g[1], c->g[2]); ph.contact_ramp = c->contact_ramp; ph.friction_visc = c->friction_visc;
     ph.limit_k = c->limit_k; ph.limit_d = c->limit_d; ph.clamp_qd = c->clamp_qd;
     ph.body_gate = c->body_gate; ph.body_kn = c->contact_k; ph.body_dn = c->contact_d * (1.0f - 0.5f * c->terrain_restitution); ph.body_mu = 0.5f * (1.0f + c->terrain_mu);
     cc.k = c->contact_k; cc.d = c->contact_d; cc.terrain_mu = c->terrain_mu; cc.terrain_restitution = c->terrain_restitution;
+    ph.self_on = c->self_on; ph.self_k = c->self_k; ph.self_d = c->self_d; ph.self_mu = c->self_mu; ph.self_visc = c->self_visc;
 }
 
 // one env; arrays are in the SoA layout with n = 1.  root: pos3 quat4 lin3 ang3.  step != 0 integrates in place.
@@ -27,16 +38,22 @@ int hh_forward(const ModelDev* m, const hh_cfg* c, const TerrainDev* tr, const f
     bs.vlin = v3(root[7], root[8], root[9]); bs.vang = v3(root[10], root[11], root[12]);
     LinkConst bk = load_base_link(*m, 0, 1, mass_scale, com_off);
     LegParams lp[2]; LegState ls[2]; SubstepCtx cx[2]; BaseContribution bc[2]; BodyContactOut bo[2];
-    for (int l = 0; l < 2; l++) {
-        load_leg_params(*m, cc, l, 0, 1, mass_scale, com_off, foot_mat, lp[l]);
-        for (int i = 0; i < 6; i++) { ls[l].q[i] = q[6 * l + i]; ls[l].qd[i] = qd[6 * l + i]; }
-        if (body_contacts_active(ph, *tr, *m, bs.pos)) bc[l] = substep_pre<true>(ph, *tr, *m, l, lp[l], ls[l], tau + 6 * l, bs, cx[l], (const SV*)nullptr, &bo[l]);
-        else bc[l] = substep_pre<false>(ph, *tr, *m, l, lp[l], ls[l], tau + 6 * l, bs, cx[l], (const SV*)nullptr, &bo[l]);
+    TapeSwap tape[2][2];  // [pass parity][leg]
+    for (int pass = 0; pass < 4; pass++) {
+        const int cur = pass & 1, prev = cur ^ 1;
+        for (int l = 0; l < 2; l++) {
+            load_leg_params(*m, cc, l, 0, 1, mass_scale, com_off, foot_mat, lp[l]);
+            for (int i = 0; i < 6; i++) { ls[l].q[i] = q[6 * l + i]; ls[l].qd[i] = qd[6 * l + i]; }
+            TapeSwap& x = tape[cur][l];
+            x.n = 0;
+            x.theirs = pass ? tape[prev][l ^ 1].mine : nullptr; x.n_theirs = pass ? tape[prev][l ^ 1].n : 0;
+            if (body_contacts_active(ph, *tr, *m, bs.pos)) bc[l] = substep_pre<true>(ph, *tr, *m, l, lp[l], ls[l], tau + 6 * l, bs, cx[l], x, (const SV*)nullptr, &bo[l]);
+            else bc[l] = substep_pre<false>(ph, *tr, *m, l, lp[l], ls[l], tau + 6 * l, bs, cx[l], x, (const SV*)nullptr, &bo[l]);
+        }
     }
     if (body_cf) {
         memset(body_cf, 0, sizeof(float) * 39);
         for (int l = 0; l < 2; l++) {
-            if (!bo[l].active) continue;
             for (int a = 0; a < 3; a++) body_cf[a] += bo[l].trunk.e[a];
             for (int i = 0; i < 6; i++) for (int a = 0; a < 3; a++) body_cf[3 * (1 + 6 * l + i) + a] = bo[l].link[i].e[a];
         }

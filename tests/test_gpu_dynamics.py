@@ -12,7 +12,10 @@ pytestmark = pytest.mark.gpu
 
 def _states(rng, m, n, contact):
     """contact: False = airborne, True = standing height (sole contacts), "low" = trunk 0.15-0.5 m above the ground in any orientation (the
-    trunk box and the hip-yaw / shank cylinders touch as well)."""
+    trunk box and the hip-yaw / shank cylinders touch as well), "crossed" = airborne with the hip rolls drawn inwards (leg against leg)."""
+    crossed = contact == "crossed"
+    if crossed:
+        contact = False
     root = np.zeros((n, 13))
     root[:, 2] = (rng.uniform(0.15, 0.5, n) if contact == "low" else rng.uniform(0.55, 0.72, n)) if contact else 5.0
     root[:, :2] = rng.uniform(-1, 1, (n, 2))
@@ -24,6 +27,9 @@ def _states(rng, m, n, contact):
         q = np.tile(np.array([-0.2, 0, 0, 0.4, -0.25, 0] * 2), (n, 1)) + rng.normal(size=(n, 12)) * 0.1
     else:
         q = rng.uniform(m.dof_lower - 0.05, m.dof_upper + 0.05, (n, 12))
+    if crossed:
+        q[:, 1], q[:, 7] = rng.uniform(-0.3, 0.0, n), rng.uniform(0.0, 0.3, n)
+        q[:, [0, 6]], q[:, [3, 9]] = rng.uniform(-0.6, 0.2, (n, 2)), rng.uniform(0.0, 0.8, (n, 2))
     qd = rng.normal(size=(n, 12))
     tau = rng.uniform(-m.dof_effort, m.dof_effort, (n, 12))
     w = rng.normal(size=(n, 6)) * 10
@@ -31,7 +37,7 @@ def _states(rng, m, n, contact):
 
 
 @pytest.mark.parametrize("terrain,contact,tol", [("plane", False, 1e-4), ("plane", True, 5e-4), ("trimesh", True, 5e-4), ("plane", "low", 1e-3),
-                                                 ("trimesh", "low", 1e-3)])
+                                                 ("trimesh", "low", 1e-3), ("plane", "crossed", 5e-4)])
 def test_forward_dynamics_matches_oracle(flat_model, terrain, contact, tol):
     from booster_gym_amd.envs import T1
     from booster_gym_amd.utils.config import load_cfg
@@ -61,7 +67,8 @@ def test_forward_dynamics_matches_oracle(flat_model, terrain, contact, tol):
         qa, cfr = ref.forward(r32, q[e].astype(np.float32), qd[e].astype(np.float32), tau[e].astype(np.float32), base_wrench=w[e].astype(np.float32),
                               mass_scale=env._mass_scale[e].astype(np.float32), com_off=env._com_off[e].astype(np.float32),
                               foot_mat=env._foot_mat[e].astype(np.float32).reshape(6))
-        worst = max(worst, np.abs(qacc[e] - qa).max() / max(1.0, np.abs(qa).max()))
+        # any active contact is stiff (also a chance leg-against-leg one among the random airborne poses): 5e-4 at least
+        worst = max(worst, np.abs(qacc[e] - qa).max() / max(1.0, np.abs(qa).max()) * (tol / max(tol, 5e-4) if np.abs(cfr).max() > 0 else 1.0))
         if np.abs(cfr).max() > 0:
             ncontact += 1
             assert np.abs(cf[e] - cfr[[6, 12]]).max() <= 2e-3 * max(1.0, np.abs(cfr).max())

@@ -226,3 +226,69 @@ def test_isaac_layout_state_views_through_the_abi():
     _lib.check(lib.bg_model_get(env._model, C.byref(d)))
     assert d.num_bodies == 13 and d.num_dofs == 12 and abs(d.mass[0] - 19.4304) < 1e-3 and list(d.joint_axis)[1:7] == [2, 1, 3, 2, 2, 1]
     assert lib.bg_env_step_count(env._env) == 25
+
+
+def _leg_capsule_overlap(env):
+    """Deepest overlap [m] between the self-collision capsules of the left and of the right leg, per env, from the env's state alone: forward
+    kinematics in torch, 17 sample points along every capsule axis (independent of the kernels and of the oracle)."""
+    m, dev = env.model, env.device
+    root, q = env.root_states, env.dof_pos
+    x, y, z, w = root[:, 3:7].unbind(-1)
+    R0 = torch.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w), 2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w),
+                      2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], dim=-1).view(-1, 3, 3)
+    pos = torch.tensor(m.body_pos, dtype=torch.float32, device=dev)
+
+    def rot(ax, a):
+        c, s, o, zz = torch.cos(a), torch.sin(a), torch.ones_like(a), torch.zeros_like(a)
+        rows = {1: [o, zz, zz, zz, c, -s, zz, s, c], 2: [c, zz, s, zz, o, zz, -s, zz, c], 3: [c, -s, zz, s, c, zz, zz, zz, o]}[ax]
+        return torch.stack(rows, dim=-1).view(-1, 3, 3)
+
+    t = torch.linspace(0.0, 1.0, 17, device=dev).view(1, -1, 1)
+    pts, rad = [[], []], [[], []]
+    caps = m.self_collision_capsules([6, 12])
+    for leg in range(2):
+        R, p = R0, root[:, 0:3]
+        for i in range(6):
+            b = 1 + leg * 6 + i
+            p = p + (R @ pos[b].view(1, 3, 1)).squeeze(-1)
+            R = R @ rot(int(m.joint_axis[b]), q[:, leg * 6 + i])
+            for body, a, bb, r in caps[leg]:
+                if body == b:
+                    A = p + (R @ torch.tensor(a, dtype=torch.float32, device=dev).view(1, 3, 1)).squeeze(-1)
+                    B = p + (R @ torch.tensor(bb, dtype=torch.float32, device=dev).view(1, 3, 1)).squeeze(-1)
+                    pts[leg].append(A[:, None, :] + t * (B - A)[:, None, :]); rad[leg].append(r)
+    depth = torch.full((root.shape[0],), -1.0, device=dev)
+    for i in range(2):
+        for j in range(2):
+            d = torch.cdist(pts[0][i], pts[1][j]).flatten(1).min(dim=1).values
+            depth = torch.maximum(depth, rad[0][i] + rad[1][j] - d)
+    return depth
+
+
+def test_self_collision_blocks_leg_interpenetration_at_scale():
+    """Size-independent property of the leg-against-leg contacts (reference: self-collision on, envs/T1.yaml:69): 16,384 standing robots are
+    told to swing both legs inwards through each other (hip-roll targets far across the mid-plane) for half a second.  With the contacts on, the
+    capsules of the two legs end up touching, not overlapping; with asset.self_collisions = 1 (filtered out, as in Isaac Gym) they pass
+    through each other.  Depths are measured from the state by an independent torch forward kinematics."""
+    n = 16384
+    res = {}
+    for mask in (0, 1):
+        env = _env(n, "plane", {"asset.self_collisions": mask, "rewards.terminate_height": -1.0, "rewards.terminate_vel": 1.0e9, "commands.still_proportion": 1.0})
+        env.reset()
+        act = torch.zeros(n, 12, device=env.device)
+        for _ in range(15):
+            env.step(act)
+        act[:, 1], act[:, 7] = -0.45, 0.45   # left hip roll negative = inwards
+        act[:, 5], act[:, 11] = 0.45, -0.45
+        worst = torch.zeros(n, device=env.device)
+        for s in range(25):
+            env.step(act)
+            if s >= 5:
+                worst = torch.maximum(worst, _leg_capsule_overlap(env))
+        assert torch.isfinite(env.root_states).all() and env.episode_stats(reset=False)[-1].item() == 0
+        res[mask] = worst.cpu().numpy()
+        del env
+    on, off = res[0], res[1]
+    print("leg overlap [m] with self-collision on: median %.4f p99 %.4f max %.4f; off: median %.4f" % (np.median(on), np.percentile(on, 99), on.max(), np.median(off)))
+    assert np.median(off) > 0.04, np.median(off)           # the command really drives the legs through each other
+    assert np.percentile(on, 99) < 0.012 and on.max() < 0.03, (np.percentile(on, 99), on.max())

@@ -28,8 +28,11 @@ def _make(terrain, n, overrides=None):
     if terrain != "plane":
         t = env.terrain
         tdict = dict(height_field_raw=t.height_field_raw, hscale=t.horizontal_scale, vscale=t.vertical_scale, border_px=t.border_pixels)
+    ct = cfg.get("contact", {}) or {}
     dyn = DynRef(env.model, feet_edge_pos=cfg["asset"]["feet_edge_pos"], terrain=tdict,
-                 phys={"terrain_mu": 0.5 * (cfg["terrain"]["static_friction"] + cfg["terrain"]["dynamic_friction"]), "terrain_restitution": cfg["terrain"]["restitution"]})
+                 phys={"terrain_mu": 0.5 * (cfg["terrain"]["static_friction"] + cfg["terrain"]["dynamic_friction"]), "terrain_restitution": cfg["terrain"]["restitution"],
+                       "self_collisions": int(int(cfg["asset"].get("self_collisions", 0)) == 0), "self_k": ct.get("self_stiffness", 4.0e4),
+                       "self_d": ct.get("self_damping", 150.0), "self_mu": ct.get("self_friction", 1.0), "self_visc": ct.get("self_friction_viscosity", 100.0)})
     f32 = lambda a: np.asarray(a, dtype=np.float32).astype(np.float64)
     params = dict(kp=f32(env._kp), kd=f32(env._kd), fric=f32(env._fric), mass_scale=f32(env._mass_scale), com_off=f32(env._com_off),
                   foot_mat=f32(env._foot_mat), bms=f32(env._bms), origins=f32(env._origins))
@@ -44,7 +47,7 @@ def _twin32(cfg, env, ref):
     from oracle.task_ref import T1Ref
 
     d = ref.dyn
-    phys = {k: getattr(d.phys, k) for k in ("terrain_mu", "terrain_restitution")}
+    phys = {k: getattr(d.phys, k) for k in ("terrain_mu", "terrain_restitution", "self_collisions", "self_k", "self_d", "self_mu", "self_visc")}
     dyn32 = DynRef(env.model, feet_edge_pos=cfg["asset"]["feet_edge_pos"], terrain=ref.terrain, phys=phys, real="f32")
     return T1Ref(cfg, env.model, dyn32, ref.p, terrain=ref.terrain, seed=cfg["basic"]["seed"], rank=0)
 
@@ -241,6 +244,83 @@ def test_body_contacts_collision_reward_and_contact_termination_match_oracle():
     assert coll_seen > n // 4 and term_seen > n // 10, (coll_seen, term_seen)  # the shapes were exercised
     assert flags_bad <= n * 4 * 2 // 100, flags_bad
     assert env.episode_stats(reset=False).cpu().numpy()[-1] == 0
+
+
+def _cross_legs(env, n, rng):
+    """Joint positions with the hip rolls turned inwards on both legs (ankle rolls compensating).  First half of the envs by 0.08 .. 0.16 rad:
+    the feet between just apart and a few centimetres inside each other; second half by 0.22 .. 0.32 rad: legs crossed so far that the shanks
+    meet as well.  Returns the action that asks the PD actuators for 0.12 rad MORE on each side, so that the legs keep pressing together."""
+    q = env.dof_pos.cpu().numpy().astype(np.float64)
+    roll = np.where(np.arange(n) < n // 2, rng.uniform(0.08, 0.16, n), rng.uniform(0.22, 0.32, n))
+    yaw = rng.uniform(-0.2, 0.2, (n, 2))
+    q[:, 1], q[:, 7] = -roll, roll
+    q[:, 5], q[:, 11] = roll, -roll
+    q[:, 2], q[:, 8] = yaw[:, 0], yaw[:, 1]
+    env.set_field("dof_pos", torch.tensor(q, dtype=torch.float32))
+    env.set_field("last_dof_targets", torch.tensor(q, dtype=torch.float32))
+    act = np.zeros((n, 12), dtype=np.float32)
+    act[:, 1], act[:, 7], act[:, 5], act[:, 11] = -(roll + 0.12), roll + 0.12, roll, -roll
+    return act
+
+
+@pytest.mark.parametrize("terrain", ["plane", "trimesh"])
+def test_self_collision_step_matches_oracle(terrain):
+    """Leg against leg (reference: PhysX self-collision enabled, envs/T1.yaml:69, envs/t1.py:128).  Standing robots get their legs crossed:
+    hip rolls inwards until feet / shanks of the two legs overlap, and the actuators keep pulling them together.  One env step at a time from
+    identical inputs against the float64 oracle, walking tolerances, every env outside them explained; the shank-against-shank contacts show
+    up in the `collision` reward term (Shank is a penalised body, t1.py:627-629) exactly as in the oracle."""
+    n = 96
+    cfg, env, ref = _make(terrain, n)
+    assert env._cfg_c.self_collisions == 1 and ref.dyn.phys.self_collisions == 1
+    env.reset(); ref.reset()
+    rng = np.random.default_rng(23)
+    _settle(env, n, rng)
+    act0 = _cross_legs(env, n, rng)
+    env.common_step_counter = 7
+    sp = StepParity(cfg, env, ref, max_explained_frac=0.03)
+    contact_seen, coll_seen, coll_diff, flags_bad = 0, 0, 0, 0
+    for s in range(5):
+        sp.begin()
+        act = (act0 + rng.uniform(-0.1, 0.1, (n, 12))).astype(np.float32)
+        obs, rew, done, extras = env.step(torch.tensor(act, device=env.device))
+        out = ref.step(act.astype(np.float64))
+        keep = sp.check(s, act, obs, rew, done, extras, out)
+        flags_bad += int((~keep).sum())
+        for e in range(n):  # leg-against-leg forces in the state the step ended in
+            contact_seen += int(np.abs(ref.dyn.self_contact_forces(ref.root[e], ref.q[e], ref.qd[e])).max() > 1.0)
+        coll_gpu, coll_ref = extras["rew_terms"]["collision"].cpu().numpy(), out[5]["collision"]
+        coll_seen += int((coll_ref < 0).sum())
+        coll_diff += int((np.abs(coll_gpu - coll_ref)[keep] > 1e-6).sum())
+    print("self-collision step parity:", sp.finish(), sp.log, "collision counts differing:", coll_diff, "flags differing:", flags_bad)
+    assert contact_seen > n and coll_seen > 10, (contact_seen, coll_seen)  # leg-against-leg forces at the end of > 20 % of the env-steps; shank contacts penalised
+    assert flags_bad <= 4, flags_bad
+    assert env.episode_stats(reset=False).cpu().numpy()[-1] == 0
+
+
+def test_self_collisions_off_lets_the_legs_pass_through_each_other():
+    """asset.self_collisions != 0 (Isaac Gym's filter mask: the actor's shapes do not collide with each other) switches the contacts off on both
+    sides: same crossed-leg start, still parity with the oracle, and the legs end up deeper inside each other than with the contacts on."""
+    n = 64
+    depth = {}
+    for mask in (0, 1):
+        cfg, env, ref = _make("plane", n, {"asset.self_collisions": mask})
+        assert env._cfg_c.self_collisions == 1 - mask
+        env.reset(); ref.reset()
+        rng = np.random.default_rng(29)
+        _settle(env, n, rng)
+        act0 = _cross_legs(env, n, rng)
+        env.common_step_counter = 7
+        sp = StepParity(cfg, env, ref, max_explained_frac=0.03)
+        for s in range(4):
+            sp.begin()
+            obs, rew, done, extras = env.step(torch.tensor(act0, device=env.device))
+            out = ref.step(act0.astype(np.float64))
+            sp.check(s, act0, obs, rew, done, extras, out)
+        sp.finish()
+        fp = env.get_field("feet_pos").cpu().numpy().reshape(n, 2, 3)
+        depth[mask] = 0.1 - np.linalg.norm(fp[:, 0, :2] - fp[:, 1, :2], axis=1)  # overlap of the two foot capsules (radius 0.05) in plan view
+    assert np.median(depth[1]) > np.median(depth[0]) + 0.02, (np.median(depth[0]), np.median(depth[1]))
+    assert np.percentile(depth[0], 90) < 0.03, np.percentile(depth[0], 90)
 
 
 FP16_FIELDS = ["dof_pos", "dof_vel", "last_dof_targets", "actions", "last_actions", "last_dof_vel", "last_root_vel", "commands", "gait_frequency",

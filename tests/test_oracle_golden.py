@@ -201,8 +201,17 @@ def test_urdf_loader_on_reference_asset_if_present(flat_model):
     assert np.allclose(m.mass, flat_model.mass) and np.allclose(m.inertia, flat_model.inertia) and np.allclose(m.com, flat_model.com)
 
 
-def test_aba_equals_inverse_dynamics(dyn, flat_model):
+@pytest.fixture(scope="module")
+def dyn_smooth(flat_model):
+    """The smooth dynamics alone: leg-against-leg contacts off (random joint angles cross the legs)."""
+    from oracle.dyn_ref import DynRef
+
+    return DynRef(flat_model, phys={"self_collisions": 0})
+
+
+def test_aba_equals_inverse_dynamics(dyn_smooth, flat_model):
     """ABA forward dynamics satisfies the independent RNEA inverse dynamics: residual < 1e-9 (double), with randomised inertias."""
+    dyn = dyn_smooth
     m, rng, worst = flat_model, np.random.default_rng(0), 0.0
     for _ in range(500):
         root = np.zeros(13); root[2] = 5.0
@@ -216,6 +225,87 @@ def test_aba_equals_inverse_dynamics(dyn, flat_model):
         res = dyn.inverse(root, q, qd, qacc, mass_scale=ms, com_off=co)
         worst = max(worst, np.abs(res - np.concatenate([w[3:], w[:3], tau])).max())
     assert worst < 1e-9
+
+
+def _airborne_state(m, rng):
+    root = np.zeros(13); root[2] = 5.0
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax); ang = rng.uniform(0, 1.0)
+    root[3:6], root[6] = ax * np.sin(ang / 2), np.cos(ang / 2)
+    root[7:13] = rng.normal(size=6)
+    return root, rng.uniform(m.dof_lower, m.dof_upper), rng.normal(size=12), rng.uniform(-m.dof_effort, m.dof_effort)
+
+
+def test_self_collision_forces_are_internal(dyn, dyn_smooth, flat_model):
+    """Leg-against-leg contacts (reference: self-collision enabled, envs/T1.yaml:69, envs/t1.py:128).  They are INTERNAL forces: with them on,
+    the independent RNEA still returns the applied base wrench as the net force on the system (linear and angular momentum conserved), the
+    contact rows of the two legs cancel, and only the joint rows of the residual change.  Hip rolls drawn inwards cross the legs in most samples."""
+    m, rng = flat_model, np.random.default_rng(5)
+    active, worst_base, worst_sum = 0, 0.0, 0.0
+    for _ in range(300):
+        root, q, qd, tau = _airborne_state(m, rng)
+        q[[1, 7]] = rng.uniform(-0.3, 0.0), rng.uniform(0.0, 0.3)  # hip rolls inwards
+        q[[0, 6]] = rng.uniform(-0.6, 0.2, 2)
+        q[[3, 9]] = rng.uniform(0.0, 0.8, 2)
+        w = rng.normal(size=6) * 10
+        qacc, cf = dyn.forward(root, q, qd, tau, base_wrench=w)
+        qacc0, cf0 = dyn_smooth.forward(root, q, qd, tau, base_wrench=w)
+        res = dyn.inverse(root, q, qd, qacc)
+        assert np.abs(cf0).max() == 0.0
+        if np.abs(cf).max() > 0:
+            active += 1
+            assert np.abs(res[6:] - tau).max() > 1e-6 and np.abs(qacc - qacc0).max() > 1e-6
+            assert np.abs(cf[[0, 1, 2, 3, 5, 7, 8, 9, 11]]).max() == 0.0  # only the shanks (4, 10) and the feet (6, 12) carry capsules
+        else:
+            assert np.abs(qacc - qacc0).max() == 0.0
+        worst_base = max(worst_base, np.abs(res[:6] - np.concatenate([w[3:], w[:3]])).max() / max(1.0, np.abs(cf).max()))
+        worst_sum = max(worst_sum, np.abs(cf.sum(axis=0)).max() / max(1.0, np.abs(cf).max()))
+    assert active > 100, active
+    assert worst_base < 1e-9 and worst_sum < 1e-12, (worst_base, worst_sum)
+
+
+def test_self_collision_pushes_crossed_feet_apart(dyn, dyn_smooth, flat_model):
+    """Feet pushed into each other sideways (hip roll inwards on both legs, zero velocities): the contact accelerates the hip-roll joints
+    outwards, the force grows with the penetration and vanishes once the capsules are clear of each other."""
+    m = flat_model
+    root = np.zeros(13); root[2] = 5.0; root[6] = 1.0
+    last = None
+    for roll in (0.0, 0.14, 0.16, 0.18):
+        q = np.array([-0.2, -roll, 0, 0.4, -0.25, roll, -0.2, roll, 0, 0.4, -0.25, -roll])  # left hip roll negative = inwards
+        qacc, cf = dyn.forward(root, q, np.zeros(12), np.zeros(12))
+        qacc0, _ = dyn_smooth.forward(root, q, np.zeros(12), np.zeros(12))
+        f = cf[6, 1]  # lateral force on the left foot, trunk frame = world frame here
+        if roll == 0.0:
+            assert np.abs(cf).max() == 0.0
+        else:
+            assert f > 0 and cf[12, 1] < 0 and abs(cf[6, 1] + cf[12, 1] + cf[4, 1] + cf[10, 1]) < 1e-9
+            assert qacc[6 + 1] - qacc0[6 + 1] > 0 and qacc[6 + 7] - qacc0[6 + 7] < 0  # left hip roll pushed positive (outwards), right negative
+            if last is not None:
+                assert f > last
+            last = f
+
+
+def test_self_collision_closest_points_regularised(dyn):
+    """The narrow phase: (1) on random segment pairs the regularised closest points give the true segment distance (brute force on a grid) to
+    second order; (2) for PARALLEL segments, where the plain problem has an interval of minimisers, the answer is unique, sits in the middle
+    of the overlap and moves continuously under a rounding-size rotation of one segment."""
+    rng = np.random.default_rng(9)
+    g = np.linspace(0.0, 1.0, 201)
+    for _ in range(200):
+        a1, a2 = rng.normal(size=3) * 0.1, rng.normal(size=3) * 0.1
+        b1, b2 = a1 + rng.normal(size=3) * 0.1, a2 + rng.normal(size=3) * 0.1
+        s, t = dyn.segment_closest(a1, b1, a2, b2)
+        d = np.linalg.norm(a1 + s * (b1 - a1) - a2 - t * (b2 - a2))
+        P1, P2 = a1 + g[:, None] * (b1 - a1), a2 + g[:, None] * (b2 - a2)
+        best = np.linalg.norm(P1[:, None, :] - P2[None, :, :], axis=2).min()
+        assert d < best + 5e-3 * max(np.linalg.norm(b1 - a1), np.linalg.norm(b2 - a2)) and d > best - 1e-3
+    a1, b1 = np.array([0.0, 0.05, 0.0]), np.array([0.2, 0.05, 0.0])
+    a2, b2 = np.array([0.1, -0.05, 0.0]), np.array([0.3, -0.05, 0.0])
+    s, t = dyn.segment_closest(a1, b1, a2, b2)
+    assert abs((a1 + s * (b1 - a1))[0] - 0.15) < 5e-4 and abs((a2 + t * (b2 - a2))[0] - 0.15) < 5e-4  # middle of the overlap [0.1, 0.2]
+    for eps, tol in ((1e-7, 1e-4), (-1e-7, 1e-4), (1e-5, 5e-3)):  # 1e-7: fp32 rounding size -> the contact point moves by < 20 micrometres
+        b2e = b2 + np.array([0.0, eps, eps])
+        s2, t2 = dyn.segment_closest(a1, b1, a2, b2e)
+        assert abs(s2 - s) < tol and abs(t2 - t) < tol
 
 
 def test_body_wrench_semantics(dyn, flat_model):
