@@ -185,7 +185,11 @@ def main():
     from booster_gym_amd.utils.model import MLPTrainer as _MT
     split_mode = _MT.SPLIT  # 0 unless the caller exported BG_GEMM_SPLIT: then the headline loop itself runs in split mode, and the line says so
     cfg["runner"]["save_interval"] = 10 ** 9  # no checkpoint inside the timed region (the reference saves every 100 iterations)
-    runner.begin_training(Recorder(cfg, root=tempfile.mkdtemp(prefix="bench_logs_"), rank=rank))
+    import atexit
+    import shutil
+    log_root = tempfile.mkdtemp(prefix="bench_logs_")
+    atexit.register(shutil.rmtree, log_root, ignore_errors=True)  # every rank and every A/B loop run would otherwise leave its directory in /tmp
+    runner.begin_training(Recorder(cfg, root=log_root, rank=rank))
 
     def barrier():
         torch.cuda.synchronize()

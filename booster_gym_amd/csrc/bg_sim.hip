@@ -167,17 +167,32 @@ __global__ __launch_bounds__(RS_BLOCK) void resample_count_kernel(EnvDev E, int*
     __syncthreads();
     if (threadIdx.x == 0) counts[blockIdx.x] = s_cnt;
 }
+// counts [nblocks] -> exclusive prefix offsets in place, total in counts[nblocks]; one workgroup (256 threads, each a contiguous chunk), so that
+// resample_apply_kernel reads two numbers per block instead of every block summing all counts (O(nblocks^2) loads at 1 M envs)
+__global__ __launch_bounds__(RS_BLOCK) void resample_offsets_kernel(int* __restrict__ counts, int nblocks) {
+    __shared__ int s_part[RS_BLOCK];
+    const int per = (nblocks + RS_BLOCK - 1) / RS_BLOCK, b0 = threadIdx.x * per, b1 = min(nblocks, b0 + per);
+    int sum = 0;
+    for (int b = b0; b < b1; b++) sum += counts[b];
+    s_part[threadIdx.x] = sum;
+    __syncthreads();
+    for (int d = 1; d < RS_BLOCK; d <<= 1) {
+        const int v = (int)threadIdx.x >= d ? s_part[threadIdx.x - d] : 0;
+        __syncthreads();
+        s_part[threadIdx.x] += v;
+        __syncthreads();
+    }
+    int run = s_part[threadIdx.x] - sum;
+    for (int b = b0; b < b1; b++) { const int c = counts[b]; counts[b] = run; run += c; }
+    if (threadIdx.x == RS_BLOCK - 1) counts[nblocks] = s_part[RS_BLOCK - 1];
+}
 __global__ __launch_bounds__(RS_BLOCK) void resample_apply_kernel(EnvDev E, const int* __restrict__ counts, int nblocks, uint32_t step, int mode, float* __restrict__ obs) {
     __shared__ int s_scan[RS_BLOCK];
     __shared__ int s_off, s_total;
     const bg_env_cfg& C = E.cfg;
     const int n = E.n, e = blockIdx.x * RS_BLOCK + threadIdx.x;
     const int flag = e < n ? E.i[(size_t)I_RESAMPLED * n + e] : 0;
-    if (threadIdx.x == 0) {
-        int off = 0, tot = 0;
-        for (int b = 0; b < nblocks; b++) { const int c = counts[b]; if (b < (int)blockIdx.x) off += c; tot += c; }
-        s_off = off; s_total = tot;
-    }
+    if (threadIdx.x == 0) { s_off = counts[blockIdx.x]; s_total = counts[nblocks]; }  // exclusive offsets + total (resample_offsets_kernel)
     s_scan[threadIdx.x] = flag;
     __syncthreads();
     for (int d = 1; d < RS_BLOCK; d <<= 1) {  // inclusive scan of the flags
@@ -599,7 +614,7 @@ static int env_create_fill(bg_env* e, const bg_env_cfg* cfg, const bg_model* mod
     HIP_OK(hipMalloc(&e->curr_read, sizeof(float) * e->curr_cells));
     if (cfg->exact_still_count || (cfg->curriculum && cfg->same_step_curriculum)) {
         if (cfg->state_fp16) return fail(-4, "bg_env_create: exact_still_count / same_step_curriculum are not available with state_fp16");
-        HIP_OK(hipMalloc(&e->rs_counts, sizeof(int) * ((n + 255) / 256)));
+        HIP_OK(hipMalloc(&e->rs_counts, sizeof(int) * ((n + 255) / 256 + 1)));
     }
     {   // t1.py:249-255: all mass on the centre cell
         std::vector<float> c0(e->curr_cells, 0.f);
@@ -765,6 +780,7 @@ static int launch_step(bg_env* e, const float* actions, int mode, const StepOut&
     if (e->rs_counts) {  // reference-exact resampling: the cross-env part of _resample_commands (see resample_apply_kernel)
         const int nb = (e->n + RS_BLOCK - 1) / RS_BLOCK;
         hipLaunchKernelGGL(resample_count_kernel, dim3(nb), dim3(RS_BLOCK), 0, st, env_dev(e), e->rs_counts);
+        hipLaunchKernelGGL(resample_offsets_kernel, dim3(1), dim3(RS_BLOCK), 0, st, e->rs_counts, nb);
         hipLaunchKernelGGL(resample_apply_kernel, dim3(nb), dim3(RS_BLOCK), 0, st, env_dev(e), (const int*)e->rs_counts, nb, cnt, mode, out.obs);
     }
     HIP_OK(hipGetLastError());

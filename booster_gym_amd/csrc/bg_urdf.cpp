@@ -102,7 +102,8 @@ struct XmlReader {
         }
         return o;
     }
-    std::unique_ptr<Xml> element() {
+    std::unique_ptr<Xml> element(int depth = 0) {
+        if (depth > 64) bad("elements nested deeper than 64");  // the recursion below is bounded on malformed / hostile input
         if (p >= s.size() || s[p] != '<') bad("'<' expected");
         p++;
         auto x = std::make_unique<Xml>();
@@ -134,7 +135,7 @@ struct XmlReader {
                 p++;
                 return x;
             }
-            x->kids.push_back(element());
+            x->kids.push_back(element(depth + 1));
         }
     }
     std::unique_ptr<Xml> document() { misc(); auto r = element(); return r; }
@@ -256,6 +257,8 @@ extern "C" int bg_model_load_urdf(const char* path, const bg_asset_options* opt,
                 j.has_limit = true;
                 j.lower = num(lim, "lower", 0); j.upper = num(lim, "upper", 0); j.effort = num(lim, "effort", 0); j.velocity = num(lim, "velocity", 0);
             }
+            if (is_child.count(j.child)) throw std::runtime_error("link " + j.child + " is the child of more than one joint (joint " + j.name + ")");
+            if (j.child == j.parent) throw std::runtime_error("joint " + j.name + " connects link " + j.child + " to itself");
             joints.push_back(j);
             is_child[j.child] = true;
         }
@@ -265,6 +268,16 @@ extern "C" int bg_model_load_urdf(const char* path, const bg_asset_options* opt,
 
         std::map<std::string, std::vector<Joint>> by_parent;
         for (const Joint& j : joints) by_parent[j.parent].push_back(j);
+        {   // every link hangs off the root: with one parent joint per link, a link that is not reached sits on a cycle of joints.  (This walk
+            // is iterative; the recursive folds below then run on a tree, their depth bounded by the number of links.)
+            std::vector<std::string> todo{roots[0]};
+            size_t seen = 0;
+            while (!todo.empty()) {
+                const std::string nm = todo.back(); todo.pop_back(); seen++;
+                if (by_parent.count(nm)) for (const Joint& j : by_parent[nm]) todo.push_back(j.child);
+            }
+            if (seen != links.size()) throw std::runtime_error(std::to_string(links.size() - seen) + " link(s) are not connected to the root link " + roots[0] + " (a cycle of joints)");
+        }
         if (opt->collapse_fixed_joints) {
             // fold leaves first so that chains of fixed joints accumulate correctly
             std::function<void(const std::string&)> fold = [&](const std::string& name) {

@@ -74,7 +74,7 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
 #pragma unroll
         for (int d = 0; d < D; d++) {
             const bool ok = kp + d < kp1;  // scalar
-            const size_t r = 2 * (size_t)(ok ? kp + d : kp1 - 1);
+            const size_t r = 2 * (size_t)(ok ? kp + d : (kp1 > 0 ? kp1 - 1 : 0));  // an empty run at the start of the rows (kp1 == 0) clamps to row 0, not to -1
             g[d] = *reinterpret_cast<const f32x4*>(Gb + r * Cout * 4 + gofb);
             a[d] = *reinterpret_cast<const avec*>(Ab + r * Cin * 4 + aofb);
             if (guard && !ok) g[d] = f32x4{0.f, 0.f, 0.f, 0.f};

@@ -37,7 +37,9 @@ def plan_wgrad_slices(shapes, rows, workgroups=256, share_rows=True):
     scale = 4.0 * workgroups / units
     ideal = [scale * c / k for c, k in zip(width, ks)]
     groups = [t // w for t, w in zip(tiles, tw)]
-    cap = [max(1, rows // (8 * k)) for k in ks]
+    # every wave should get at least one run of 16 row pairs (fp32 kernel) / two 16-row blocks (split kernel: a hard limit there): slices x ks <=
+    # rows / 32.  Below 32 x ks rows one slice remains and some of its waves get an empty run, which the fp32 kernel handles (they add zeros).
+    cap = [max(1, rows // (32 * k)) for k in ks]
     s = [max(1, min(cp, int(x))) for x, cp in zip(ideal, cap)]
     order = sorted(range(len(shapes)), key=lambda k: ideal[k] - int(ideal[k]), reverse=True)
     for k in order:
@@ -65,7 +67,7 @@ class GroupedWeightGrad:
         if key != self._key:  # buffers are static: built once
             rows = probs[0][0].shape[0]
             # split mode (bg_mlp_weight_grad_group_split): the waves of a workgroup share their rows through LDS, all tiles of a layer in one workgroup
-            self.split = MLPTrainer.SPLIT if rows % 32 == 0 and all((co, ci) in ((256, 256), (128, 256), (128, 128), (256, 64)) for _, _, _, co, ci, _ in probs) else 0
+            self.split = MLPTrainer.SPLIT if rows % 32 == 0 and rows >= 128 and all((co, ci) in ((256, 256), (128, 256), (128, 128), (256, 64)) for _, _, _, co, ci, _ in probs) else 0
             slices, tw = plan_wgrad_slices([(co, ci) for _, _, _, co, ci, _ in probs], rows, self.workgroups, share_rows=self.share_rows or bool(self.split))
             self._scratch = [torch.empty(sl * co * ci, dtype=torch.float32, device=probs[0][0].device) for sl, (_, _, _, co, ci, _) in zip(slices, probs)]
             arr = (_lib.WgradProblem * len(probs))()
@@ -83,7 +85,8 @@ class GroupedWeightGrad:
             _lib.check(_lib.load().bg_mlp_weight_grad_group(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
         if ev is not None:
             e1.record()
-            ev.append((e0, e1, sum(2.0 * g.shape[0] * co * ci for g, _, _, co, ci, _ in probs), [(g.shape[0], co, ci) for g, _, _, co, ci, _ in probs]))
+            # algorithmic flops: the REAL input columns (47 / 61 of the zero-padded 64 of the first layers)
+            ev.append((e0, e1, sum(2.0 * g.shape[0] * co * cr for g, _, _, co, _, cr in probs), [(g.shape[0], co, cr) for g, _, _, co, _, cr in probs]))
 
 
 class MLPTrainer:
@@ -157,7 +160,7 @@ class MLPTrainer:
             return 0
         ntiles = (c_out // 128) * max(1, c_in // 128)
         s = max(8, cls.WGRAD_WORKGROUPS // ntiles // 8 * 8)
-        while s > 8 and s * 8 > B:
+        while s > 8 and s * 4 > (B // 2) // 16:  # 4 waves per slice, each at least one run of 16 row pairs where the batch allows it
             s -= 8
         return s
 

@@ -6,7 +6,9 @@ optimiser step: (1) [sum adv, sum adv^2, count] so that every rank normalises ad
 per-parameter hooks), averaged, (3) the loss / KL sums so that every rank takes the same learning-rate branch
 (runner.py:174-180).  With equal shards this is algebraically the reference update on the union of all shards.
 
-Backend: "nccl" (= RCCL on ROCm) on GPUs; `BG_DIST_BACKEND=gloo` lets the CPU tests run the same code path.
+Backend: "nccl" (= RCCL on ROCm) on GPUs; `BG_DIST_BACKEND=gloo` lets the CPU tests run the same code path.  `BG_DIST_FORCE=1` takes the
+collective path with a world of ONE process too (process group initialised, every exchange issued): the one-GPU box's way to execute the RCCL
+calls of this file (tests/test_gpu_rccl.py).
 """
 import os
 
@@ -21,21 +23,23 @@ class DataParallel:
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.backend = os.environ.get("BG_DIST_BACKEND", backend or "nccl")
         self.owns_group = False
+        self.force = os.environ.get("BG_DIST_FORCE", "0") == "1"
         self.timed_events = None
         # device of this rank: LOCAL_RANK, unless the launcher already narrowed the visible devices to one per process
         # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), or a test shares one GPU between ranks (BG_LOCAL_DEVICE)
         ndev = torch.cuda.device_count()
         self.device_index = int(os.environ.get("BG_LOCAL_DEVICE", self.local_rank if self.local_rank < max(ndev, 1) else 0))
-        if self.world_size > 1 and not dist.is_initialized():
+        if (self.world_size > 1 or self.force) and not dist.is_initialized():
             if self.backend == "nccl":
                 torch.cuda.set_device(self.device_index)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29511")
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size)
             self.owns_group = True
 
     @property
     def active(self):
-        return self.world_size > 1
+        return self.world_size > 1 or self.force
 
     def sum_(self, t):
         """In-place SUM all-reduce (no-op for a single process)."""
@@ -51,8 +55,11 @@ class DataParallel:
             if ev is not None and t.is_cuda:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
-            t.mul_(1.0 / self.world_size)
+            if self.backend == "nccl":  # RCCL averages inside the collective: no second launch on the critical path of every mini-epoch
+                dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            else:                       # gloo has no AVG
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+                t.mul_(1.0 / self.world_size)
             if ev is not None and t.is_cuda:
                 e1.record()
                 ev.append((e0, e1))

@@ -146,3 +146,33 @@ def test_mlp_weight_grad_group_matches_torch_fp64(share_rows):
     assert _lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()) == -4
     arr[0].slices, arr[5].tiles_per_workgroup = slices[0], 2  # the 128 x 128 layer has one tile
     assert _lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()) == -4
+
+
+@pytest.mark.parametrize("M", [96, 768, 2400])
+def test_mlp_weight_grad_group_small_batches(M):
+    """The grouped weight-gradient launch at small batches (4, 32 and 100 envs x 24 steps), where (M / 2) / 16 runs of 16 row pairs do not
+    cover slices x waves and some waves get an EMPTY run: such a wave must add zeros (and, when its run starts at row 0, must not read in
+    front of the arrays: its clamped prologue load now lands on row 0).  Operands sit at the very start of their own allocations, next to
+    canaries, so that a read before G or A would be a read of another buffer or of unmapped memory.  Against torch float64, both layouts."""
+    from booster_gym_amd import _lib
+    from booster_gym_amd.utils.model import plan_wgrad_slices
+
+    shapes = [(256, 64, 61), (256, 256, 256), (128, 256, 256), (256, 64, 47), (128, 256, 256), (128, 128, 128)]
+    torch.manual_seed(7)
+    for share_rows in (False, True):
+        slices, tw = plan_wgrad_slices([(co, ci) for co, ci, _ in shapes], M, 256, share_rows=share_rows)
+        assert all(sl >= 1 and sl * (4 // w) <= max(M // 32, 4 // w) for sl, w in zip(slices, tw)), (slices, tw)
+        arr = (_lib.WgradProblem * len(shapes))()
+        keep = []
+        for k, ((co, ci, cr), sl) in enumerate(zip(shapes, slices)):
+            G = torch.randn(M, co, device=DEV); A = torch.randn(M, ci, device=DEV); A[:, cr:] = 0.0
+            dW = torch.full((co, cr), float("nan"), device=DEV); sc = torch.empty(sl * co * ci, device=DEV)
+            keep.append((G, A, dW, sc))
+            arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = G.data_ptr(), A.data_ptr(), dW.data_ptr(), sc.data_ptr()
+            arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices, arr[k].tiles_per_workgroup = M, co, ci, cr, sl, tw[k]
+        _lib.check(_lib.load().bg_mlp_weight_grad_group(arr, len(shapes), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
+        torch.cuda.synchronize()
+        for (co, ci, cr), (G, A, dW, sc) in zip(shapes, keep):
+            ref64 = G.double().t() @ A.double()[:, :cr]
+            err, err_t = (dW.double() - ref64).abs().max().item(), ((G.t() @ A[:, :cr]).double() - ref64).abs().max().item()
+            assert torch.isfinite(dW).all() and err <= max(4 * err_t, 1e-4), (M, share_rows, co, ci, err, err_t)

@@ -605,6 +605,25 @@ def test_c_urdf_loader_matches_the_python_loader(flat_model, tmp_path):
     assert rc == -1 and "XML" in msg
     rc, msg, _, _ = _load_urdf_c(tmp_path / "missing.urdf")
     assert rc == -3 and "cannot open" in msg
+    # malformed joint graphs come back as errors, not as unbounded recursion: a link with two parent joints, a cycle of joints that the root
+    # does not reach, a joint from a link to itself; and XML nested deeper than the reader's bound
+    good = open(p).read()
+    two = good.replace("</robot>", '<joint name="extra" type="fixed"><parent link="Trunk"/><child link="Hand"/></joint></robot>')
+    pt2 = tmp_path / "two_parents.urdf"; pt2.write_text(two)
+    rc, msg, _, _ = _load_urdf_c(pt2)
+    assert rc == -1 and "more than one joint" in msg
+    cyc = good.replace("</robot>", '<link name="CA"/><link name="CB"/><joint name="c1" type="fixed"><parent link="CA"/><child link="CB"/></joint>'
+                       '<joint name="c2" type="fixed"><parent link="CB"/><child link="CA"/></joint></robot>')
+    pc = tmp_path / "cycle.urdf"; pc.write_text(cyc)
+    rc, msg, _, _ = _load_urdf_c(pc)
+    assert rc == -1 and "not connected to the root" in msg
+    slf = good.replace("</robot>", '<joint name="s1" type="fixed"><parent link="Hand"/><child link="Hand"/></joint></robot>')
+    ps = tmp_path / "self.urdf"; ps.write_text(slf)
+    rc, msg, _, _ = _load_urdf_c(ps)
+    assert rc == -1 and ("itself" in msg or "more than one joint" in msg)
+    pd = tmp_path / "deep.urdf"; pd.write_text("<robot>" + "<a>" * 500 + "</a>" * 500 + "</robot>")
+    rc, msg, _, _ = _load_urdf_c(pd)
+    assert rc == -1 and "nested deeper" in msg
 
 
 def test_c_urdf_loader_on_the_reference_asset(flat_model):
