@@ -168,5 +168,8 @@ class StepParity:
     def finish(self):
         frac = self.explained / max(self.checked, 1)
         assert frac <= self.max_explained_frac, f"{self.explained} of {self.checked} env-steps needed an explanation ({frac:.4f}): {self.log[:10]}"
-        return {"env_steps": self.checked, "explained": self.explained, "foot_contact_flag_flips": self.flag_flips,
-                "by_reason": {w: sum(1 for _, _, _, why in self.log if w in " ".join(why)) for w in ("contact_flag", "limit_crossing", "fp32_backward")}}
+        out = {"env_steps": self.checked, "explained": self.explained, "foot_contact_flag_flips": self.flag_flips,
+               "by_reason": {w: sum(1 for _, _, _, why in self.log if w in " ".join(why)) for w in ("contact_flag", "limit_crossing", "fp32_backward")}}
+        # always in the test output (pytest -s / the captured log of a failure): a regression that starts leaning on the explanations shows here
+        print("StepParity:", out, flush=True)
+        return out

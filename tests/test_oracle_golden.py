@@ -465,3 +465,75 @@ def test_cross_sim_player_gait_rule_and_walk():
     assert tr_[-1, 0] > 1.5 and tr_[:, 2].min() > 0.55
     stand = po.rollout(po.load_actor(os.path.join(HERE, "golden", "t1_actor.npz")), [0.0, 0.0, 0.0], 3.0)
     assert abs(stand[-1, 0]) < 0.5 and stand[:, 2].min() > 0.55  # zero command: gait frequency 0, the policy stands
+
+
+# ------------------------------------------------------------------ an independent derivation of the leg dynamics: Lagrange's equations (sympy)
+@pytest.fixture(scope="module")
+def lagrange_leg(flat_model):
+    """tau(q, qd, qdd, g) of ONE fixed-base T1 leg (6 DoF; inertials of resources/T1/T1_locomotion.xml:55-79 / :88-112 via the flat model) from
+    Lagrange's equations d/dt dL/dqd - dL/dq, L = sum_i 1/2 m v_c^2 + 1/2 w^T I_c w - m g z_c, derived symbolically (kinetic energy from
+    the Jacobian of the centre-of-mass positions and from R^T Rdot): no spatial algebra, no recursion -- mathematics that is not the build's
+    own.  Returns {leg: f(q, qd, qdd, g) -> tau[6]}."""
+    import sympy as sp
+
+    m = flat_model
+    out = {}
+    for leg in range(2):
+        q, qd, qdd, g = sp.symbols("q0:6"), sp.symbols("qd0:6"), sp.symbols("qdd0:6"), sp.Symbol("g")
+
+        def rot(ax, a):
+            c, s = sp.cos(a), sp.sin(a)
+            return {1: sp.Matrix([[1, 0, 0], [0, c, -s], [0, s, c]]), 2: sp.Matrix([[c, 0, s], [0, 1, 0], [-s, 0, c]]), 3: sp.Matrix([[c, -s, 0], [s, c, 0], [0, 0, 1]])}[ax]
+
+        R, p, T, V = sp.eye(3), sp.zeros(3, 1), 0, 0
+        for i in range(6):
+            b = 1 + 6 * leg + i
+            p = p + R * sp.Matrix([float(v) for v in m.body_pos[b]])
+            R = R * rot(int(m.joint_axis[b]), q[i])
+            pc = p + R * sp.Matrix([float(v) for v in m.com[b]])
+            vc = pc.jacobian(q) * sp.Matrix(qd)
+            Rdot = sum((R.diff(q[k]) * qd[k] for k in range(6)), sp.zeros(3, 3))
+            W = R.T * Rdot  # skew matrix of the angular velocity in body coordinates
+            w = sp.Matrix([W[2, 1], W[0, 2], W[1, 0]])
+            I6 = [float(v) for v in m.inertia[b]]
+            Ic = sp.Matrix([[I6[0], I6[3], I6[4]], [I6[3], I6[1], I6[5]], [I6[4], I6[5], I6[2]]])
+            T += sp.Rational(1, 2) * float(m.mass[b]) * (vc.T * vc)[0] + sp.Rational(1, 2) * (w.T * Ic * w)[0]
+            V += float(m.mass[b]) * g * pc[2]
+        L = T - V
+        tau = []
+        for i in range(6):
+            dLdqd = sp.diff(L, qd[i])
+            tau.append(sum(sp.diff(dLdqd, q[k]) * qd[k] + sp.diff(dLdqd, qd[k]) * qdd[k] for k in range(6)) - sp.diff(L, q[i]))
+        out[leg] = sp.lambdify((q, qd, qdd, g), tau, modules="numpy", cse=True)
+    return out
+
+
+def test_oracle_rnea_and_aba_match_lagrange_equations(lagrange_leg, dyn_smooth, flat_model):
+    """oracle/dyn_ref.c against Lagrange's equations of one leg (reference: the MuJoCo step the north star names, play_mujoco.py:751-756, solves
+    the same equations of motion M(q) qdd + c(q, qd) + g(q) = tau).  (1) RNEA with the trunk held still in gravity: joint torques of each leg on
+    1,000 random states, relative 1e-10.  (2) ABA: the floating trunk made 1e8 times heavier falls freely and the legs, in its frame, obey the
+    gravity-free fixed-base equations: qdd = M^-1 (tau - c), relative 1e-6 (the trunk's reaction is O(1e-8)).  This cannot lift the
+    'parity unpinned' label (only reference-held vectors could); it is the one check here whose mathematics is not the build's own recursion."""
+    m, rng = flat_model, np.random.default_rng(31)
+    root = np.zeros(13); root[2], root[6] = 5.0, 1.0
+    worst_id, worst_fd = 0.0, 0.0
+    ms = np.ones(13); ms[0] = 1.0e8
+    for _ in range(1000):
+        q, qd, qdd = rng.uniform(m.dof_lower, m.dof_upper), rng.normal(size=12) * 2.0, rng.normal(size=12) * 20.0
+        res = dyn_smooth.inverse(root, q, qd, np.concatenate([np.zeros(6), qdd]))
+        for leg in range(2):
+            sl = slice(6 * leg, 6 * leg + 6)
+            want = np.array(lagrange_leg[leg](q[sl], qd[sl], qdd[sl], 9.81), dtype=np.float64)
+            worst_id = max(worst_id, np.abs(res[6:][sl] - want).max() / max(1.0, np.abs(want).max()))
+    for _ in range(300):
+        q, qd, tau = rng.uniform(m.dof_lower, m.dof_upper), rng.normal(size=12) * 2.0, rng.uniform(-m.dof_effort, m.dof_effort)
+        qacc, _ = dyn_smooth.forward(root, q, qd, tau, mass_scale=ms)
+        for leg in range(2):
+            sl = slice(6 * leg, 6 * leg + 6)
+            f = lagrange_leg[leg]
+            c = np.array(f(q[sl], qd[sl], np.zeros(6), 0.0), dtype=np.float64)
+            M = np.stack([np.array(f(q[sl], qd[sl], np.eye(6)[k], 0.0), dtype=np.float64) - c for k in range(6)], axis=1)
+            assert np.allclose(M, M.T, atol=1e-12) and np.linalg.eigvalsh(M).min() > 0
+            want = np.linalg.solve(M, tau[sl] - c)
+            worst_fd = max(worst_fd, np.abs(qacc[6:][sl] - want).max() / max(1.0, np.abs(want).max()))
+    assert worst_id < 1e-10 and worst_fd < 1e-6, (worst_id, worst_fd)
