@@ -47,6 +47,13 @@ class WgradProblem(C.Structure):
                 ("C_in_real", C.c_int32), ("slices", C.c_int32), ("tiles_per_workgroup", C.c_int32)]
 
 
+class ReduceProblem(C.Structure):
+    """bg_reduce_problem: a deferred fixed-order reduction (include/booster_gym_amd.h)."""
+    _fields_ = [("partial", C.c_void_p), ("groups", C.c_int32), ("record", C.c_int32), ("n_out", C.c_int32), ("out", C.c_void_p * 3), ("n", C.c_int32 * 3),
+                ("stat_base", C.c_uint64), ("n_stat", C.c_int32), ("n_ls", C.c_int32), ("stat_skip", C.c_uint32), ("entropy_coef", C.c_double),
+                ("grad_logstd", C.c_void_p), ("stats", C.c_void_p)]
+
+
 class Rand(C.Structure):
     _fields_ = [("mode", C.c_int32), ("a", C.c_float), ("b", C.c_float)]
 
@@ -94,6 +101,7 @@ SYMBOLS = [
     "bg_env_forward_dynamics", "bg_sim_bind_state", "bg_sim_set_actuation", "bg_sim_apply_body_wrench_local", "bg_sim_simulate",
     "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_optimizer_step", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward", "bg_mlp_split_weights", "bg_mlp_layer_forward_split", "bg_mlp_layer_backward_split", "bg_mlp_weight_grad", "bg_mlp_weight_grad_group", "bg_mlp_weight_grad_group_split",
     "bg_critic_head_forward", "bg_actor_head", "bg_critic_head_backward",
+    "bg_reduce_group", "bg_actor_head_partial", "bg_critic_head_backward_partial", "bg_mlp_layer_backward_partial",
     "bg_last_error", "bg_version",
 ]
 
@@ -164,6 +172,10 @@ def load():
         "bg_critic_head_forward": (i32, [i32, vp, vp, vp, vp, vp]),
         "bg_actor_head": (i32, [i32, i32] + [vp] * 10 + [f32, f32, f32] + [vp] * 9),
         "bg_critic_head_backward": (i32, [i32] + [vp] * 11),
+        "bg_reduce_group": (i32, [C.POINTER(ReduceProblem), i32, vp]),
+        "bg_actor_head_partial": (i32, [i32] + [vp] * 10 + [f32, f32, f32] + [vp] * 8 + [C.POINTER(ReduceProblem), vp]),
+        "bg_critic_head_backward_partial": (i32, [i32] + [vp] * 10 + [C.POINTER(ReduceProblem), vp]),
+        "bg_mlp_layer_backward_partial": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, C.POINTER(ReduceProblem), vp]),
         "bg_last_error": (C.c_char_p, []),
         "bg_version": (C.c_char_p, []),
     }

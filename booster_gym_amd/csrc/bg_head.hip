@@ -323,6 +323,73 @@ __global__ __launch_bounds__(256) void head_finish_kernel(int groups, int record
     }
 }
 
+// ---- deferred reductions (include/booster_gym_amd.h: bg_reduce_problem / bg_reduce_group): the work of head_finish_kernel (and of the backward
+// layer's column-sum finish) for up to 8 descriptors in one launch.  Workgroups [begin_k, begin_k + nblk_k) serve descriptor k: 16 outputs x 16
+// slices of the groups each, the last one of a descriptor with statistics adds those up (float64) and issues one atomic per statistic.
+constexpr int RG_MAX = 8;
+struct ReduceGroup { int np; int begin[RG_MAX]; bg_reduce_problem p[RG_MAX]; };
+__global__ __launch_bounds__(256) void reduce_group_kernel(ReduceGroup grp) {
+    int k = 0;
+#pragma unroll
+    for (int j = 1; j < RG_MAX; j++)
+        if (j < grp.np && (int)blockIdx.x >= grp.begin[j]) k = j;
+    const bg_reduce_problem& pr = grp.p[k];
+    const int b = blockIdx.x - grp.begin[k], nsum = (pr.n_out + 15) / 16;
+    if (b >= nsum) {  // the statistics block of this descriptor
+        __shared__ double sd[4];
+        const double* sp = reinterpret_cast<const double*>(pr.partial + pr.stat_base);
+        for (int s_ = 0; s_ < pr.n_stat; s_++) {
+            if ((pr.stat_skip >> s_) & 1u) continue;
+            double s = 0.0;
+            for (int g = threadIdx.x; g < pr.groups; g += 256) s += sp[(size_t)s_ * pr.groups + g];
+            s = wave_sum_d(s);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = s;
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                const double v = sd[0] + sd[1] + sd[2] + sd[3];
+                if (s_ < pr.n_ls) atomicAdd(&pr.grad_logstd[s_], v + pr.entropy_coef);
+                else atomicAdd(&pr.stats[s_ - pr.n_ls], v);
+            }
+        }
+        return;
+    }
+    __shared__ float sm[16][17];
+    const int o = threadIdx.x & 15, gs = threadIdx.x >> 4, i = b * 16 + o;
+    float s = 0.f;
+    if (i < pr.n_out)
+        for (int g = gs; g < pr.groups; g += 16) s += pr.partial[(size_t)g * pr.record + i];
+    sm[gs][o] = s;
+    __syncthreads();
+    if (threadIdx.x < 16 && i < pr.n_out) {
+        float v = 0.f;
+        for (int j = 0; j < 16; j++) v += sm[j][o];
+        if (i < pr.n[0]) pr.out[0][i] = v;
+        else if (i < pr.n[0] + pr.n[1]) pr.out[1][i - pr.n[0]] = v;
+        else pr.out[2][i - pr.n[0] - pr.n[1]] = v;
+    }
+}
+extern "C" int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stream) {
+    if (!problems || count <= 0 || count > RG_MAX) return bg_set_error(-1, "bg_reduce_group: 1 to 8 descriptors");
+    ReduceGroup grp;
+    grp.np = count;
+    int blocks = 0;
+    for (int k = 0; k < count; k++) {
+        const bg_reduce_problem& q = problems[k];
+        if (!q.partial || q.groups <= 0 || q.record <= 0 || q.n_out <= 0 || q.n_out > q.record || !q.out[0] || q.n[0] <= 0 ||
+            q.n[0] + q.n[1] + q.n[2] != q.n_out || (q.n[1] > 0 && !q.out[1]) || (q.n[2] > 0 && !q.out[2]))
+            return bg_set_error(-1, "bg_reduce_group: bad descriptor");
+        if (q.n_stat < 0 || q.n_stat > 32 || (q.n_stat > 0 && (!q.stats || (q.n_ls > 0 && !q.grad_logstd) || (q.stat_base & 1))))
+            return bg_set_error(-1, "bg_reduce_group: bad statistics descriptor");
+        grp.begin[k] = blocks;
+        grp.p[k] = q;
+        blocks += (q.n_out + 15) / 16 + (q.n_stat > 0 ? 1 : 0);
+    }
+    hipLaunchKernelGGL(reduce_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 // values = h w + b: half a wave per row (32 lanes x 16 bytes = one 512-byte row), 4 rows in flight per half-wave
 __global__ __launch_bounds__(256) void critic_head_forward_kernel(int rows, const float* __restrict__ h, const float* __restrict__ w,
                                                                   const float* __restrict__ b, float* __restrict__ values) {
@@ -387,6 +454,41 @@ extern "C" int bg_actor_head(int32_t B, int32_t mode, const float* h, const floa
     hipLaunchKernelGGL(head_finish_kernel, dim3((n_out + 15) / 16 + 1), dim3(256), 0, st, grid, head_record<HA>(), n_out, scratch, grad_W, HA * HK,
                        grad_b_hidden, grad_b, head_stat_base<HA>(), HEAD_NSTAT, HA, 1u << HA, (double)entropy_coef, grad_logstd, stats);
     HIP_OK(hipGetLastError());
+    return 0;
+}
+
+static void head_finish_desc(bg_reduce_problem* f, const float* scratch, int grid, int record, float* grad_w, int n_w, float* grad_b_hidden, float* grad_b, int n_b,
+                             size_t stat_base, int n_stat, int n_ls, unsigned skip, double entropy_coef, double* grad_logstd, double* stats) {
+    f->partial = scratch; f->groups = grid; f->record = record; f->n_out = n_w + HK + n_b;
+    f->out[0] = grad_w; f->n[0] = n_w; f->out[1] = grad_b_hidden; f->n[1] = HK; f->out[2] = grad_b; f->n[2] = n_b;
+    f->stat_base = stat_base; f->n_stat = n_stat; f->n_ls = n_ls; f->stat_skip = skip; f->entropy_coef = entropy_coef; f->grad_logstd = grad_logstd; f->stats = stats;
+}
+extern "C" int bg_actor_head_partial(int32_t B, const float* h, const float* W, const float* bias, const float* logstd, const float* actions,
+                                     const float* old_mu, const float* old_logstd, const float* old_logp, const float* adv, const double* adv_stats,
+                                     float e_clip, float bound_coef, float entropy_coef, float* mu_out, float* g_hidden, float* grad_W, float* grad_b,
+                                     float* grad_b_hidden, double* grad_logstd, double* stats, float* scratch, bg_reduce_problem* finish, void* stream) {
+    if (B <= 0 || !h || !W || !bias || !logstd || !actions || !old_mu || !old_logstd || !old_logp || !adv || !adv_stats || !g_hidden || !grad_W || !grad_b ||
+        !grad_b_hidden || !grad_logstd || !stats || !scratch || !finish)
+        return bg_set_error(-1, "bg_actor_head_partial: bad argument");
+    if (!aligned16(h)) return bg_set_error(-1, "bg_actor_head_partial: h must be 16-byte aligned");
+    const int tiles = (B + HT - 1) / HT, grid = head_grid(tiles);
+    hipLaunchKernelGGL(actor_head_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, tiles, h, W, bias, logstd, actions, old_mu, old_logstd, old_logp,
+                       adv, adv_stats, e_clip, bound_coef, mu_out, g_hidden, scratch);
+    HIP_OK(hipGetLastError());
+    head_finish_desc(finish, scratch, grid, head_record<HA>(), grad_W, HA * HK, grad_b_hidden, grad_b, HA, head_stat_base<HA>(), HEAD_NSTAT, HA, 1u << HA,
+                     (double)entropy_coef, grad_logstd, stats);
+    return 0;
+}
+extern "C" int bg_critic_head_backward_partial(int32_t B, const float* h, const float* w, const float* values, const float* returns, float* g_hidden,
+                                               float* grad_w, float* grad_b, float* grad_b_hidden, double* stats, float* scratch, bg_reduce_problem* finish,
+                                               void* stream) {
+    if (B <= 0 || !h || !w || !values || !returns || !g_hidden || !grad_w || !grad_b || !grad_b_hidden || !stats || !scratch || !finish)
+        return bg_set_error(-1, "bg_critic_head_backward_partial: bad argument");
+    if (!aligned16(h)) return bg_set_error(-1, "bg_critic_head_backward_partial: h must be 16-byte aligned");
+    const int tiles = (B + HT - 1) / HT, grid = head_grid(tiles);
+    hipLaunchKernelGGL(critic_head_backward_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, B, tiles, h, w, values, returns, g_hidden, scratch);
+    HIP_OK(hipGetLastError());
+    head_finish_desc(finish, scratch, grid, head_record<1>(), grad_w, HK, grad_b_hidden, grad_b, 1, head_stat_base<1>(), 1, 0, 0u, 0.0, nullptr, stats);
     return 0;
 }
 

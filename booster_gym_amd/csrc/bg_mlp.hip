@@ -6,6 +6,7 @@
 //   * bias + ELU are applied to the accumulators before the only store of the output (the library GEMM + elementwise pair writes and
 //     re-reads the [M][N] tensor twice more).
 #include <hip/hip_runtime.h>
+#include <string.h>
 
 #include "../../include/booster_gym_amd.h"
 
@@ -198,6 +199,33 @@ extern "C" int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const floa
     BG_BWD(128)
 #undef BG_BWD
     return bg_set_error(-4, "bg_mlp_layer_backward: unsupported K (128, 256)");
+}
+
+// bg_mlp_layer_backward without the column-sum finish: the descriptor of that reduction instead (bg_reduce_group runs it later)
+extern "C" int bg_mlp_layer_backward_partial(int32_t M, int32_t K, int32_t N, const float* G, const float* Wt, const float* act_below, float* Gout,
+                                             float* bias_grad_below, float* scratch, bg_reduce_problem* finish, void* stream) {
+    if (M <= 0 || !G || !Wt || !act_below || !Gout || !bias_grad_below || !scratch || !finish) return bg_set_error(-1, "bg_mlp_layer_backward_partial: bad argument");
+    if ((((uintptr_t)G | (uintptr_t)Wt | (uintptr_t)Gout | (uintptr_t)act_below) & 15) != 0)
+        return bg_set_error(-1, "bg_mlp_layer_backward_partial: pointers must be 16-byte aligned");
+    if (N % 128 != 0 || N > 1024) return bg_set_error(-4, "bg_mlp_layer_backward_partial: unsupported N (multiples of 128 up to 1024)");
+    if (K != 256 && K != 128) return bg_set_error(-4, "bg_mlp_layer_backward_partial: unsupported K (128, 256)");
+    const int nb = (M + FW_BM - 1) / FW_BM;
+    dim3 grid(((nb + 7) / 8) * 8 * (N / 128)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+#define BG_BWDP(KK)                                                                                                               \
+    if (K == KK) {                                                                                                                \
+        if (N == 128) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2, 1>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch);      \
+        else if (N == 256) hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2, 2>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch); \
+        else hipLaunchKernelGGL((mlp_fwd_kernel<KK, 2, 0>), grid, block, 0, st, M, N, G, Wt, nullptr, Gout, act_below, scratch);               \
+    }
+    BG_BWDP(256)
+    BG_BWDP(128)
+#undef BG_BWDP
+    HIP_OK(hipGetLastError());
+    memset(finish, 0, sizeof(*finish));
+    finish->partial = scratch; finish->groups = nb; finish->record = N; finish->n_out = N;
+    finish->out[0] = bias_grad_below; finish->n[0] = N;
+    return 0;
 }
 
 // launch of the fixed-order column-sum finish for bg_mlp_split.hip's backward layer

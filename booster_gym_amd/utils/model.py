@@ -228,10 +228,12 @@ class MLPTrainer:
         """[B, width] buffer the fused head kernels write dL/dz of the last hidden layer into (input of `backward_hidden`)."""
         return self.gin[len(self.layers) - 1]
 
-    def backward_hidden(self, g=None):
+    def backward_hidden(self, g=None, finishes=None):
         """Backward from the last hidden layer down.  g = dL/dz of that layer (default: `hidden_grad`); its bias gradient and the output
-        layer's weight / bias gradients have already been written by the fused head kernel."""
-        self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g)
+        layer's weight / bias gradients have already been written by the fused head kernel.  finishes (a list): the fused backward layers run
+        without their column-sum finish and append its descriptor (_lib.ReduceProblem) instead; the caller runs them later with
+        utils.reduce_group (the bias gradients are not needed before the optimiser step)."""
+        self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g, finishes)
 
     # The backward chain computes only dL/dz; the weight gradients of all layers run afterwards, when both networks' chains are done and nothing
     # else competes for the GPU (grouped launch, or `weight_grads()` layer by layer).  BG_DEFER_WGRAD=0: inside the chain, as in round 1.
@@ -274,7 +276,7 @@ class MLPTrainer:
             torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
             torch.sum(self.dw[i], dim=0, out=l.weight.grad)
 
-    def _backward_from(self, start, g):
+    def _backward_from(self, start, g, finishes=None):
         lib = _lib.load()
         B = self._B
         stream = _lib.current_stream_ptr()
@@ -301,8 +303,15 @@ class MLPTrainer:
                     if self.wt[i] is None:
                         self.wt[i] = torch.empty(C_in, C_out, dtype=torch.float32, device=g.device)
                     self.wt[i].copy_(l.weight.t())
-                    _lib.check(lib.bg_mlp_layer_backward(B, C_out, C_in, _lib.ptr(g), _lib.ptr(self.wt[i]), _lib.ptr(a_in), _lib.ptr(self.gin[i]),
-                                                         _lib.ptr(below.bias.grad), _lib.ptr(self.cs[i - 1]), stream), "bg_mlp_layer_backward")
+                    if finishes is not None:
+                        fin = _lib.ReduceProblem()
+                        _lib.check(lib.bg_mlp_layer_backward_partial(B, C_out, C_in, _lib.ptr(g), _lib.ptr(self.wt[i]), _lib.ptr(a_in), _lib.ptr(self.gin[i]),
+                                                                     _lib.ptr(below.bias.grad), _lib.ptr(self.cs[i - 1]), fin, stream),
+                                   "bg_mlp_layer_backward_partial")
+                        finishes.append(fin)
+                    else:
+                        _lib.check(lib.bg_mlp_layer_backward(B, C_out, C_in, _lib.ptr(g), _lib.ptr(self.wt[i]), _lib.ptr(a_in), _lib.ptr(self.gin[i]),
+                                                             _lib.ptr(below.bias.grad), _lib.ptr(self.cs[i - 1]), stream), "bg_mlp_layer_backward")
                 else:
                     torch.mm(g, l.weight, out=self.gin[i])
                     _lib.check(lib.bg_elu_backward_colsum(B, C_in, _lib.ptr(self.gin[i]), _lib.ptr(a_in), _lib.ptr(below.bias.grad), _lib.ptr(self.cs[i - 1]),

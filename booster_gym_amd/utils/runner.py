@@ -34,7 +34,7 @@ from .config import load_cfg
 from .model import ActorCritic, GroupedWeightGrad, MLPTrainer
 from .parallel import DataParallel
 from .recorder import Recorder
-from .utils import (actor_head_forward, actor_head_loss_backward, critic_head_backward, critic_head_forward, gae, gaussian_logp, head_scratch,
+from .utils import (actor_head_forward, actor_head_loss_backward, critic_head_backward, critic_head_forward, gae, gaussian_logp, head_scratch, reduce_group,
                     ppo_loss_fused)
 
 
@@ -196,6 +196,12 @@ class Runner:
         # the critic's stream goes ahead of the actor's in workgroup dispatch: its chain is the longer one and the actor's loss waits for its GAE
         # (update 23.17 -> 23.06 ms, tools/ab_prio.sh; BG_SIDE_PRIORITY=0: equal priorities)
         self._side_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("BG_SIDE_PRIORITY", "-1")))
+        # Opt-in (BG_DEFER_FINISH=1): the small fixed-order reductions behind the head / backward-layer kernels as ONE launch on the side stream beside
+        # the weight gradients instead of inside the chains (see update()).  Measured in the loop (tools/ab_env.sh, 3 alternating runs each): update
+        # 23.11-23.21 ms deferred against 22.62-22.72 ms with the finishes in the chains, where they already hide under the other network's GEMMs;
+        # beside the one-workgroup-per-CU weight-gradient launch they delay its workgroups.  Default off.
+        self._defer_finish = os.environ.get("BG_DEFER_FINISH", "0") == "1"
+
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
         # library GEMMs + bg_ppo_loss for these layers (A/B comparisons).
         self._fused_head = (os.environ.get("BG_FUSED_HEAD", "1") == "1" and A == 12
@@ -331,22 +337,29 @@ class Runner:
                 if fused_head:
                     # Output layers fused with the loss (bg_head.hip): per network ONE pass over the [B][128] hidden activations gives the
                     # output, the loss terms, dL/dz of the hidden layer and the output layer's gradients.  Both heads add into _stats.
+                    # defer (opt-in, see __init__): the small fixed-order reductions behind the head kernels and behind every backward layer
+                    # (output-layer and bias gradients, loss statistics: nothing a chain needs) run as ONE launch on the side stream beside the
+                    # weight-gradient launch (bg_reduce_group) instead of inside the chains.
+                    defer = self._defer_finish and not MLPTrainer.SPLIT
+                    fins = [] if defer else None
+                    fin_c, fin_a = (_lib.ReduceProblem(), _lib.ReduceProblem()) if defer else (None, None)
                     ha = self._actor_tr.forward_hidden(obs_flat)
                     with torch.cuda.stream(side):
                         critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,
-                                             c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c)
-                        self._critic_tr.backward_hidden()
+                                             c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c, finish=fin_c)
+                        self._critic_tr.backward_hidden(finishes=fins)
                     main.wait_event(gae_done)  # advantages and their moments
                     actor_head_loss_backward(ha, a_out.weight, a_out.bias, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp,
                                              self._adv.view(B), self._adv_sums, 0.2, alg["bound_coef"], alg["entropy_coef"],
                                              self._actor_tr.hidden_grad, a_out.weight.grad, a_out.bias.grad, self._actor_tr.layers[-2].bias.grad,
-                                             self._grad_logstd, self._stats, self._head_scratch_a)
-                    if self.dp.active:
+                                             self._grad_logstd, self._stats, self._head_scratch_a, finish=fin_a)
+                    if self.dp.active and not defer:
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
                             self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
-                    self._actor_tr.backward_hidden()
+                    self._actor_tr.backward_hidden(finishes=fins)
                 else:
+                    defer = False
                     mu = self._actor_tr.forward(obs_flat)
                     main.wait_stream(side)
                     ppo_loss_fused(mu, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
@@ -358,15 +371,25 @@ class Runner:
                         self._critic_tr.backward(self._grad_val.view(B, 1))
                     self._actor_tr.backward(self._grad_mu)
                 fused_tail = self._fused_opt and not self._lr_restart
-                if self.dp.active or not fused_tail:
+                if (self.dp.active or not fused_tail) and not defer:
                     self._logstd_grad_view.copy_(self._grad_logstd)  # into the flat bucket before the all-reduce
                 main.wait_stream(side)
+                if defer:  # the deferred reductions (+ what depends on them) on the side stream, beside the weight gradients on the main stream
+                    side.wait_stream(main)
+                    with torch.cuda.stream(side):
+                        reduce_group([fin_c, fin_a] + fins)
+                        if self.dp.active:
+                            self.dp.sum_(self._stats)  # exchange (3)
+                        if self.dp.active or not fused_tail:
+                            self._logstd_grad_view.copy_(self._grad_logstd)
                 if MLPTrainer.DEFER_WGRAD:  # all weight gradients after both backward chains, alone on the GPU
                     if MLPTrainer.FUSED_WGRAD and MLPTrainer.FUSED:
                         self._wgrad_group.run((self._critic_tr, self._actor_tr))  # one launch pair for the six layers
                     else:
                         self._critic_tr.weight_grads()
                         self._actor_tr.weight_grads()
+                if defer:
+                    main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
                 if fused_tail:
                     # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch

@@ -131,11 +131,20 @@ def actor_head_forward(h, weight, bias, mu_out):
 
 
 def actor_head_loss_backward(h, weight, bias, logstd, actions, old_mu, old_logstd, old_logp, adv, adv_stats, e_clip, bound_coef, entropy_coef,
-                             g_hidden, grad_weight, grad_bias, grad_bias_hidden, grad_logstd, stats, scratch, mu_out=None):
+                             g_hidden, grad_weight, grad_bias, grad_bias_hidden, grad_logstd, stats, scratch, mu_out=None, finish=None):
     """Output layer + PPO actor loss (runner.py:145-174) + output-layer backward in one pass over h [B, 128].  grad_logstd float64[12] and
-    stats float64[5] (entries 1..4) are ACCUMULATED with atomics: the caller zeroes them (the critic head adds entry 0 concurrently)."""
+    stats float64[5] (entries 1..4) are ACCUMULATED with atomics: the caller zeroes them (the critic head adds entry 0 concurrently).
+    finish (a _lib.ReduceProblem): only the main kernel runs; the sums over its workgroups (grad_weight, grad_bias, grad_bias_hidden, grad_logstd,
+    stats) are left to a later bg_reduce_group call on the descriptor written into `finish`; g_hidden is complete either way."""
     _need_cuda(h, weight, bias, logstd, actions, old_mu, old_logstd, old_logp, adv, adv_stats, g_hidden, grad_weight, grad_bias, grad_bias_hidden,
                grad_logstd, stats, scratch)
+    if finish is not None:
+        _lib.check(_lib.load().bg_actor_head_partial(h.shape[0], _lib.ptr(h), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(logstd), _lib.ptr(actions),
+                                                     _lib.ptr(old_mu), _lib.ptr(old_logstd), _lib.ptr(old_logp), _lib.ptr(adv), _lib.ptr(adv_stats), e_clip,
+                                                     bound_coef, entropy_coef, _lib.ptr(mu_out), _lib.ptr(g_hidden), _lib.ptr(grad_weight), _lib.ptr(grad_bias),
+                                                     _lib.ptr(grad_bias_hidden), _lib.ptr(grad_logstd), _lib.ptr(stats), _lib.ptr(scratch), finish,
+                                                     _lib.current_stream_ptr()), "bg_actor_head_partial")
+        return
     _lib.check(_lib.load().bg_actor_head(h.shape[0], 1, _lib.ptr(h), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(logstd), _lib.ptr(actions),
                                          _lib.ptr(old_mu), _lib.ptr(old_logstd), _lib.ptr(old_logp), _lib.ptr(adv), _lib.ptr(adv_stats), e_clip,
                                          bound_coef, entropy_coef, _lib.ptr(mu_out), _lib.ptr(g_hidden), _lib.ptr(grad_weight), _lib.ptr(grad_bias),
@@ -143,12 +152,26 @@ def actor_head_loss_backward(h, weight, bias, logstd, actions, old_mu, old_logst
                                          _lib.current_stream_ptr()), "bg_actor_head")
 
 
-def critic_head_backward(h, weight, values, returns, g_hidden, grad_weight, grad_bias, grad_bias_hidden, stats, scratch):
-    """Backward of mean((values - returns)^2) (runner.py:148) through the 128 -> 1 output layer; stats[0] += sum of squared errors."""
+def critic_head_backward(h, weight, values, returns, g_hidden, grad_weight, grad_bias, grad_bias_hidden, stats, scratch, finish=None):
+    """Backward of mean((values - returns)^2) (runner.py:148) through the 128 -> 1 output layer; stats[0] += sum of squared errors.
+    finish: as for actor_head_loss_backward."""
     _need_cuda(h, weight, values, returns, g_hidden, grad_weight, grad_bias, grad_bias_hidden, stats, scratch)
+    if finish is not None:
+        _lib.check(_lib.load().bg_critic_head_backward_partial(h.shape[0], _lib.ptr(h), _lib.ptr(weight), _lib.ptr(values), _lib.ptr(returns), _lib.ptr(g_hidden),
+                                                               _lib.ptr(grad_weight), _lib.ptr(grad_bias), _lib.ptr(grad_bias_hidden), _lib.ptr(stats),
+                                                               _lib.ptr(scratch), finish, _lib.current_stream_ptr()), "bg_critic_head_backward_partial")
+        return
     _lib.check(_lib.load().bg_critic_head_backward(h.shape[0], _lib.ptr(h), _lib.ptr(weight), _lib.ptr(values), _lib.ptr(returns), _lib.ptr(g_hidden),
                                                    _lib.ptr(grad_weight), _lib.ptr(grad_bias), _lib.ptr(grad_bias_hidden), _lib.ptr(stats),
                                                    _lib.ptr(scratch), _lib.current_stream_ptr()), "bg_critic_head_backward")
+
+
+def reduce_group(problems):
+    """Run the deferred reductions of a list of _lib.ReduceProblem descriptors in one launch on the current stream (bg_reduce_group)."""
+    if not problems:
+        return
+    arr = (_lib.ReduceProblem * len(problems))(*problems)
+    _lib.check(_lib.load().bg_reduce_group(arr, len(problems), _lib.current_stream_ptr()), "bg_reduce_group")
 
 
 def surrogate_loss(old_actions_log_prob, actions_log_prob, advantages, e_clip=0.2):

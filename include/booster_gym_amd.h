@@ -350,6 +350,34 @@ int bg_actor_head(int32_t B, int32_t mode, const float* h, const float* W, const
 int bg_critic_head_backward(int32_t B, const float* h, const float* w, const float* values, const float* returns, float* g_hidden, float* grad_w,
                             float* grad_b, float* grad_b_hidden, double* stats, float* scratch, void* stream);
 
+/* ---- deferred fixed-order reductions.  The head kernels and the backward layer kernel leave per-workgroup partial sums that a small second
+ * kernel adds up (head: output-layer weight / bias gradients, last hidden layer's bias gradient, float64 loss statistics; backward layer: the
+ * bias gradient of the layer below).  None of these sums is needed before the optimiser step (utils/runner.py:162-165), so instead of one small
+ * launch in the middle of each network's chain (40 + 80 launches per PPO iteration that wait for workgroup slots between the GEMMs) the
+ * `_partial` forms below launch the main kernel only and fill a descriptor; bg_reduce_group then runs all descriptors of a mini-epoch in ONE
+ * launch, e.g. on a second stream beside the weight-gradient launch.  Same sums, same fixed order as the immediate forms for the heads; the
+ * column sums of the backward layer are added in a different (still fixed) order than bg_mlp_layer_backward's own finish. */
+typedef struct {
+    const float* partial;           /* [groups][record] floats */
+    int32_t groups, record, n_out;  /* out[i] = sum over g of partial[g * record + i], i < n_out */
+    float* out[3]; int32_t n[3];    /* element i < n[0] goes to out[0][i], the next n[1] to out[1], the rest to out[2] (unused: NULL / 0) */
+    /* optional float64 statistics, statistic-major [n_stat][groups] at (partial + stat_base): statistic k < n_ls is added (+ entropy_coef) to
+     * grad_logstd[k], the others to stats[k - n_ls]; bit k of stat_skip skips statistic k */
+    uint64_t stat_base; int32_t n_stat, n_ls; uint32_t stat_skip; double entropy_coef; double* grad_logstd; double* stats;
+} bg_reduce_problem;
+int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stream); /* count <= 8 */
+/* bg_actor_head mode 1 / bg_critic_head_backward / bg_mlp_layer_backward without their finishing launch: same arguments, plus the descriptor
+ * of the reduction that produces grad_W, grad_b, grad_b_hidden, grad_logstd, stats / bias_grad_below when handed to bg_reduce_group. */
+int bg_actor_head_partial(int32_t B, const float* h, const float* W, const float* bias, const float* logstd, const float* actions,
+                          const float* old_mu, const float* old_logstd, const float* old_logp, const float* adv, const double* adv_stats, float e_clip,
+                          float bound_coef, float entropy_coef, float* mu_out, float* g_hidden, float* grad_W, float* grad_b, float* grad_b_hidden,
+                          double* grad_logstd, double* stats, float* scratch, bg_reduce_problem* finish, void* stream);
+int bg_critic_head_backward_partial(int32_t B, const float* h, const float* w, const float* values, const float* returns, float* g_hidden,
+                                    float* grad_w, float* grad_b, float* grad_b_hidden, double* stats, float* scratch, bg_reduce_problem* finish,
+                                    void* stream);
+int bg_mlp_layer_backward_partial(int32_t M, int32_t K, int32_t N, const float* G, const float* Wt, const float* act_below, float* Gout,
+                                  float* bias_grad_below, float* scratch, bg_reduce_problem* finish, void* stream);
+
 const char* bg_last_error(void);
 const char* bg_version(void);
 

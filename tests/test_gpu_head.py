@@ -108,3 +108,58 @@ def test_head_results_are_run_to_run_deterministic():
         outs.append((g_hidden.clone(), dw.clone(), db.clone(), dbh.clone()))
     for a, b2 in zip(*outs):
         assert torch.equal(a, b2)
+
+
+def test_deferred_reductions_equal_the_immediate_finishes():
+    """bg_actor_head_partial / bg_critic_head_backward_partial / bg_mlp_layer_backward_partial + ONE bg_reduce_group launch against the
+    immediate forms (main kernel + its own finish launch): the heads' sums are added in the same fixed order -> bit-equal, float64 statistics
+    and grad_logstd equal; the backward layer's column sums are added in another (fixed) order -> 1e-5 of the largest entry.  dL/dz outputs
+    of the main kernels are untouched by the deferral."""
+    from booster_gym_amd import _lib
+    from booster_gym_amd.utils.utils import actor_head_loss_backward, critic_head_backward, head_scratch, reduce_group
+
+    B, A = 98304, 12
+    g, dev, h, W, b = _data(B, 4)
+    logstd = torch.full((A,), -2.0, device=dev) + 0.1 * torch.randn(A, generator=g).to(dev)
+    old_logstd = torch.full((A,), -2.0, device=dev)
+    old_mu = h @ W.t() + b + 0.02 * torch.randn(B, A, generator=g).to(dev)
+    actions = old_mu + 0.135 * torch.randn(B, A, generator=g).to(dev)
+    old_logp = (-0.5 * ((actions - old_mu) / old_logstd.exp()) ** 2 - old_logstd - 0.9189385332046727).sum(-1)
+    adv = torch.randn(B, generator=g).to(dev)
+    adv_stats = torch.stack([adv.double().sum(), (adv.double() ** 2).sum(), torch.tensor(float(B), dtype=torch.float64, device=dev)])
+    values, returns = torch.randn(B, generator=g).to(dev), torch.randn(B, generator=g).to(dev)
+    w1 = W[:1].contiguous()
+    # a backward layer 256 -> 128 (K = 256 columns of G, N = 128)
+    G = torch.randn(B, 256, generator=g).to(dev); Wt = (torch.randn(128, 256, generator=g) * 0.05).to(dev); act = torch.nn.functional.elu(torch.randn(B, 128, generator=g)).to(dev)
+
+    def run(defer):
+        out = {}
+        fa, fc, fl = (_lib.ReduceProblem(), _lib.ReduceProblem(), _lib.ReduceProblem()) if defer else (None, None, None)
+        gh_a, dW, db, dbh = torch.empty(B, 128, device=dev), torch.full((A, 128), float("nan"), device=dev), torch.full((A,), float("nan"), device=dev), torch.full((128,), float("nan"), device=dev)
+        gls, st = torch.zeros(A, dtype=torch.float64, device=dev), torch.zeros(5, dtype=torch.float64, device=dev)
+        sa, sc = head_scratch(dev), head_scratch(dev)
+        actor_head_loss_backward(h, W, b, logstd, actions, old_mu, old_logstd, old_logp, adv, adv_stats, 0.2, 1.0, -0.01, gh_a, dW, db, dbh, gls, st, sa, finish=fa)
+        gh_c, dw, dbc, dbhc = torch.empty(B, 128, device=dev), torch.full((1, 128), float("nan"), device=dev), torch.full((1,), float("nan"), device=dev), torch.full((128,), float("nan"), device=dev)
+        critic_head_backward(h, w1, values, returns, gh_c, dw, dbc, dbhc, st, sc, finish=fc)
+        Gout, bg, scr = torch.empty(B, 128, device=dev), torch.full((128,), float("nan"), device=dev), torch.empty((B + 127) // 128 * 128, device=dev)
+        lib = _lib.load()
+        if defer:
+            _lib.check(lib.bg_mlp_layer_backward_partial(B, 256, 128, _lib.ptr(G), _lib.ptr(Wt), _lib.ptr(act), _lib.ptr(Gout), _lib.ptr(bg), _lib.ptr(scr), fl,
+                                                         _lib.current_stream_ptr()), "bg_mlp_layer_backward_partial")
+            assert torch.isnan(dW).all() and torch.isnan(bg).all() and (st == 0).all()  # nothing reduced yet
+            reduce_group([fa, fc, fl])
+        else:
+            _lib.check(lib.bg_mlp_layer_backward(B, 256, 128, _lib.ptr(G), _lib.ptr(Wt), _lib.ptr(act), _lib.ptr(Gout), _lib.ptr(bg), _lib.ptr(scr),
+                                                 _lib.current_stream_ptr()), "bg_mlp_layer_backward")
+        torch.cuda.synchronize()
+        return dict(gh_a=gh_a, dW=dW, db=db, dbh=dbh, gls=gls, st=st, gh_c=gh_c, dw=dw, dbc=dbc, dbhc=dbhc, Gout=Gout, bg=bg)
+
+    now, later = run(False), run(True)
+    for k in ("gh_a", "dW", "db", "dbh", "gh_c", "dw", "dbc", "dbhc", "Gout"):
+        assert torch.equal(now[k], later[k]), k
+    assert torch.allclose(now["gls"], later["gls"], rtol=1e-12, atol=0) and torch.allclose(now["st"], later["st"], rtol=1e-12, atol=0)
+    assert (now["bg"] - later["bg"]).abs().max() <= 1e-5 * now["bg"].abs().max() and torch.isfinite(later["bg"]).all()
+    # argument errors
+    assert _lib.load().bg_reduce_group(None, 1, None) == -1
+    bad = _lib.ReduceProblem()
+    assert _lib.load().bg_reduce_group((_lib.ReduceProblem * 1)(bad), 1, None) == -1
