@@ -18,6 +18,16 @@
 #pragma once
 #include "bg_math.h"
 
+// Instruction census (tools/isa_census.py builds with -DBG_ISA_PHASES): named markers that the scheduler may not move code across, so that
+// the VALU instructions of the emitted ISA can be attributed to the phases of the algorithm.  No effect on the product build.
+#if defined(BG_ISA_PHASES) && defined(__HIP_DEVICE_COMPILE__)
+#define BG_PHASE(name) do { __builtin_amdgcn_sched_barrier(0); asm volatile("; BG_PHASE " name); __builtin_amdgcn_sched_barrier(0); } while (0)
+#define BG_PIN1(x) asm volatile("" : "+v"(x))   // the value exists HERE: what produces it cannot sink below, what uses it cannot rise above
+#else
+#define BG_PHASE(name) do { } while (0)
+#define BG_PIN1(x) do { } while (0)
+#endif
+
 namespace bg {
 
 constexpr int LEG_LINKS = 6;
@@ -39,6 +49,11 @@ struct Phys {
     int clamp_qd;
     // non-foot body contacts (explicit penalty on the contact spheres of the trunk box / hip-yaw and shank cylinders)
     float body_gate, body_kn, body_dn, body_mu;
+    // bit i: the origin of leg link i lies on the z axis of its parent's frame (pos = (0, 0, z)) in BOTH legs -- true for the T1's hip-roll,
+    // hip-yaw and ankle-pitch links.  Wave-uniform, so the sweeps branch on it at no cost and run their r-dependent parts (cross products with
+    // the link position, the shift of the articulated inertia) with the two zero components folded away: 46 VALU instructions per such link.
+    // 0 = the general code for every link.
+    int zmask;
     // leg against leg (explicit penalty between the shank / foot capsules of the two legs)
     int self_on;
     float self_k, self_d, self_mu, self_visc;
@@ -91,6 +106,9 @@ typedef __attribute__((address_space(3))) float lds_f32;  // explicit LDS pointe
 typedef float lds_f32;
 #endif
 struct RegStore {
+    // the z-axis specialisation of the sweeps (Phys::zmask) is off here: this store serves the fused env step, one wave per SIMD and latency-bound,
+    // where the extra (wave-uniform) branches split the blocks the scheduler overlaps work in: 107.7 -> 109.3 us per env step with it on (measured)
+    static constexpr bool ZSPEC = false;
     SV v[LEG_LINKS], cb[LEG_LINKS], U[LEG_LINKS];
     template <int I> BG_HD void put_v(SV x) { v[I] = x; }
     template <int I> BG_HD SV get_v() const { return v[I]; }
@@ -103,6 +121,7 @@ struct RegStore {
 };
 // v / cb / U in registers, the per-env link constants (13 floats per link, computed once per launch) in LDS
 struct LdsLinkStore : RegStore {
+    static constexpr bool ZSPEC = true;  // the ABA kernel: throughput-bound (two waves per SIMD), fewer issued instructions pay directly
     static constexpr int SLOTS = 13 * LEG_LINKS, STRIDE = 64;
     lds_f32* p;
     template <class LP> BG_HD void stash(const LP& lp) const {
@@ -132,6 +151,7 @@ struct LdsLinkStore : RegStore {
 template <class Store>
 struct LegWorkT {  // what the inward sweep leaves behind for the outward sweep
     float c[LEG_LINKS], s[LEG_LINKS];
+    int zmask;         // Phys::zmask, for the sweeps that do not see Phys
     Store st;
     float dinv[LEG_LINKS], u[LEG_LINKS];
     M3 Rfoot;          // foot -> world
@@ -149,6 +169,11 @@ struct LegWorkT {  // what the inward sweep leaves behind for the outward sweep
 using LegWork = LegWorkT<RegStore>;
 
 struct BaseContribution { SI I; SV p; };  // articulated inertia / bias force seen at the trunk
+BG_HD void bg_pin(V3& v) { for (int a = 0; a < 3; a++) BG_PIN1(v.e[a]); }
+BG_HD void bg_pin(SV& v) { bg_pin(v.a); bg_pin(v.l); }
+BG_HD void bg_pin(M3& m) { for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) BG_PIN1(m.e[a][b]); }
+BG_HD void bg_pin(S3& m) { for (int a = 0; a < 6; a++) BG_PIN1(m.e[a]); }
+BG_HD void bg_pin(SI& i) { bg_pin(i.A); bg_pin(i.H); bg_pin(i.M); }
 
 BG_HD SI rigid_inertia(const LinkConst& k) {
     SI I;
@@ -181,6 +206,9 @@ BG_HD SV crf(SV v, SV f) {
 
 // bilinear terrain height and surface normal (reference utils/terrain.py:101-121; indices clamped)
 BG_HD void terrain_query(const TerrainDev& t, float x, float y, float* h, V3* n) {
+#ifdef BG_CENSUS_PLANE   // tools/isa_census.py --plane: count the instructions a launch on flat ground executes (the height-field branch is never taken there)
+    *h = 0.f; *n = v3(0.f, 0.f, 1.f); return;
+#endif
     if (t.type == 0) { *h = 0.f; *n = v3(0.f, 0.f, 1.f); return; }
     float px = (float)t.border_px + x * t.inv_hscale, py = (float)t.border_px + y * t.inv_hscale;
     int x1 = (int)floorf(px), y1 = (int)floorf(py);
@@ -271,6 +299,8 @@ BG_HD void leg_contact_prepass(const Phys& ph, const TerrainDev& tr, const Model
 template <int I, class W>
 BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M3 Rpar, V3 ppar, SV* vfoot, V3* pfoot) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    bg_pin(vpar); bg_pin(Rpar); bg_pin(ppar);
+    BG_PHASE("outward_link");
     float s, c;
     bg_sincos(ls.q[I], &s, &c);
     w.c[I] = c; w.s[I] = s;
@@ -278,7 +308,16 @@ BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M
     SV v;
     v.a = rotT<AX>(c, s, vpar.a);
     const V3 lpos = w.st.template link_pos<I>(lp);
-    v.l = rotT<AX>(c, s, vpar.l + cross(vpar.a, lpos));
+    V3 vlin, p;  // linear velocity of the link origin in parent coordinates, link origin relative to the trunk origin
+    if ((w.zmask >> I) & 1) {  // r = (0, 0, z): wave-uniform branch (Phys::zmask)
+        const V3 rz = v3(0.f, 0.f, lpos.e[2]);
+        vlin = vpar.l + cross(vpar.a, rz);
+        p = ppar + mul(Rpar, rz);
+    } else {
+        vlin = vpar.l + cross(vpar.a, lpos);
+        p = ppar + mul(Rpar, lpos);
+    }
+    v.l = rotT<AX>(c, s, vlin);
     // c_i = v_i x (S qd)   (S = unit angular axis A)
     V3 sq = v3(0.f, 0.f, 0.f); sq.e[A] = ls.qd[I];
     SV cb;
@@ -287,8 +326,7 @@ BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M
     w.st.template put_cb<I>(cb);
     v.a.e[A] += ls.qd[I];
     w.st.template put_v<I>(v);
-    // world pose of the link (needed for the foot only, carried down the chain)
-    V3 p = ppar + mul(Rpar, lpos);
+    // world-aligned pose of the link (for the foot and the self-collision capsules, carried down the chain)
     M3 R;  // R_world_child = R_world_parent * R(axis,q): rotate the columns J,K
     {
         constexpr int J = Plane<AX>::J, K = Plane<AX>::K;
@@ -443,46 +481,60 @@ BG_HD void self_contacts(const Phys& ph, const ModelDev& M, int leg, W& w, const
 // ---------------------------------------------------------------- foot contact (4 sole corners)
 template <class W>
 BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& lp, W& w, SV vfoot, V3 pfoot, V3* force_w0) {
-    SI B; B.A = s3_zero(); B.H = m3_zero(); B.M = s3_zero();
+    bg_pin(vfoot); bg_pin(pfoot); bg_pin(w.Rfoot);
+    BG_PHASE("foot_contact");
+    // Everything after the terrain query is done in FOOT coordinates (normal and velocities rotated once; the friction law only needs norms
+    // and the normal component, which do not depend on the frame).  With C = alpha nb nb^T + beta 1 (alpha = cn - ctt, beta = ctt) and the
+    // corner at r, the impedance B = J^T C J, J = [-rx 1], is
+    //     M += alpha nb nb^T + beta 1,   H += alpha m nb^T + beta rx,   A += alpha m m^T + beta (|r|^2 1 - r r^T),   m = r x nb,
+    // so a corner costs three rank-1 updates (two of them symmetric) instead of two 3x3 cross-column products; the beta terms are summed
+    // over the corners first (sb = sum beta, sr = sum beta r, P = sum beta r r^T) and added once.
+    S3 BM = s3_zero(), BA = s3_zero(), P = s3_zero();
+    M3 BH = m3_zero();
     SV f0 = sv_zero();
-    V3 fw_sum = v3(0.f, 0.f, 0.f);
+    V3 sr = v3(0.f, 0.f, 0.f);
+    float sb = 0.f;
     bool any = false;
     for (int k = 0; k < 4; k++) {
-        V3 r = lp.corner[k];
-        V3 xw = pfoot + mul(w.Rfoot, r);
-        V3 vb = vfoot.l + cross(vfoot.a, r);
-        V3 vw = mul(w.Rfoot, vb);
+        const V3 r = lp.corner[k];
+        const V3 xw = pfoot + mul(w.Rfoot, r);
+        const V3 vb = vfoot.l + cross(vfoot.a, r);
         float h; V3 n;
         terrain_query(tr, xw.e[0], xw.e[1], &h, &n);
-        float pen = (h - xw.e[2]) * n.e[2];
-        float vn = dot(vw, n);
-        float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
-        float d_eff = lp.dn * ramp;
-        float fn0 = lp.kn * pen - d_eff * vn;
+        const V3 nb = mulT(w.Rfoot, n);
+        const float pen = (h - xw.e[2]) * n.e[2];
+        const float vn = dot(vb, nb);
+        const float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
+        const float d_eff = lp.dn * ramp;
+        const float fn0 = lp.kn * pen - d_eff * vn;
         if (pen > 0.f && fn0 > 0.f) {
             any = true;
-            V3 vt = vw - vn * n;
-            float vtn = bg_sqrt(dot(vt, vt));
-            float c_t = fminf(ph.friction_visc, lp.mu * fn0 * bg_rcp(vtn + 1e-6f));
-            V3 fw = fn0 * n - c_t * vt;
-            fw_sum = fw_sum + fw;
-            V3 nb = mulT(w.Rfoot, n), fb = mulT(w.Rfoot, fw);
-            float cn = ph.dt * (d_eff + ph.dt * lp.kn), ctt = ph.dt * c_t;
-            M3 C = outer((cn - ctt) * nb, nb);
-            C.e[0][0] += ctt; C.e[1][1] += ctt; C.e[2][2] += ctt;
-            // wrench J^T f = (r x f, f);  B = J^T C J = [-rx C rx, rx C; -C rx, C]
-            f0.a = f0.a + cross(r, fb);
+            const V3 vt = vb - vn * nb;
+            const float c_t = fminf(ph.friction_visc, lp.mu * fn0 * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
+            const V3 fb = fn0 * nb - c_t * vt;
+            const float beta = ph.dt * c_t, alpha = ph.dt * (d_eff + ph.dt * lp.kn) - beta;
             f0.l = f0.l + fb;
-            M3 rC = cross_cols(r, C);          // rx C
-            M3 rCr = mul_skew(rC, r);           // rx C rx
-            B.M = B.M + upper(C);
-            B.H = B.H + rC;
-            S3 a = upper(rCr);
-            for (int i = 0; i < 6; i++) B.A.e[i] -= a.e[i];
+            f0.a = f0.a + cross(r, fb);
+            const V3 m = cross(r, nb), an = alpha * nb, am = alpha * m, br = beta * r;
+            BM.e[0] += an.e[0] * nb.e[0]; BM.e[1] += an.e[1] * nb.e[1]; BM.e[2] += an.e[2] * nb.e[2];
+            BM.e[3] += an.e[0] * nb.e[1]; BM.e[4] += an.e[0] * nb.e[2]; BM.e[5] += an.e[1] * nb.e[2];
+            BA.e[0] += am.e[0] * m.e[0]; BA.e[1] += am.e[1] * m.e[1]; BA.e[2] += am.e[2] * m.e[2];
+            BA.e[3] += am.e[0] * m.e[1]; BA.e[4] += am.e[0] * m.e[2]; BA.e[5] += am.e[1] * m.e[2];
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) BH.e[i][j] += am.e[i] * nb.e[j];
+            P.e[0] += br.e[0] * r.e[0]; P.e[1] += br.e[1] * r.e[1]; P.e[2] += br.e[2] * r.e[2];
+            P.e[3] += br.e[0] * r.e[1]; P.e[4] += br.e[0] * r.e[2]; P.e[5] += br.e[1] * r.e[2];
+            sr = sr + br;
+            sb += beta;
         }
     }
+    const float trP = P.e[0] + P.e[1] + P.e[2];
+    SI B;
+    B.M = BM; B.M.e[0] += sb; B.M.e[1] += sb; B.M.e[2] += sb;
+    B.H = BH + skew(sr);
+    B.A.e[0] = BA.e[0] + trP - P.e[0]; B.A.e[1] = BA.e[1] + trP - P.e[1]; B.A.e[2] = BA.e[2] + trP - P.e[2];
+    B.A.e[3] = BA.e[3] - P.e[3]; B.A.e[4] = BA.e[4] - P.e[4]; B.A.e[5] = BA.e[5] - P.e[5];
     w.Bc = B; w.f0c = f0; w.contact = any;
-    *force_w0 = fw_sum;
+    *force_w0 = v3(0.f, 0.f, 0.f);  // (the force that acts over the step comes out of substep_solve: f0 - B a)
 }
 
 // ---------------------------------------------------------------- inward sweep, link I (child -> parent)
@@ -490,12 +542,14 @@ template <int I, class W>
 BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, const float* tau, W& w, SI IA, SV pA,
                       BaseContribution* out, const SV* fext) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    bg_pin(IA); bg_pin(pA);
+    BG_PHASE("inward_link");
     // joint limit spring/damper, implicit in the joint velocity: tau_lim = t0 - bl * qdd
     float viol = ls.q[I] < lp.q_lo[I] ? ls.q[I] - lp.q_lo[I] : (ls.q[I] > lp.q_hi[I] ? ls.q[I] - lp.q_hi[I] : 0.f);
     float t0 = 0.f, bl = 0.f;
     if (viol != 0.f) { t0 = -ph.limit_k * viol - ph.limit_d * ls.qd[I]; bl = ph.dt * (ph.limit_d + ph.dt * ph.limit_k); }
-    // U = IA S ; d = S.U + bl ; u = tau - S.pA
-    M3 Af = full(IA.A), Mf = full(IA.M);
+    // U = IA S ; d = S.U + bl ; u = tau - S.pA     (S = the unit angular axis A: U is a column of [A; H^T])
+    const M3 Af = full(IA.A);
     SV U;
     U.a = v3(Af.e[0][A], Af.e[1][A], Af.e[2][A]);
     U.l = v3(IA.H.e[A][0], IA.H.e[A][1], IA.H.e[A][2]);
@@ -503,22 +557,40 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
     float dinv = bg_rcp(d);
     float u = tau[I] + t0 - pA.a.e[A];
     w.dinv[I] = dinv; w.u[I] = u;
-    // Ia = IA - U U^T / d ;  pa = pA + Ia c + U u / d
-    V3 Uad = dinv * U.a, Uld = dinv * U.l;
-    M3 A1 = Af - outer(Uad, U.a), H1 = IA.H - outer(Uad, U.l), M1 = Mf - outer(Uld, U.l);
+    // Ia = IA - U U^T / d ;  pa = pA + Ia c + U u / d.   A and M stay SYMMETRIC through the update, the rotation and the shift: only their six
+    // unique entries are computed (the compiler cannot see the symmetry of a full 3x3 and computed all nine)
+    const V3 Uad = dinv * U.a, Uld = dinv * U.l;
+    S3 A1, M1;
+    A1.e[0] = IA.A.e[0] - Uad.e[0] * U.a.e[0]; A1.e[1] = IA.A.e[1] - Uad.e[1] * U.a.e[1]; A1.e[2] = IA.A.e[2] - Uad.e[2] * U.a.e[2];
+    A1.e[3] = IA.A.e[3] - Uad.e[0] * U.a.e[1]; A1.e[4] = IA.A.e[4] - Uad.e[0] * U.a.e[2]; A1.e[5] = IA.A.e[5] - Uad.e[1] * U.a.e[2];
+    M1.e[0] = IA.M.e[0] - Uld.e[0] * U.l.e[0]; M1.e[1] = IA.M.e[1] - Uld.e[1] * U.l.e[1]; M1.e[2] = IA.M.e[2] - Uld.e[2] * U.l.e[2];
+    M1.e[3] = IA.M.e[3] - Uld.e[0] * U.l.e[1]; M1.e[4] = IA.M.e[4] - Uld.e[0] * U.l.e[2]; M1.e[5] = IA.M.e[5] - Uld.e[1] * U.l.e[2];
+    M3 H1 = IA.H - outer(Uad, U.l);
     SV cb = w.st.template get_cb<I>();
     SV pa;
     pa.a = pA.a + mul(A1, cb.a) + mul(H1, cb.l) + u * Uad;
     pa.l = pA.l + mulT(H1, cb.a) + mul(M1, cb.l) + u * Uld;
     // to parent coordinates: rotate by R(axis,q) then shift the origin by r = pos
     float c = w.c[I], s = w.s[I];
-    A1 = rot_conj<AX>(c, s, A1); H1 = rot_conj<AX>(c, s, H1); M1 = rot_conj<AX>(c, s, M1);
-    V3 r = w.st.template link_pos<I>(lp);
-    M3 H2 = H1 + cross_cols(r, M1);
-    M3 A2 = A1 + cross_cols(r, transpose(H1)) - mul_skew(H2, r);
+    const float c2 = c * c - s * s, s2 = 2.0f * c * s;
+    A1 = rot_conj_sym<AX>(c, s, c2, s2, A1); M1 = rot_conj_sym<AX>(c, s, c2, s2, M1);
+    H1 = rot_conj<AX>(c, s, H1);
+    const V3 r0 = w.st.template link_pos<I>(lp);
+    const M3 M1f = full(M1);
+    M3 H2, A2;
     SV pp;
     pp.l = rot<AX>(c, s, pa.l);
-    pp.a = rot<AX>(c, s, pa.a) + cross(r, pp.l);
+    if ((w.zmask >> I) & 1) {  // r = (0, 0, z): wave-uniform branch (Phys::zmask)
+        const V3 r = v3(0.f, 0.f, r0.e[2]);
+        H2 = H1 + cross_cols(r, M1f);
+        A2 = full(A1) + cross_cols(r, transpose(H1)) - mul_skew(H2, r);
+        pp.a = rot<AX>(c, s, pa.a) + cross(r, pp.l);
+    } else {
+        const V3 r = r0;
+        H2 = H1 + cross_cols(r, M1f);
+        A2 = full(A1) + cross_cols(r, transpose(H1)) - mul_skew(H2, r);
+        pp.a = rot<AX>(c, s, pa.a) + cross(r, pp.l);
+    }
     if constexpr (I > 0) {
         // parent's own rigid inertia and velocity-dependent bias
         const LinkConst pk = w.st.template link<I - 1>(lp);
@@ -527,11 +599,11 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
         w.st.template put_U<I>(U);
         SV pP = crf(vp, mul_rigid(pk, vp));
         if (fext) pP = pP - fext[I - 1];
-        IP.A = IP.A + upper(A2); IP.H = IP.H + H2; IP.M = IP.M + upper(M1);
+        IP.A = IP.A + upper(A2); IP.H = IP.H + H2; IP.M = IP.M + M1;
         leg_inward<I - 1>(ph, lp, ls, tau, w, IP, pP + pp, out, fext);
     } else {
         w.st.template put_U<I>(U);
-        out->I.A = upper(A2); out->I.H = H2; out->I.M = upper(M1);
+        out->I.A = upper(A2); out->I.H = H2; out->I.M = M1;
         out->p = pp;
     }
 }
@@ -542,16 +614,23 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
 template <int SELF, class W, class X>
 BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int leg, const LegParams& lp, const LegState& ls, const float* tau,
                                   const BaseState& bs, M3 R0, SV v0, W& w, X& x, V3* foot_force_w0, const SV* fext_in = nullptr) {
+    w.zmask = decltype(w.st)::ZSPEC ? ph.zmask : 0;
+#ifdef BG_CENSUS_ZMASK   // tools/isa_census.py --t1: count what a T1 launch executes (the wave-uniform branches on zmask resolved at compile time)
+    w.zmask = BG_CENSUS_ZMASK;
+#endif
     SV vfoot;
     V3 pfoot_rel;  // link origins are carried RELATIVE to the trunk origin: the leg-against-leg distances must not lose digits to the world position
     leg_outward<0>(lp, ls, w, v0, R0, v3(0.f, 0.f, 0.f), &vfoot, &pfoot_rel);
     const V3 pfoot = bs.pos + pfoot_rel;
+    BG_PHASE("self_clearance");
     self_contacts<SELF>(ph, M, leg, w, R0, pfoot_rel, vfoot, x);
     SV fext[LEG_LINKS];  // applied wrenches per link: the caller's, plus the leg-against-leg contacts on the shank and the foot
     for (int i = 0; i < LEG_LINKS; i++) fext[i] = fext_in ? fext_in[i] : sv_zero();
     fext[SELF_SHANK] = fext[SELF_SHANK] + w.self_fx[0];
     fext[SELF_FOOT] = fext[SELF_FOOT] + w.self_fx[1];
     foot_contact(ph, tr, lp, w, vfoot, pfoot, foot_force_w0);
+    bg_pin(w.Bc); bg_pin(w.f0c);
+    BG_PHASE("foot_inertia_bias");
     const LinkConst fk = w.st.template link<LEG_LINKS - 1>(lp);
     SI IA = rigid_inertia(fk);
     SV pA = crf(vfoot, mul_rigid(fk, vfoot));
@@ -585,10 +664,16 @@ BG_HD SV base_solve(const SI& I, SV p) {
 template <int I, class W>
 BG_HD void leg_accel(const Phys& ph, const LegParams& lp, LegState& ls, const W& w, SV apar, float* qdd, SV* afoot) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
+    bg_pin(apar);
+    BG_PHASE("accel_link");
     float c = w.c[I], s = w.s[I];
     SV a;
     a.a = rotT<AX>(c, s, apar.a);
-    a.l = rotT<AX>(c, s, apar.l + cross(apar.a, w.st.template link_pos<I>(lp)));
+    const V3 lpos = w.st.template link_pos<I>(lp);
+    V3 alin;
+    if ((w.zmask >> I) & 1) alin = apar.l + cross(apar.a, v3(0.f, 0.f, lpos.e[2]));  // r = (0, 0, z): wave-uniform branch (Phys::zmask)
+    else alin = apar.l + cross(apar.a, lpos);
+    a.l = rotT<AX>(c, s, alin);
     a = a + w.st.template get_cb<I>();
     float qa = (w.u[I] - dot(w.st.template get_U<I>(), a)) * w.dinv[I];
     a.a.e[A] += qa;
@@ -769,6 +854,7 @@ BG_HD bool body_contacts_active(const Phys& ph, const TerrainDev& tr, const Mode
 template <bool BODY, int SELF = SELF_INLINE, class Ctx, class X>
 BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int leg, const LegParams& lp, const LegState& ls,
                                    const float* tau, const BaseState& bs, Ctx& cx, X& x, const SV* fext = nullptr, BodyContactOut* bo = nullptr) {
+    BG_PHASE("base_kinematics");
     cx.R0 = quat_to_mat(bs.quat);
     cx.v0 = base_body_velocity(cx.R0, bs);
     V3 unused;
@@ -802,11 +888,14 @@ BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const M
 template <class Ctx>
 BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& lp, LegState& ls, const Ctx& cx, const BaseContribution& both,
                          SV wrench, float* qdd, V3* lin_w, V3* ang_w, V3* foot_force_w) {
+    BG_PHASE("base_solve");
     BaseContribution own = base_own(bk, cx.v0, wrench);
     SI I; I.A = own.I.A + both.I.A; I.H = own.I.H + both.I.H; I.M = own.I.M + both.I.M;
     SV a0p = base_solve(I, own.p + both.p);
     SV afoot;
     leg_accel<0>(ph, lp, ls, cx.w, a0p, qdd, &afoot);
+    bg_pin(afoot); bg_pin(a0p);
+    BG_PHASE("rates_and_foot_force");
     base_world_rates(cx.R0, cx.v0, a0p, ph.g, lin_w, ang_w);
     V3 fw = v3(0.f, 0.f, 0.f);
     if (cx.w.contact) {  // force that acts over the step: f0 - B a_true

@@ -75,6 +75,7 @@ struct EnvDev {
     float* stats;  // [STATS_COUNT], atomics
     float* curr;   // curriculum_prob running sums [(2L+1)*(2A+1)], atomics
     const float* curr_read;  // snapshot taken before this launch: what the samplers read (deterministic)
+    int zmask;               // Phys::zmask of this model (which leg links sit on their parent's z axis)
     const ModelDev* model;
     TerrainDev terrain;
     bg_env_cfg cfg;
@@ -165,6 +166,7 @@ BG_HD Phys make_phys(const bg_env_cfg& c) {
     // non-foot shapes: default material (friction 1, restitution 0) averaged with the terrain's, nominal stiffness / damping
     ph.body_gate = c.body_gate_height; ph.body_kn = c.contact_k; ph.body_dn = c.contact_d * (1.0f - 0.5f * c.terrain_restitution);
     ph.body_mu = 0.5f * (1.0f + c.terrain_mu);
+    ph.zmask = 0;  // callers that run the sweeps set it from EnvDev::zmask
     ph.self_on = c.self_collisions; ph.self_k = c.self_k; ph.self_d = c.self_d; ph.self_mu = c.self_mu; ph.self_visc = c.self_visc;
     return ph;
 }
@@ -221,6 +223,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
     const int j0 = leg * LEG_LINKS;
     const float dt_env = C.sim_dt * (float)C.decimation;
     Phys ph = make_phys(C);
+    ph.zmask = E.zmask;
     ContactCfg cc = make_contact_cfg(C);
 
     // ------------------------------------------------------------ load

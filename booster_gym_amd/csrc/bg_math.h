@@ -159,6 +159,23 @@ template <int AX> BG_HD M3 rot_conj(float c, float s, M3 m) {
     return o;
 }
 
+// R s R^T for a SYMMETRIC s: the axis entry stays, the two entries that couple the axis with the rotated plane turn like a 2-vector, and
+// the 2x2 block of the plane turns by the double angle -- 14 operations (+ 3 for c2, s2, shared by the caller) against 24 for a full matrix
+BG_HD constexpr int s3_index(int i, int j) { return i == j ? i : (i + j == 1 ? 3 : (i + j == 2 ? 4 : 5)); }  // xx yy zz xy xz yz
+template <int AX> BG_HD S3 rot_conj_sym(float c, float s, float c2, float s2, S3 m) {
+    constexpr int J = Plane<AX>::J, K = Plane<AX>::K, A = Plane<AX>::A;
+    constexpr int JJ = s3_index(J, J), KK = s3_index(K, K), JK = s3_index(J, K), AJ = s3_index(A, J), AK = s3_index(A, K);
+    S3 o = m;
+    o.e[AJ] = c * m.e[AJ] - s * m.e[AK];
+    o.e[AK] = s * m.e[AJ] + c * m.e[AK];
+    const float mean = 0.5f * (m.e[JJ] + m.e[KK]), dev = 0.5f * (m.e[JJ] - m.e[KK]);
+    const float t = dev * c2 - m.e[JK] * s2;
+    o.e[JJ] = mean + t;
+    o.e[KK] = mean - t;
+    o.e[JK] = dev * s2 + m.e[JK] * c2;
+    return o;
+}
+
 // quaternion xyzw (Isaac Gym convention, t1.py:221) -> body-to-world rotation
 BG_HD M3 quat_to_mat(const float q[4]) {
     float x = q[0], y = q[1], z = q[2], w = q[3];

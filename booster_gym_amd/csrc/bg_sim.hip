@@ -49,6 +49,7 @@ struct bg_env {
     TerrainDev terrain;
     StepOut bound;
     int64_t step_count = 0;
+    int zmask = 0;  // Phys::zmask: leg links whose origin lies on the parent's z axis in both legs
     // granular simulator calls (bg_sim_*): caller-owned Isaac-layout tensors + this library's copies of the last actuation / applied forces
     float *sim_root = nullptr, *sim_dof = nullptr, *sim_contact = nullptr, *sim_body = nullptr;
     float *sim_tau = nullptr, *sim_bforce = nullptr, *sim_btorque = nullptr;
@@ -243,7 +244,9 @@ __device__ __forceinline__ bool forward_dynamics_lane(const EnvDev& E, int e, bo
                                                       const float* __restrict__ wrench, float* __restrict__ qacc) {
     const int lane = threadIdx.x, leg = lane & 1;
     const int n = E.n;
+    BG_PHASE("load_state_and_link_constants");
     Phys ph = make_phys(E.cfg);
+    ph.zmask = E.zmask;
     ContactCfg cc = make_contact_cfg(E.cfg);
     BaseState bs;
     const float* r = root + (size_t)e * 13;
@@ -266,12 +269,16 @@ __device__ __forceinline__ bool forward_dynamics_lane(const EnvDev& E, int e, bo
     cx.w.st.stash(lp);
     BaseContribution mine = substep_pre<BODY, SELF>(ph, E.terrain, *E.model, leg, lp, ls, t6, bs, cx, x), both;
     if constexpr (SELF == SELF_DEFER) { if (cx.w.self_deferred) return true; }  // the legs can meet: the second kernel's env (both lanes agree)
+    bg_pin(mine.I); bg_pin(mine.p);
+    BG_PHASE("pair_exchange");
     for (int k = 0; k < 6; k++) { both.I.A.e[k] = mine.I.A.e[k] + x.swap(mine.I.A.e[k]); both.I.M.e[k] = mine.I.M.e[k] + x.swap(mine.I.M.e[k]); }
     for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) both.I.H.e[a][b] = mine.I.H.e[a][b] + x.swap(mine.I.H.e[a][b]);
     for (int k = 0; k < 3; k++) { both.p.a.e[k] = mine.p.a.e[k] + x.swap(mine.p.a.e[k]); both.p.l.e[k] = mine.p.l.e[k] + x.swap(mine.p.l.e[k]); }
     float qdd[LEG_LINKS];
     V3 lin_w, ang_w, fw;
     substep_solve(ph, bk, lp, ls, cx, both, wr, qdd, &lin_w, &ang_w, &fw);
+    bg_pin(lin_w); bg_pin(ang_w); bg_pin(fw);
+    BG_PHASE("store");
     if (!valid) return false;
     float* o = qacc + (size_t)e * 18;
     if (leg == 0) for (int a = 0; a < 3; a++) { o[a] = lin_w.e[a]; o[3 + a] = ang_w.e[a]; }
@@ -398,6 +405,7 @@ __device__ __forceinline__ void sim_substep_lane(const EnvDev& E, int e, bool va
                                                  float* __restrict__ contact, float* __restrict__ body) {
     const int lane = threadIdx.x, leg = lane & 1;
     Phys ph = make_phys(E.cfg);
+    ph.zmask = E.zmask;
     SimLane L;
     sim_load(E, e, leg, root, dof, L);
     float t6[LEG_LINKS];
@@ -596,6 +604,7 @@ extern "C" void bg_model_destroy(bg_model* m) { delete m; }
 // ------------------------------------------------------------------ ABI: env
 static EnvDev env_dev(const bg_env* e) {
     EnvDev E;
+    E.zmask = e->zmask;
     E.f = e->f; E.h = e->h; E.i = e->i; E.stats = e->stats; E.curr = e->curr; E.curr_read = e->curr_read; E.model = e->model_dev; E.terrain = e->terrain; E.cfg = e->cfg; E.n = e->n;
     return E;
 }
@@ -643,6 +652,12 @@ static int env_create_fill(bg_env* e, const bg_env_cfg* cfg, const bg_model* mod
         if (md.sph_cnt[b]++ == 0) md.sph_first[b] = k;
         md.sph_r[k] = model->desc.sphere_radius[k];
         for (int a = 0; a < 3; a++) md.sph_pos[k][a] = model->desc.sphere_pos[k][a];
+    }
+    e->zmask = 0;
+    for (int i = 0; i < 6; i++) {
+        bool z = true;
+        for (int leg = 0; leg < 2; leg++) z = z && model->desc.body_pos[1 + 6 * leg + i][0] == 0.f && model->desc.body_pos[1 + 6 * leg + i][1] == 0.f;
+        if (z) e->zmask |= 1 << i;
     }
     bool caps = true;
     for (int leg = 0; leg < 2; leg++)

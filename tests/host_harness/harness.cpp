@@ -8,7 +8,7 @@ using namespace bg;
 extern "C" {
 
 struct hh_cfg { float dt, g[3], contact_k, contact_d, contact_ramp, friction_visc, limit_k, limit_d, terrain_mu, terrain_restitution; int clamp_qd; float body_gate;
-                int self_on; float self_k, self_d, self_mu, self_visc; };
+                int self_on; float self_k, self_d, self_mu, self_visc; int zmask; };
 
 // Lane-pair exchange for a host that runs the two legs one after the other: every swap() records the value it is given and returns what the
 // partner recorded at the same position in the PREVIOUS pass (0 if there is none).  The caller repeats the two-leg pass until the tapes no
@@ -24,6 +24,7 @@ static void setup(const hh_cfg* c, Phys& ph, ContactCfg& cc) {
     ph.limit_k = c->limit_k; ph.limit_d = c->limit_d; ph.clamp_qd = c->clamp_qd;
     ph.body_gate = c->body_gate; ph.body_kn = c->contact_k; ph.body_dn = c->contact_d * (1.0f - 0.5f * c->terrain_restitution); ph.body_mu = 0.5f * (1.0f + c->terrain_mu);
     cc.k = c->contact_k; cc.d = c->contact_d; cc.terrain_mu = c->terrain_mu; cc.terrain_restitution = c->terrain_restitution;
+    ph.zmask = c->zmask;
     ph.self_on = c->self_on; ph.self_k = c->self_k; ph.self_d = c->self_d; ph.self_mu = c->self_mu; ph.self_visc = c->self_visc;
 }
 

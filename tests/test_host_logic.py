@@ -271,7 +271,7 @@ def test_product_dynamics_header_matches_oracle(harness, flat_model):
     class Cfg(C.Structure):
         _fields_ = [("dt", C.c_float), ("g", C.c_float * 3)] + [(k, C.c_float) for k in ("contact_k", "contact_d", "contact_ramp", "friction_visc", "limit_k", "limit_d",
                                                                                       "terrain_mu", "terrain_restitution")] + [("clamp_qd", C.c_int), ("body_gate", C.c_float), ("self_on", C.c_int)] + \
-                   [(k, C.c_float) for k in ("self_k", "self_d", "self_mu", "self_visc")]
+                   [(k, C.c_float) for k in ("self_k", "self_d", "self_mu", "self_visc")] + [("zmask", C.c_int)]
 
     class Terr(C.Structure):
         _fields_ = [("type", C.c_int), ("rows", C.c_int), ("cols", C.c_int), ("border_px", C.c_int), ("inv_hscale", C.c_float), ("vscale", C.c_float), ("hf", C.c_void_p)]
@@ -310,6 +310,9 @@ def test_product_dynamics_header_matches_oracle(harness, flat_model):
     cfg.self_on = 1
     for k in ("self_k", "self_d", "self_mu", "self_visc"):
         setattr(cfg, k, DEFAULT_PHYS[k])
+    # links whose origin lies on the parent's z axis in both legs take the kernels' specialised code (Phys::zmask); the T1: hip roll, hip yaw, ankle pitch
+    cfg.zmask = sum(1 << i for i in range(6) if all(m.body_pos[1 + 6 * leg + i, 0] == 0 and m.body_pos[1 + 6 * leg + i, 1] == 0 for leg in range(2)))
+    assert cfg.zmask == 0b010110
     for a in range(3):
         cfg.g[a] = DEFAULT_PHYS["g"][a]
     for k in ("contact_k", "contact_d", "contact_ramp", "friction_visc", "limit_k", "limit_d", "terrain_mu", "terrain_restitution"):
