@@ -52,7 +52,7 @@ ABA_BYTES = 4 * (13 + 12 + 12 + 12 + 6 + 18 + 6 + 58)  # forward_dynamics_kernel
 from booster_gym_amd import _lib  # noqa: E402  (raw ABI calls for the kernel-level timings)
 
 
-PMC_TAG = "r02"
+PMC_TAG = "r03"
 PMC_SOURCE = (f"profiles/{PMC_TAG}_bench_pmc.json / profiles/{PMC_TAG}_env_pmc.json: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes of "
               "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra` and `tools/prof_env.py 4096 plane` (tools/profile.sh); "
               "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE for the 16-byte-per-lane MFMA layer kernels (the guide's gfx950 correction), FETCH_SIZE + WRITE_SIZE otherwise")
@@ -69,38 +69,76 @@ def pmc_traffic(kernel_prefix, which="bench"):
         return None
 
 
+def _aba_pmc():
+    """Per-launch HBM bytes and VALU instructions per wave of the ABA launch's kernels from this round's rocprofv3 passes (tools/profile_aba.sh)."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", "r03_a_aba_pmc.json")))["kernels"]
+        return {k.split("<")[0]: {"hbm_bytes": v.get("hbm_bytes"), "valu_per_wave": v.get("valu_per_wave")} for k, v in ks.items()}
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def aba_roofline(n=1 << 20, launches=30):
-    """HBM roofline of the ABA kernel on a FULL chip: forward_dynamics_kernel (one substep's accelerations per launch) on n synthetic states
-    (joints around the default pose, unit-normal joint velocities, torques within the effort limits), HIP events on the
-    launch stream.  At the training size (4096 envs = 128 waves on 1024 SIMDs) no kernel can approach a bandwidth roof."""
+    """HBM roofline of the ABA launch on a FULL chip: bg_env_forward_dynamics (one substep's accelerations per launch) on n synthetic states, HIP
+    events on the launch stream.  At the training size (4096 envs = 128 waves on 1024 SIMDs) no kernel can approach a bandwidth roof.
+    The launch is forward_dynamics_kernel (every env) + aba_compact_kernel + forward_dynamics_body_kernel (the envs whose legs can meet: the
+    leg-against-leg narrow phase) -- `achieved` prices the WHOLE launch.  Two state distributions:
+      `standing_noise_0.1` (the headline entry, the state of rounds 1 and 2): joints = default pose + N(0, 0.1 rad), trunk upright at 0.66 m.  The
+          0.1 rad of hip-roll noise crosses the legs of 8 % of the envs, which now go through the second kernel;
+      `survey_8d_state`: SURVEY section 8(d)'s K1 inputs (joints ~ U(limits), trunk at 0.72 m within 0.3 rad of upright, torques ~ U(+-effort))."""
     from booster_gym_amd.envs import T1
     from booster_gym_amd.utils.config import load_cfg
 
     env = T1(load_cfg("T1", {"env.num_envs": n, "terrain.type": "plane"}))
     dev = env.device
+    m = env.model
+    lib = _lib.load()
+    qacc = torch.empty(n, 18, device=dev)
+
+    def measure(root, q, qd, tau):
+        root, q, qd, tau = (t.to(dev).contiguous() for t in (root, q, qd, tau))
+        call = lambda: _lib.check(lib.bg_env_forward_dynamics(env._env, _lib.ptr(root), _lib.ptr(q), _lib.ptr(qd), _lib.ptr(tau), None, _lib.ptr(qacc),
+                                                              _lib.current_stream_ptr()), "bg_env_forward_dynamics")
+        for _ in range(3):
+            call()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(launches):
+            call()
+        e1.record(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / launches * 1e3
+
     g = torch.Generator(device="cpu").manual_seed(1234)
     root = torch.zeros(n, 13); root[:, 2] = 0.66; root[:, 6] = 1.0; root[:, 7:13] = torch.randn(n, 6, generator=g) * 0.3
     q = torch.tensor([-0.2, 0, 0, 0.4, -0.25, 0] * 2).repeat(n, 1) + torch.randn(n, 12, generator=g) * 0.1
     qd = torch.randn(n, 12, generator=g)
     tau = (torch.rand(n, 12, generator=g) * 2 - 1) * 20
-    root, q, qd, tau = (t.to(dev).contiguous() for t in (root, q, qd, tau))
-    qacc = torch.empty(n, 18, device=dev)
-    lib = _lib.load()
-    call = lambda: _lib.check(lib.bg_env_forward_dynamics(env._env, _lib.ptr(root), _lib.ptr(q), _lib.ptr(qd), _lib.ptr(tau), None, _lib.ptr(qacc),
-                                                          _lib.current_stream_ptr()), "bg_env_forward_dynamics")
-    for _ in range(3):
-        call()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(launches):
-        call()
-    e1.record(); torch.cuda.synchronize()
-    us = e0.elapsed_time(e1) / launches * 1e3
-    gbs = n * ABA_BYTES / us / 1e3
-    return {"kernel": "forward_dynamics_kernel (hand-written HIP: one ABA substep with contact and limits, per-step joint accelerations)",
-            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None,
-            "avg_launch_us": us, "num_envs": n, "algorithmic_bytes_per_launch": n * ABA_BYTES,
-            "note": "VALU-issue bound: 88% of the issue slots at 1M envs (profiles/r01_d_aba_pmc.json); curve over N in profiles/r01_d_aba_roofline_curve.json"}
+    us = measure(root, q, qd, tau)
+    # SURVEY 8(d) K1 inputs
+    lo, hi, eff = (torch.tensor(a, dtype=torch.float32) for a in (m.dof_lower, m.dof_upper, m.dof_effort))
+    root2 = torch.zeros(n, 13); root2[:, 2] = 0.72
+    ax = torch.randn(n, 3, generator=g); ax = ax / ax.norm(dim=1, keepdim=True)
+    ang = torch.rand(n, generator=g) * 0.3
+    root2[:, 3:6] = ax * torch.sin(ang / 2)[:, None]; root2[:, 6] = torch.cos(ang / 2)
+    q2 = lo + (hi - lo) * torch.rand(n, 12, generator=g)
+    tau2 = (torch.rand(n, 12, generator=g) * 2 - 1) * eff
+    us2 = measure(root2, q2, torch.randn(n, 12, generator=g), tau2)
+    gbs, gbs2 = n * ABA_BYTES / us / 1e3, n * ABA_BYTES / us2 / 1e3
+    pmc = _aba_pmc()
+    traffic = sum(v["hbm_bytes"] for v in pmc.values() if v.get("hbm_bytes")) if pmc else None
+    return {"kernel": "bg_env_forward_dynamics: forward_dynamics_kernel (hand-written HIP: one ABA substep with contact and limits, per-step joint accelerations) + "
+                      "aba_compact_kernel + forward_dynamics_body_kernel (leg-against-leg narrow phase for the envs whose legs can meet)",
+            "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
+            "traffic_source": "profiles/r03_a_aba_pmc.json (tools/profile_aba.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in separate passes "
+                              "of tools/aba_only.py, the same launch); FETCH_SIZE + WRITE_SIZE as reported: dword-per-lane accesses, whose width the guide "
+                              "calls uncalibrated on gfx950, and inputs that stay in the 256 MB Infinity Cache between launches -- indicative only",
+            "avg_launch_us": us, "num_envs": n, "algorithmic_bytes_per_launch": n * ABA_BYTES, "state": "standing_noise_0.1",
+            "kernels_per_launch_rocprof": "profiles/r03_a_aba_kernel_stats.csv: forward_dynamics_kernel 210.4 us (3,120 VALU per wave, was 3,331 in round 2), "
+                                          "forward_dynamics_body_kernel 78.6 us, aba_compact_kernel 3 us",
+            "survey_8d_state": {"avg_launch_us": us2, "achieved": gbs2, "frac": gbs2 / HBM_PEAK_GBS,
+                                "state": "joints ~ U(limits), trunk at 0.72 m within 0.3 rad of upright, torques ~ U(+-effort), qd ~ N(0, 1)"},
+            "note": "VALU-issue bound (SQ counters in the PMC file: the SIMDs issue VALU 100 % of the wave cycles of forward_dynamics_kernel at 4 cycles per "
+                    "instruction); itemised instruction budget: tools/isa_census.py, DESIGN.md section 6"}
 
 
 def cpu_baseline(n_envs=4096):

@@ -17,7 +17,7 @@ extern int bg_set_error(int code, const char* msg);
         if (_e != hipSuccess) return bg_set_error(-2, hipGetErrorString(_e));               \
     } while (0)
 
-#ifdef BG_PROBE_TIMELINE  // tools/mlp_timeline_probe.py: shader-clock stamps of every wave at the phase boundaries (never defined in the product build)
+#ifdef BG_PROBE_TIMELINE  // tools/archive/mlp_timeline_probe.py: shader-clock stamps of every wave at the phase boundaries (never defined in the product build)
 __device__ long long bg_timeline_buf[2048 * 4 * 16];
 #define BG_STAMP(SLOT) do { if ((threadIdx.x & 63) == 0) bg_timeline_buf[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (SLOT)] = clock64(); } while (0)
 #define BG_EPI_STAMP(SLOT) BG_STAMP(SLOT)

@@ -35,7 +35,7 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&
         // (16 bytes per lane, 8 full 128-byte lines per instruction: with 64 dword stores per lane the store tail was issue-bound).  The tile goes
         // through a wave-private 32 x 32 block of LDS (the weight staging buffer, free after the loop's last barrier): 16 ds_write_b32 in the C
         // layout, 4 ds_read_b128 by rows -- 20 LDS instructions where the 4 x 4 quad transposes (DPP) of the first version cost 64 VALU per tile in
-        // an epilogue that is VALU-issue bound (tools/mlp_timeline_probe.py).  Row stride 36 floats: 16-byte aligned, spreads both access patterns.
+        // an epilogue that is VALU-issue bound (tools/archive/mlp_timeline_probe.py).  Row stride 36 floats: 16-byte aligned, spreads both access patterns.
         constexpr int LS = 36;
         float* wl = csum + wave * (32 * LS);
         const int r8 = lane >> 3, c8 = (lane & 7) * 4;  // read side: row r8 + 8 k of the block, columns c8 .. c8 + 3
@@ -54,7 +54,7 @@ __device__ __forceinline__ void layer_epilogue(f32x16 (&acc)[NT], const f32x4 (&
                 f32x4 v = *reinterpret_cast<const f32x4*>(&wl[(r8 + 8 * k) * LS + c8]) + b4[t];
                 if (EPI == 1) { v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w); }
                 const int rr = rbase + r8 + 8 * k;
-#ifdef BG_PROBE_NO_STORE  // tools/mlp_nostore_probe.py: how much of the kernel is its store tail?  (never defined in the product build)
+#ifdef BG_PROBE_NO_STORE  // tools/archive/mlp_nostore_probe.py: how much of the kernel is its store tail?  (never defined in the product build)
                 if (rr < M && v.x == 12345.678f) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + c8) = v;
 #else
                 if (rr < M) *reinterpret_cast<f32x4*>(Y + (size_t)rr * ldy + t * 32 + c8) = v;

@@ -14,7 +14,7 @@ extern int bg_set_error(int code, const char* msg);
         if (_e != hipSuccess) return bg_set_error(-2, hipGetErrorString(_e));               \
     } while (0)
 
-#ifdef BG_PROBE_TIMELINE  // tools/wgrad_timeline_probe.py: shader-clock stamps of every wave at the phase boundaries (never defined in the product build)
+#ifdef BG_PROBE_TIMELINE  // tools/archive/wgrad_timeline_probe.py: shader-clock stamps of every wave at the phase boundaries (never defined in the product build)
 __device__ long long bg_wg_timeline[1024 * 4 * 8];
 #define BG_STAMP(SLOT) do { if ((threadIdx.x & 63) == 0) bg_wg_timeline[((size_t)blockIdx.x * 4 + (threadIdx.x >> 6)) * 8 + (SLOT)] = clock64(); } while (0)
 extern "C" int bg_probe_read_wgrad_timeline(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bg_wg_timeline), bytes); }
@@ -53,7 +53,7 @@ __device__ __forceinline__ void wgrad_tile(float* red_base, int M, int Cout, int
     const int tco = tile / ntile_ci, tci = tile % ntile_ci;
     // runs are cut at multiples of 2 * D row pairs (one double set of the steady-state loop), the last one takes what is left: only that run has a
     // tail.  (Cut at arbitrary row pairs every wave ran the guarded tail -- two sets of mostly zero rows behind loads that are waited for one by
-    // one: 22.8 k of a wave's 637 k cycles, tools/wgrad_timeline_probe.py.)
+    // one: 22.8 k of a wave's 637 k cycles, tools/archive/wgrad_timeline_probe.py.)
     const long KP = M >> 1, W = (long)slices * ks, widx = (long)slice * ks + ksub, KG = KP / 16;
     const int kp0 = 16 * (int)(KG * widx / W), kp1 = widx == W - 1 ? (int)KP : 16 * (int)(KG * (widx + 1) / W);
     const unsigned gofb = 4u * (h * Cout + tco * 128 + 4 * i), aofb = 4u * (h * Cin + tci * (32 * TCI) + TCI * i);  // byte offsets of this lane

@@ -199,7 +199,7 @@ __device__ __forceinline__ void wgrad_split_tile(float* lds, int M, const float*
     auto top = [&](int c) {
         __builtin_amdgcn_s_waitcnt(0x0F70 | ((NBUF - 2) * N_MINE & 15) | (((NBUF - 2) * N_MINE >> 4) << 14));
         __builtin_amdgcn_s_barrier();
-#ifndef BG_PROBE_NO_STAGE  // tools/wgrad_split_parts_probe.py: the loop without its copies (never defined in the product build)
+#ifndef BG_PROBE_NO_STAGE  // tools/archive/wgrad_split_parts_probe.py: the loop without its copies (never defined in the product build)
         stage(c + NBUF);
 #endif
     };

@@ -146,7 +146,7 @@ class MLPTrainer:
 
     # Weight gradients (the dW part of loss.backward(), runner.py:163): hand-written fp32-MFMA kernel, ALL hidden layers of both networks in one
     # launch pair after both backward chains (bg_mlp_weight_grad_group, GroupedWeightGrad; DEFER_WGRAD below).  Measured on MI355X, round 2
-    # (tools/ab_defer.sh, update phase per iteration): library split-K bmm + sum inside the chains 24.13 ms; the hand-written kernel one layer at a
+    # (tools/archive/ab_defer.sh, update phase per iteration): library split-K bmm + sum inside the chains 24.13 ms; the hand-written kernel one layer at a
     # time inside the chains 26.46 ms (its 512-register, 128 KB-LDS workgroups cannot share a CU with the other stream's kernels); the library
     # path deferred 24.39 ms; the grouped hand-written launch 23.01 ms = 3.77 M env-steps/s against 3.61 M.  BG_FUSED_WGRAD=0 selects the library path.
     FUSED_WGRAD = __import__("os").environ.get("BG_FUSED_WGRAD", "1") == "1"

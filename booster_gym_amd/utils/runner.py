@@ -194,7 +194,7 @@ class Runner:
             MLPTrainer.SPLIT = int(gs)
         self._wgrad_group = GroupedWeightGrad()
         # the critic's stream goes ahead of the actor's in workgroup dispatch: its chain is the longer one and the actor's loss waits for its GAE
-        # (update 23.17 -> 23.06 ms, tools/ab_prio.sh; BG_SIDE_PRIORITY=0: equal priorities)
+        # (update 23.17 -> 23.06 ms, tools/archive/ab_prio.sh; BG_SIDE_PRIORITY=0: equal priorities)
         self._side_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("BG_SIDE_PRIORITY", "-1")))
         # Opt-in (BG_DEFER_FINISH=1): the small fixed-order reductions behind the head / backward-layer kernels as ONE launch on the side stream beside
         # the weight gradients instead of inside the chains (see update()).  Measured in the loop (tools/ab_env.sh, 3 alternating runs each): update

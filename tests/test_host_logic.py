@@ -642,3 +642,23 @@ def test_c_urdf_loader_on_the_reference_asset(flat_model):
     _compare_c_and_python_models(d, names, py)
     assert names[0] == list(flat_model.body_names) and abs(sum(d.mass) - 31.6144) < 1e-3
     assert np.allclose([list(r) for r in d.inertia], flat_model.inertia, rtol=1e-5, atol=1e-8)
+
+
+def test_config_keys_without_effect_are_reported():
+    """Keys of the reference's T1.yaml that only configure Isaac Gym / PhysX (sim.physx.*, most of asset.*): accepted, but a value that asks
+    for a behaviour this build does not have is named in a warning; the shipped values are silent.  asset.self_collisions is NOT among them
+    any more: it switches the leg-against-leg contacts (envs/T1.yaml:69, envs/t1.py:128)."""
+    import warnings
+
+    from booster_gym_amd.envs.base_task import IGNORED_KEYS, warn_ignored_keys
+    from booster_gym_amd.utils.config import load_cfg
+
+    cfg = load_cfg("T1", {})
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        assert warn_ignored_keys(cfg) == []
+    assert ("asset", "self_collisions") not in IGNORED_KEYS
+    cfg2 = load_cfg("T1", {"sim.physx.num_position_iterations": 8, "asset.armature": 0.01, "sim.substeps": 2})
+    with pytest.warns(UserWarning, match="no effect"):
+        bad = warn_ignored_keys(cfg2)
+    assert sorted(bad) == ["asset.armature", "sim.physx.num_position_iterations", "sim.substeps"]
