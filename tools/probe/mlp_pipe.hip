@@ -1,9 +1,16 @@
-// PROBE, not part of libbooster_gym_amd.so (round 3: built, bit-identical to mlp_fwd_kernel, and SLOWER alone on the GPU: 144.5 against 118.7 us at
-// 256 x 256, 74.4 against 55.6 us at 256 -> 128, M = 98,304; tools/mlp_pipe_probe.py).  Two reasons, both visible in its ISA and its shape: the
-// compiler emits each chunk's MFMAs first and the previous item's epilogue as one clump behind them (no interleaving: the matrix pipe idles for
-// this wave exactly as before, the double accumulators buy nothing), and with two tiles per wave a k-chunk is only 32 MFMAs, so the loads of
-// the next chunk get half the latency cover the 64-MFMA chunks of mlp_fwd_kernel give them.  What a winning version would need: the epilogue
-// written as micro-steps placed between individual MFMAs (sched_group_barrier patterns), and weights / A values fetched two chunks ahead.
+// PROBE, not part of libbooster_gym_amd.so.  Round-3 experiments on a PERSISTENT form of mlp_fwd_kernel (tools/mlp_pipe_probe.py; all variants
+// bit-identical to mlp_fwd_kernel; times alone on the GPU at M = 98,304, current kernel 118.7 us at 256 x 256, 55.2 us at 256 -> 128):
+//   1. two accumulator sets, the previous item's epilogue issued under the next item's MFMAs, 64 x 128 items (two tiles per wave): 144.5 / 74.4 us.
+//      The compiler emits a chunk's MFMAs first and the epilogue as one clump behind them, and -- the real flaw -- stores and loads share vmcnt on
+//      this part, so the vmcnt(0) in front of every chunk barrier drained the previous item's stores right there;
+//   2. the same with the epilogue's VALUES computed under the MFMAs and its STORES issued behind the chunk's wait + barrier (a whole chunk to
+//      drain): 130.9 / 69.4 us; 128 x 128 items (four tiles, 2 x 64 accumulators) spill 270 B per lane at two waves per SIMD;
+//   3. (this file, "design Q") ONE accumulator set, three waves per SIMD like mlp_fwd_kernel, weights staged by global_load_lds, an item's
+//      epilogue right behind its loop with the stores NOT waited for (the next item's first operands were fetched under the last chunk, its
+//      chunk 0 starts at once and the stores drain under it): 114.5 us at 256 x 256 with 768 workgroups x 2 items (-3.6 %), but 59.9 / 34.9 /
+//      65.1 us against 55.2 / 31.7 / 59.9 at 256 -> 128, 128 -> 128, 128 -> 256 (profiles/r03_mlp_pipe_probe_designQ.log).
+// Conclusion: hiding the store tail buys a few per cent on the one shape with two items per workgroup and loses elsewhere; the lockstep of
+// the co-resident workgroups is untouched by persistence.  Not adopted.
 //
 // Persistent, software-pipelined form of the fused fp32-MFMA layer kernels of bg_mlp.hip (reference utils/model.py:9-26 Linear + ELU stacks under
 // utils/runner.py:132,147,163), gfx950 only.
@@ -36,7 +43,7 @@ namespace {
 // 32 x 32 tiles.  With two accumulator sets that is 64 accumulator registers per wave (128-row items with four tiles per wave needed 128 and
 // spilled at two waves per SIMD), three workgroups fit a CU, and a layer has twice as many items (1536 / 3072 at M = 98,304), which divide evenly
 // over the resident workgroups.
-constexpr int PN = 128, PBM = 64, PNT = 2, PLS = 36;
+constexpr int PN = 128, PBM = 128, PNT = 4, PLS = 36;
 
 struct PipeItem {           // what the epilogue of an item needs after its main loop is over
     int rbase;              // first row of this wave's 32 rows
@@ -73,27 +80,37 @@ __device__ __forceinline__ void pipe_mfma_chunk(f32x16 (&acc)[PNT], const f32x4 
         }
     }
 }
-// epilogue of ONE 32-column tile of a finished item: C layout -> (row, 4 columns) through the wave's LDS block, + bias, ELU, 16-byte stores
+// epilogue of ONE 32-column tile of a finished item, in two halves.  COMPUTE: C layout -> (row, 4 columns) through the wave's LDS block, + bias,
+// ELU, the four 16-byte row pieces left in registers.  STORE: the global stores.  They are separate because loads and stores share vmcnt on
+// this part and return out of order against each other: a store issued before the chunk's `s_waitcnt vmcnt(0)` (which the weight / A loads of
+// the next chunk need) is drained right there, at full HBM write latency, in the middle of the main loop.  Issued AFTER that wait, the stores
+// have the whole next chunk to drain.
 template <int EPI, int T>
-__device__ __forceinline__ void pipe_epilogue_tile(const f32x16 (&acc)[PNT], const PipeItem& it, int M, int ldy, float* wl, int lane, int i, int h) {
+__device__ __forceinline__ void pipe_epilogue_compute(const f32x16 (&acc)[PNT], const f32x4 b4, float* wl, int lane, int i, int h, f32x4 (&v)[4]) {
     const int r8 = lane >> 3, c8 = (lane & 7) * 4;
-    const f32x4 b4 = *reinterpret_cast<const f32x4*>(it.bias + T * 32 + c8);
 #pragma unroll
     for (int r = 0; r < 16; r++) wl[((r & 3) + 8 * (r >> 2) + 4 * h) * PLS + i] = acc[T][r];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(&wl[(r8 + 8 * k) * PLS + c8]) + b4;
-        if (EPI == 1) { v.x = elu_f(v.x); v.y = elu_f(v.y); v.z = elu_f(v.z); v.w = elu_f(v.w); }
-        const int rr = it.rbase + r8 + 8 * k;
-        if (rr < M) *reinterpret_cast<f32x4*>(it.Y + (size_t)rr * ldy + T * 32 + c8) = v;
+        v[k] = *reinterpret_cast<const f32x4*>(&wl[(r8 + 8 * k) * PLS + c8]) + b4;
+        if (EPI == 1) { v[k].x = elu_f(v[k].x); v[k].y = elu_f(v[k].y); v[k].z = elu_f(v[k].z); v[k].w = elu_f(v[k].w); }
     }
 }
-// the tiles of the previous item that are finished under k-chunk KC of the current one: the 2 tiles spread evenly over the CH chunks
-template <int EPI, int CH, int KC>
-__device__ __forceinline__ void pipe_epilogue_piece(const f32x16 (&acc)[PNT], const PipeItem& it, int M, int ldy, float* wl, int lane, int i, int h) {
-    if constexpr (KC % (CH / 2) == 0) pipe_epilogue_tile<EPI, KC / (CH / 2)>(acc, it, M, ldy, wl, lane, i, h);
+template <int T>
+__device__ __forceinline__ void pipe_epilogue_store(const f32x4 (&v)[4], const PipeItem& it, int M, int ldy, int lane) {
+    const int r8 = lane >> 3, c8 = (lane & 7) * 4;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int rr = it.rbase + r8 + 8 * k;
+        if (rr < M) *reinterpret_cast<f32x4*>(it.Y + (size_t)rr * ldy + T * 32 + c8) = v[k];
+    }
 }
-
+template <int EPI, int T>
+__device__ __forceinline__ void pipe_epilogue_tile(const f32x16 (&acc)[PNT], const PipeItem& it, int M, int ldy, float* wl, int lane, int i, int h) {
+    f32x4 v[4];
+    pipe_epilogue_compute<EPI, T>(acc, *reinterpret_cast<const f32x4*>(it.bias + T * 32 + (lane & 7) * 4), wl, lane, i, h, v);
+    pipe_epilogue_store<T>(v, it, M, ldy, lane);
+}
 struct PipeOperands {  // per-item pointers of the main loop
     const float* xrow;   // this lane's row of X, offset by 4 h
     const float* W;      // weight rows of the item's column block
@@ -111,22 +128,27 @@ struct PipeKernel {
     static __device__ __forceinline__ void item(f32x16 (&acc)[PNT], const f32x16 (&accp)[PNT], const PipeOperands& cur, const PipeOperands& next, bool has_next,
                                                 const PipeItem& prev, int M, int ldy, float (&sW)[2][PN * PSW], float* wl, f32x4 (&aA)[4], int wave, int lane,
                                                 int i, int h) {
-        const int wcol = wave >> 1;
         f32x4 aB[4];
 #pragma unroll
         for (int t = 0; t < PNT; t++)
 #pragma unroll
             for (int r = 0; r < 16; r++) acc[t][r] = 0.f;
+        // the previous item's four tiles are finished one per CH / 4 chunks (CH == 2: two per chunk): values computed between the chunk's MFMAs
+        // and its wait, stores issued behind the barrier
+        f32x4 bias[PNT], v[4], v2[4];
+        if constexpr (PREV) {  // all bias pieces up front: no load is issued behind a store
+#pragma unroll
+            for (int t = 0; t < PNT; t++) bias[t] = *reinterpret_cast<const f32x4*>(prev.bias + t * 32 + (lane & 7) * 4);
+        }
 #pragma unroll
         for (int kc = 0; kc < CH; kc += 2) {
-            // chunk kc runs on (aA, sW[0]); chunk kc + 1 is fetched meanwhile: weights straight into sW[1] (every wave is past its reads of
-            // sW[1]: the barrier at the end of the previous trip), this lane's A values into aB
             pipe_stage_w<K>(cur.W, kc + 1, sW[1], wave, lane);
             load_a_chunk(aB, cur.xrow, kc + 1);
-            pipe_mfma_chunk(acc, aA, sW[0] + wcol * 64 * PSW, i, h);
-            if constexpr (PREV) epilogue_at(accp, prev, M, ldy, wl, lane, i, h, kc);
-            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of sW[1] has landed (and aB)
+            pipe_mfma_chunk(acc, aA, sW[0], i, h);
+            if constexpr (PREV) epi_compute(accp, bias, wl, lane, i, h, v, v2, kc);
+            __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): this wave's share of sW[1] has landed (and aB); the stores of the chunk before are long done
             __syncthreads();
+            if constexpr (PREV) epi_store(v, v2, prev, M, ldy, lane, kc);
             if (kc + 2 < CH) {
                 pipe_stage_w<K>(cur.W, kc + 2, sW[0], wave, lane);
                 load_a_chunk(aA, cur.xrow, kc + 2);
@@ -134,23 +156,37 @@ struct PipeKernel {
                 pipe_stage_w<K>(next.W, 0, sW[0], wave, lane);
                 load_a_chunk(aA, next.xrow, 0);
             }
-            pipe_mfma_chunk(acc, aB, sW[1] + wcol * 64 * PSW, i, h);
-            if constexpr (PREV) epilogue_at(accp, prev, M, ldy, wl, lane, i, h, kc + 1);
+            pipe_mfma_chunk(acc, aB, sW[1], i, h);
+            if constexpr (PREV) epi_compute(accp, bias, wl, lane, i, h, v, v2, kc + 1);
             __builtin_amdgcn_s_waitcnt(0x0F70);
             __syncthreads();
+            if constexpr (PREV) epi_store(v, v2, prev, M, ldy, lane, kc + 1);
         }
     }
-    // compile-time dispatch of the epilogue piece that belongs to chunk kc (kc is a constant after unrolling; the switch folds)
-    static __device__ __forceinline__ void epilogue_at(const f32x16 (&accp)[PNT], const PipeItem& prev, int M, int ldy, float* wl, int lane, int i, int h, int kc) {
-        switch (kc) {
-            case 0: pipe_epilogue_piece<EPI, CH, 0>(accp, prev, M, ldy, wl, lane, i, h); break;
-            case 1: pipe_epilogue_piece<EPI, CH, 1>(accp, prev, M, ldy, wl, lane, i, h); break;
-            case 2: if constexpr (CH > 2) pipe_epilogue_piece<EPI, CH, 2>(accp, prev, M, ldy, wl, lane, i, h); break;
-            case 3: if constexpr (CH > 2) pipe_epilogue_piece<EPI, CH, 3>(accp, prev, M, ldy, wl, lane, i, h); break;
-            case 4: if constexpr (CH > 4) pipe_epilogue_piece<EPI, CH, 4>(accp, prev, M, ldy, wl, lane, i, h); break;
-            case 5: if constexpr (CH > 4) pipe_epilogue_piece<EPI, CH, 5>(accp, prev, M, ldy, wl, lane, i, h); break;
-            case 6: if constexpr (CH > 4) pipe_epilogue_piece<EPI, CH, 6>(accp, prev, M, ldy, wl, lane, i, h); break;
-            case 7: if constexpr (CH > 4) pipe_epilogue_piece<EPI, CH, 7>(accp, prev, M, ldy, wl, lane, i, h); break;
+    // which tile(s) of the previous item belong to chunk kc (kc is a constant after unrolling: the branches fold)
+    static __device__ __forceinline__ void epi_compute(const f32x16 (&accp)[PNT], const f32x4 (&bias)[PNT], float* wl, int lane, int i, int h, f32x4 (&v)[4],
+                                                       f32x4 (&v2)[4], int kc) {
+        if constexpr (CH == 2) {
+            if (kc == 0) { pipe_epilogue_compute<EPI, 0>(accp, bias[0], wl, lane, i, h, v); pipe_epilogue_compute<EPI, 1>(accp, bias[1], wl, lane, i, h, v2); }
+            else { pipe_epilogue_compute<EPI, 2>(accp, bias[2], wl, lane, i, h, v); pipe_epilogue_compute<EPI, 3>(accp, bias[3], wl, lane, i, h, v2); }
+        } else {
+            constexpr int STEP = CH / 4;
+            if (kc == 0 * STEP) pipe_epilogue_compute<EPI, 0>(accp, bias[0], wl, lane, i, h, v);
+            else if (kc == 1 * STEP) pipe_epilogue_compute<EPI, 1>(accp, bias[1], wl, lane, i, h, v);
+            else if (kc == 2 * STEP) pipe_epilogue_compute<EPI, 2>(accp, bias[2], wl, lane, i, h, v);
+            else if (kc == 3 * STEP) pipe_epilogue_compute<EPI, 3>(accp, bias[3], wl, lane, i, h, v);
+        }
+    }
+    static __device__ __forceinline__ void epi_store(const f32x4 (&v)[4], const f32x4 (&v2)[4], const PipeItem& prev, int M, int ldy, int lane, int kc) {
+        if constexpr (CH == 2) {
+            if (kc == 0) { pipe_epilogue_store<0>(v, prev, M, ldy, lane); pipe_epilogue_store<1>(v2, prev, M, ldy, lane); }
+            else { pipe_epilogue_store<2>(v, prev, M, ldy, lane); pipe_epilogue_store<3>(v2, prev, M, ldy, lane); }
+        } else {
+            constexpr int STEP = CH / 4;
+            if (kc == 0 * STEP) pipe_epilogue_store<0>(v, prev, M, ldy, lane);
+            else if (kc == 1 * STEP) pipe_epilogue_store<1>(v, prev, M, ldy, lane);
+            else if (kc == 2 * STEP) pipe_epilogue_store<2>(v, prev, M, ldy, lane);
+            else if (kc == 3 * STEP) pipe_epilogue_store<3>(v, prev, M, ldy, lane);
         }
     }
 };
@@ -158,7 +194,7 @@ struct PipeKernel {
 // items [blockIdx.x * per, + per) of the launch: item = slab * ncb + column block, so the column blocks of a slab follow each other in ONE
 // workgroup and the second read of the slab's X rows comes out of this CU's L2
 template <int K, int EPI>
-__global__ __launch_bounds__(256, 2) void mlp_pipe_kernel(int M, int ldy, const float* __restrict__ X, const float* __restrict__ Wfull,
+__global__ __launch_bounds__(256, 3) void mlp_pipe_kernel(int M, int ldy, const float* __restrict__ X, const float* __restrict__ Wfull,
                                                           const float* __restrict__ biasfull, float* __restrict__ Yfull, int nitems, int per) {
     using PK = PipeKernel<K, EPI>;
     __shared__ __attribute__((aligned(16))) float sW[2][PN * PSW];
@@ -170,7 +206,7 @@ __global__ __launch_bounds__(256, 2) void mlp_pipe_kernel(int M, int ldy, const 
     float* wl = sT + wave * (32 * PLS);
     auto operands = [&](int it) {
         const int bx = it / ncb, by = it % ncb;
-        const int row = bx * PBM + (wave & 1) * 32 + i;
+        const int row = bx * PBM + wave * 32 + i;
         PipeOperands o;
         o.xrow = X + (size_t)(row < M ? row : M - 1) * K + 4 * h;
         o.W = Wfull + (size_t)by * PN * K;
@@ -179,12 +215,12 @@ __global__ __launch_bounds__(256, 2) void mlp_pipe_kernel(int M, int ldy, const 
     auto epi_item = [&](int it) {
         const int bx = it / ncb, by = it % ncb;
         PipeItem e;
-        e.rbase = bx * PBM + (wave & 1) * 32;
-        e.Y = Yfull + by * PN + (wave >> 1) * 64;
-        e.bias = biasfull + by * PN + (wave >> 1) * 64;
+        e.rbase = bx * PBM + wave * 32;
+        e.Y = Yfull + by * PN;
+        e.bias = biasfull + by * PN;
         return e;
     };
-    f32x16 acc0[PNT], acc1[PNT];
+    f32x16 acc0[PNT], accn[PNT];  // accn: never read (the PREV = false form of item() takes no previous item)
     f32x4 aA[4];
     {   // prologue: first chunks of the first item
         const PipeOperands o = operands(it0);
@@ -193,24 +229,25 @@ __global__ __launch_bounds__(256, 2) void mlp_pipe_kernel(int M, int ldy, const 
         __builtin_amdgcn_s_waitcnt(0x0F70);
         __syncthreads();
     }
-    PipeOperands cur = operands(it0);
-    PipeOperands nxt = it0 + 1 < it1 ? operands(it0 + 1) : cur;
     PipeItem none; none.rbase = 0; none.Y = nullptr; none.bias = nullptr;
-    PK::template item<false>(acc0, acc1, cur, nxt, it0 + 1 < it1, none, M, ldy, sW, wl, aA, wave, lane, i, h);
-    int it = it0 + 1;
-    for (; it < it1; it += 2) {  // (acc1 <- item `it` | epilogue of acc0), then (acc0 <- item `it + 1` | epilogue of acc1)
-        cur = nxt;
-        nxt = it + 1 < it1 ? operands(it + 1) : cur;
-        PK::template item<true>(acc1, acc0, cur, nxt, it + 1 < it1, epi_item(it - 1), M, ldy, sW, wl, aA, wave, lane, i, h);
-        if (it + 1 >= it1) break;
-        cur = nxt;
-        nxt = it + 2 < it1 ? operands(it + 2) : cur;
-        PK::template item<true>(acc0, acc1, cur, nxt, it + 2 < it1, epi_item(it), M, ldy, sW, wl, aA, wave, lane, i, h);
+    // Design Q: ONE accumulator set.  An item's epilogue follows its main loop at once; its 16 stores are issued and NOT waited for: the next item's
+    // first operands are already there (fetched under this item's last chunk), so its chunk 0 starts immediately and the stores drain under its 64
+    // MFMAs -- the first vmcnt(0) they meet is the one at the end of that chunk.
+    for (int it = it0; it < it1; it++) {
+        const PipeOperands cur = operands(it);
+        const bool has_next = it + 1 < it1;
+        const PipeOperands nxt = has_next ? operands(it + 1) : cur;
+        PK::template item<false>(acc0, accn, cur, nxt, has_next, none, M, ldy, sW, wl, aA, wave, lane, i, h);
+        const PipeItem e = epi_item(it);
+        f32x4 bias[PNT];
+#pragma unroll
+        for (int t = 0; t < PNT; t++) bias[t] = *reinterpret_cast<const f32x4*>(e.bias + t * 32 + (lane & 7) * 4);
+        f32x4 v[4];
+        pipe_epilogue_compute<EPI, 0>(acc0, bias[0], wl, lane, i, h, v); pipe_epilogue_store<0>(v, e, M, ldy, lane);
+        pipe_epilogue_compute<EPI, 1>(acc0, bias[1], wl, lane, i, h, v); pipe_epilogue_store<1>(v, e, M, ldy, lane);
+        pipe_epilogue_compute<EPI, 2>(acc0, bias[2], wl, lane, i, h, v); pipe_epilogue_store<2>(v, e, M, ldy, lane);
+        pipe_epilogue_compute<EPI, 3>(acc0, bias[3], wl, lane, i, h, v); pipe_epilogue_store<3>(v, e, M, ldy, lane);
     }
-    // the last item's epilogue has nothing to hide under
-    const PipeItem last = epi_item(it1 - 1);
-    if ((it1 - it0) & 1) { pipe_epilogue_tile<EPI, 0>(acc0, last, M, ldy, wl, lane, i, h); pipe_epilogue_tile<EPI, 1>(acc0, last, M, ldy, wl, lane, i, h); }
-    else { pipe_epilogue_tile<EPI, 0>(acc1, last, M, ldy, wl, lane, i, h); pipe_epilogue_tile<EPI, 1>(acc1, last, M, ldy, wl, lane, i, h); }
 }
 
 }  // namespace
@@ -223,7 +260,7 @@ extern "C" int bg_mlp_layer_forward_pipe(int32_t M, int32_t K, int32_t N, const 
     if ((((uintptr_t)X | (uintptr_t)W | (uintptr_t)Y | (uintptr_t)bias) & 15) != 0) return bg_set_error(-1, "bg_mlp_layer_forward_pipe: pointers must be 16-byte aligned");
     if (N % 128 != 0 || N > 1024) return bg_set_error(-4, "bg_mlp_layer_forward_pipe: unsupported N (multiples of 128 up to 1024)");
     const int nitems = ((M + PBM - 1) / PBM) * (N / 128);
-    int grid = workgroups > 0 ? workgroups : 512;
+    int grid = workgroups > 0 ? workgroups : 768;
     if (grid > nitems) grid = nitems;
     const int per = (nitems + grid - 1) / grid;
     grid = (nitems + per - 1) / per;
