@@ -165,7 +165,12 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_group_kernel(WgradGroup grp)
     for (int j = 1; j < WG_MAX_PROBLEMS; j++)
         if (j < grp.np && b >= grp.p[j].wg_begin) k = j;
     const WgradProblem& pr = grp.p[k];
-    const int groups = pr.ntiles / pr.tw, local = b - pr.wg_begin, tile0 = (local % groups) * pr.tw, slice = local / groups;
+    // Workgroups that read the same rows (the tile groups of one slice) get block indices 8 apart: workgroups are dealt round-robin over the 8
+    // XCDs, so they share an L2 and the second reader of a row block hits it instead of crossing the fabric again.  Slices go in chunks of 8
+    // (the last chunk of a layer may hold fewer): within a chunk of n slices, local index r -> (tile group r / n, slice r % n).
+    const int groups = pr.ntiles / pr.tw, local = b - pr.wg_begin;
+    const int chunk = local / (8 * groups), r = local - chunk * 8 * groups, left = pr.slices - chunk * 8, n = left < 8 ? left : 8;
+    const int tile0 = (r / n) * pr.tw, slice = chunk * 8 + r % n;
     if (pr.tci == 4) wgrad_tile<4>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile0, pr.tw, slice, pr.slices);
     else wgrad_tile<2>(red, pr.M, pr.Cout, pr.Cin, pr.G, pr.A, pr.P, pr.ntile_ci, tile0, pr.tw, slice, pr.slices);
 }
