@@ -54,6 +54,12 @@ class ReduceProblem(C.Structure):
                 ("grad_logstd", C.c_void_p), ("stats", C.c_void_p)]
 
 
+class ParamMirror(C.Structure):
+    """bg_param_mirror: a transposed / re-strided copy of one weight matrix kept current by bg_optimizer_step (include/booster_gym_amd.h)."""
+    _fields_ = [("offset", C.c_int32), ("rows", C.c_int32), ("cols", C.c_int32), ("transpose", C.c_int32), ("ld", C.c_int32), ("pad", C.c_int32),
+                ("dst", C.c_void_p)]
+
+
 class Rand(C.Structure):
     _fields_ = [("mode", C.c_int32), ("a", C.c_float), ("b", C.c_float)]
 
@@ -159,7 +165,7 @@ def load():
         "bg_actor_sample": (i32, [i32] + [vp] * 10 + [u64, u64, vp, vp, vp]),
         "bg_adam_step": (i32, [i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, vp]),
         "bg_adapt_lr": (i32, [vp, f32, f32, f32, f32, vp, vp]),
-        "bg_optimizer_step": (i32, [i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, i32, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp]),
+        "bg_optimizer_step": (i32, [i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, i32, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, i32, vp]),
         "bg_elu_backward_colsum": (i32, [i32, i32, vp, vp, vp, vp, vp]),
         "bg_mlp_layer_forward": (i32, [i32, i32, i32, vp, vp, vp, vp, i32, vp]),
         "bg_mlp_layer_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),

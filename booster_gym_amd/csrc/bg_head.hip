@@ -281,37 +281,45 @@ __global__ __launch_bounds__(256) void critic_head_backward_kernel(int B, int ti
     }
 }
 
-// fixed-order sum of the workgroups' records: out[i] = sum_g partial[g][i]; 16 outputs x 16 record slices per workgroup.  The LAST workgroup
-// adds up the float64 statistics (stat-major [n_stat][groups] at stat_base) and issues one atomic per statistic: k < n_ls goes to
-// grad_logstd[k] (+ entropy_coef: d(entropy.mean())/dlogstd = 1), the rest to stats[k - n_ls]; statistics whose stat_skip bit is set are skipped.
+// One float64 statistic (row k of the stat-major [n_stat][groups] block) added up by one workgroup in a fixed order, then ONE atomic: k < n_ls goes to
+// grad_logstd[k] (+ entropy_coef: d(entropy.mean())/dlogstd = 1), the rest to stats[k - n_ls]; a statistic whose stat_skip bit is set is skipped.
+// (One workgroup PER statistic: a single workgroup walking the 17 statistics of the actor head one after the other -- a load, a butterfly and two
+// barriers each -- was a 66 us launch on the actor's chain of every mini-epoch.)
+__device__ __forceinline__ void finish_statistic(const double* __restrict__ sp, int groups, int k, int n_ls, unsigned stat_skip, double entropy_coef,
+                                                 double* __restrict__ grad_logstd, double* __restrict__ stats) {
+    if ((stat_skip >> k) & 1u) return;
+    __shared__ double sd[4];
+    double s = 0.0;
+#pragma unroll 4
+    for (int g = threadIdx.x; g < groups; g += 256) s += sp[(size_t)k * groups + g];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const double v = sd[0] + sd[1] + sd[2] + sd[3];
+        if (k < n_ls) atomicAdd(&grad_logstd[k], v + entropy_coef);
+        else atomicAdd(&stats[k - n_ls], v);
+    }
+}
+
+// fixed-order sum of the workgroups' records: out[i] = sum_g partial[g][i]; 16 outputs x 16 record slices per workgroup.  The n_stat workgroups
+// behind those add up the float64 statistics (stat-major [n_stat][groups] at stat_base), one each (finish_statistic).
 __global__ __launch_bounds__(256) void head_finish_kernel(int groups, int record, int n_out, const float* __restrict__ partial, float* __restrict__ grad_w,
                                                           int n_w, float* __restrict__ grad_b_hidden, float* __restrict__ grad_b, size_t stat_base,
                                                           int n_stat, int n_ls, unsigned stat_skip, double entropy_coef,
                                                           double* __restrict__ grad_logstd, double* __restrict__ stats) {
-    if (blockIdx.x == gridDim.x - 1) {
-        __shared__ double sd[4];
-        const double* sp = reinterpret_cast<const double*>(partial + stat_base);
-        for (int k = 0; k < n_stat; k++) {
-            if ((stat_skip >> k) & 1u) continue;
-            double s = 0.0;
-            for (int g = threadIdx.x; g < groups; g += 256) s += sp[(size_t)k * groups + g];
-            s = wave_sum_d(s);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = s;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const double v = sd[0] + sd[1] + sd[2] + sd[3];
-                if (k < n_ls) atomicAdd(&grad_logstd[k], v + entropy_coef);
-                else atomicAdd(&stats[k - n_ls], v);
-            }
-        }
+    const int nsum = (n_out + 15) / 16;
+    if ((int)blockIdx.x >= nsum) {
+        finish_statistic(reinterpret_cast<const double*>(partial + stat_base), groups, blockIdx.x - nsum, n_ls, stat_skip, entropy_coef, grad_logstd, stats);
         return;
     }
     __shared__ float sm[16][17];
     const int o = threadIdx.x & 15, gs = threadIdx.x >> 4, i = blockIdx.x * 16 + o;
     float s = 0.f;
-    if (i < n_out)
+    if (i < n_out) {
+#pragma unroll 8  // 8 loads in flight: the 48 dependent adds of a thread were a chain of 48 L2 round trips
         for (int g = gs; g < groups; g += 16) s += partial[(size_t)g * record + i];
+    }
     sm[gs][o] = s;
     __syncthreads();
     if (threadIdx.x < 16 && i < n_out) {
@@ -325,7 +333,7 @@ __global__ __launch_bounds__(256) void head_finish_kernel(int groups, int record
 
 // ---- deferred reductions (include/booster_gym_amd.h: bg_reduce_problem / bg_reduce_group): the work of head_finish_kernel (and of the backward
 // layer's column-sum finish) for up to 8 descriptors in one launch.  Workgroups [begin_k, begin_k + nblk_k) serve descriptor k: 16 outputs x 16
-// slices of the groups each, the last one of a descriptor with statistics adds those up (float64) and issues one atomic per statistic.
+// slices of the groups each, followed by one workgroup per float64 statistic of the descriptor (finish_statistic).
 constexpr int RG_MAX = 8;
 struct ReduceGroup { int np; int begin[RG_MAX]; bg_reduce_problem p[RG_MAX]; };
 __global__ __launch_bounds__(256) void reduce_group_kernel(ReduceGroup grp) {
@@ -335,30 +343,18 @@ __global__ __launch_bounds__(256) void reduce_group_kernel(ReduceGroup grp) {
         if (j < grp.np && (int)blockIdx.x >= grp.begin[j]) k = j;
     const bg_reduce_problem& pr = grp.p[k];
     const int b = blockIdx.x - grp.begin[k], nsum = (pr.n_out + 15) / 16;
-    if (b >= nsum) {  // the statistics block of this descriptor
-        __shared__ double sd[4];
-        const double* sp = reinterpret_cast<const double*>(pr.partial + pr.stat_base);
-        for (int s_ = 0; s_ < pr.n_stat; s_++) {
-            if ((pr.stat_skip >> s_) & 1u) continue;
-            double s = 0.0;
-            for (int g = threadIdx.x; g < pr.groups; g += 256) s += sp[(size_t)s_ * pr.groups + g];
-            s = wave_sum_d(s);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) sd[threadIdx.x >> 6] = s;
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                const double v = sd[0] + sd[1] + sd[2] + sd[3];
-                if (s_ < pr.n_ls) atomicAdd(&pr.grad_logstd[s_], v + pr.entropy_coef);
-                else atomicAdd(&pr.stats[s_ - pr.n_ls], v);
-            }
-        }
+    if (b >= nsum) {  // one of the statistics blocks of this descriptor
+        finish_statistic(reinterpret_cast<const double*>(pr.partial + pr.stat_base), pr.groups, b - nsum, pr.n_ls, pr.stat_skip, pr.entropy_coef, pr.grad_logstd,
+                         pr.stats);
         return;
     }
     __shared__ float sm[16][17];
     const int o = threadIdx.x & 15, gs = threadIdx.x >> 4, i = b * 16 + o;
     float s = 0.f;
-    if (i < pr.n_out)
+    if (i < pr.n_out) {
+#pragma unroll 8
         for (int g = gs; g < pr.groups; g += 16) s += pr.partial[(size_t)g * pr.record + i];
+    }
     sm[gs][o] = s;
     __syncthreads();
     if (threadIdx.x < 16 && i < pr.n_out) {
@@ -383,7 +379,7 @@ extern "C" int bg_reduce_group(const bg_reduce_problem* problems, int32_t count,
             return bg_set_error(-1, "bg_reduce_group: bad statistics descriptor");
         grp.begin[k] = blocks;
         grp.p[k] = q;
-        blocks += (q.n_out + 15) / 16 + (q.n_stat > 0 ? 1 : 0);
+        blocks += (q.n_out + 15) / 16 + q.n_stat;
     }
     hipLaunchKernelGGL(reduce_group_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
     HIP_OK(hipGetLastError());
@@ -451,7 +447,7 @@ extern "C" int bg_actor_head(int32_t B, int32_t mode, const float* h, const floa
     hipLaunchKernelGGL(actor_head_kernel<1>, dim3(grid), dim3(256), 0, st, B, tiles, h, W, bias, logstd, actions, old_mu, old_logstd, old_logp, adv,
                        adv_stats, e_clip, bound_coef, mu_out, g_hidden, scratch);
     constexpr int n_out = HA * HK + HK + HA;
-    hipLaunchKernelGGL(head_finish_kernel, dim3((n_out + 15) / 16 + 1), dim3(256), 0, st, grid, head_record<HA>(), n_out, scratch, grad_W, HA * HK,
+    hipLaunchKernelGGL(head_finish_kernel, dim3((n_out + 15) / 16 + HEAD_NSTAT), dim3(256), 0, st, grid, head_record<HA>(), n_out, scratch, grad_W, HA * HK,
                        grad_b_hidden, grad_b, head_stat_base<HA>(), HEAD_NSTAT, HA, 1u << HA, (double)entropy_coef, grad_logstd, stats);
     HIP_OK(hipGetLastError());
     return 0;

@@ -307,14 +307,19 @@ __global__ void adapt_lr_kernel(const double* __restrict__ kl_sum, float count, 
 //   tail     the last workgroup to finish (ticket counter; every workgroup has read the learning rate before it takes its ticket) applies the KL rule
 //            to the learning rate, publishes / accumulates the loss statistics and zeroes the accumulators for the next mini-epoch.
 // grad_logstd (optional): the log-std gradient as the head kernels leave it (float64 [ls_n]); it stands for grads[ls_off .. ls_off + ls_n).
-constexpr int OPT_GRID = 64, OPT_THREADS = 1024;
+//   mirrors  every updated parameter inside one of the caller's [rows][cols] weight matrices is also written to that matrix's mirror: a transposed
+//            copy (the operand layout of the backward layer kernel) or a copy with a wider row stride (the zero-padded first layer).  Six strided torch
+//            copies per mini-epoch (5-20 us each, inside the two chains) otherwise.
+constexpr int OPT_GRID = 64, OPT_THREADS = 1024, OPT_MAX_MIRRORS = 8;
+struct ParamMirrors { int n; bg_param_mirror m[OPT_MAX_MIRRORS]; };
 __global__ __launch_bounds__(OPT_THREADS) void optimizer_step_kernel(int n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                                      float* __restrict__ v, float* __restrict__ lr_dev, float bc1, float bc2_sqrt,
                                                                      float beta1, float beta2, float eps, float max_norm,
                                                                      double* __restrict__ grad_logstd, int ls_off, int ls_n,
                                                                      double* __restrict__ stats, double* __restrict__ stats_acc,
                                                                      double* __restrict__ stats_last, int n_stats, int kl_index, float kl_count,
-                                                                     float desired_kl, float lr_min, float lr_max, unsigned* __restrict__ ticket) {
+                                                                     float desired_kl, float lr_min, float lr_max, unsigned* __restrict__ ticket,
+                                                                     ParamMirrors mir) {
     __shared__ double s_part[OPT_THREADS / 64];
     __shared__ double s_total;
     const int t = threadIdx.x;
@@ -325,6 +330,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimizer_step_kernel(int n, floa
     double acc = 0.0;
     const int n4 = n >> 2;
     const float4* g4 = reinterpret_cast<const float4*>(g);
+#pragma unroll 8  // 8 loads in flight (the adds stay in order): 44 dependent L2 round trips per thread otherwise
     for (int i = t; i < n4; i += OPT_THREADS) {
         const float4 x = g4[i];
         acc += (double)x.x * (double)x.x + (double)x.y * (double)x.y + (double)x.z * (double)x.z + (double)x.w * (double)x.w;
@@ -348,7 +354,16 @@ __global__ __launch_bounds__(OPT_THREADS) void optimizer_step_kernel(int n, floa
         const float mi = beta1 * m[i] + (1.0f - beta1) * gi;
         const float vi = beta2 * v[i] + (1.0f - beta2) * gi * gi;
         m[i] = mi; v[i] = vi;
-        p[i] -= step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        const float pn = p[i] - step_size * mi / (sqrtf(vi) / bc2_sqrt + eps);
+        p[i] = pn;
+        for (int k = 0; k < mir.n; k++) {
+            const bg_param_mirror& mm = mir.m[k];
+            const int j = i - mm.offset;
+            if (j >= 0 && j < mm.rows * mm.cols) {
+                const int r = j / mm.cols, c = j - r * mm.cols;
+                mm.dst[mm.transpose ? (size_t)c * mm.ld + r : (size_t)r * mm.ld + c] = pn;
+            }
+        }
     }
     __syncthreads();
     if (t == 0) {
@@ -528,8 +543,17 @@ extern "C" int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, 
 extern "C" int bg_optimizer_step(int32_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr_device, int32_t step, float beta1,
                                  float beta2, float eps, float max_grad_norm, double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats,
                                  double* stats_acc, double* stats_last, int32_t n_stats, int32_t kl_index, float kl_count, float desired_kl,
-                                 float lr_min, float lr_max, uint32_t* ticket, void* stream) {
+                                 float lr_min, float lr_max, uint32_t* ticket, const bg_param_mirror* mirrors, int32_t n_mirrors, void* stream) {
     if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr_device || !ticket || step < 1) return bg_set_error(-1, "bg_optimizer_step: bad argument");
+    if (n_mirrors < 0 || n_mirrors > OPT_MAX_MIRRORS || (n_mirrors > 0 && !mirrors)) return bg_set_error(-1, "bg_optimizer_step: 0 to 8 mirrors");
+    ParamMirrors mir;
+    mir.n = n_mirrors;
+    for (int k = 0; k < n_mirrors; k++) {
+        const bg_param_mirror& q = mirrors[k];
+        if (!q.dst || q.rows <= 0 || q.cols <= 0 || q.offset < 0 || (int64_t)q.offset + (int64_t)q.rows * q.cols > n || q.ld < (q.transpose ? q.rows : q.cols))
+            return bg_set_error(-1, "bg_optimizer_step: bad mirror descriptor");
+        mir.m[k] = q;
+    }
     if ((((uintptr_t)grads) & 15) != 0) return bg_set_error(-1, "bg_optimizer_step: grads must be 16-byte aligned");
     if (grad_logstd && (ls_n <= 0 || ls_n > OPT_THREADS || ls_off < 0 || ls_off + ls_n > n)) return bg_set_error(-1, "bg_optimizer_step: log-std slice out of range");
     if (stats && (!stats_acc || !stats_last || n_stats <= 0 || kl_index < 0 || kl_index >= n_stats || !(kl_count > 0.f)))
@@ -537,7 +561,7 @@ extern "C" int bg_optimizer_step(int32_t n, float* params, float* grads, float* 
     const float bc1 = 1.0f - powf(beta1, (float)step), bc2s = sqrtf(1.0f - powf(beta2, (float)step));
     hipLaunchKernelGGL(optimizer_step_kernel, dim3(OPT_GRID), dim3(OPT_THREADS), 0, (hipStream_t)stream, n, params, grads, exp_avg, exp_avg_sq, lr_device, bc1,
                        bc2s, beta1, beta2, eps, max_grad_norm, grad_logstd, ls_off, ls_n, stats, stats_acc, stats_last, n_stats, kl_index, kl_count,
-                       desired_kl, lr_min, lr_max, ticket);
+                       desired_kl, lr_min, lr_max, ticket, mir);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -138,6 +138,9 @@ class MLPTrainer:
         self.dw = [torch.empty(self.wg_slices[i] or self._S, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1], dtype=torch.float32, device=dev)
                    for i, l in enumerate(self.layers)]
         self.wt = [None] * len(self.layers)  # transposed weights for the fused backward kernel
+        # True while w0pad and wt ARE the current weights: the optimiser launch keeps them current (mirror_descriptors); False makes forward /
+        # backward copy them first.  The owner of the optimiser sets it (utils/runner.py) and clears it wherever weights change by other means.
+        self.mirror_fresh = False
         self.planes = [None] * len(self.layers)  # SPLIT: bf16 planes of the weights (forward) ...
         self.planes_t = [None] * len(self.layers)  # ... and of the transposed weights (backward)
         l0 = self.layers[0]
@@ -192,7 +195,8 @@ class MLPTrainer:
                 h = self.acts[i]
                 continue
             if i == 0 and self.w0pad is not None:
-                self.w0pad[:, :k_in].copy_(l.weight)  # weights change every optimiser step; 16k floats
+                if not self.mirror_fresh:
+                    self.w0pad[:, :k_in].copy_(l.weight)  # weights change every optimiser step; 16k floats
                 w, k_in = self.w0pad, self._kin
             if i < last and self._fusable(k_in, n_out):
                 # hand-written fp32-MFMA layer with bias + ELU in the epilogue (bg_mlp.hip)
@@ -276,6 +280,22 @@ class MLPTrainer:
             torch.bmm(g.view(S, B // S, C_out).transpose(1, 2), a_in.view(S, B // S, C_in), out=self.dw[i])
             torch.sum(self.dw[i], dim=0, out=l.weight.grad)
 
+    def mirror_descriptors(self, flat):
+        """bg_param_mirror entries for the copies of this network's weights that the fp32 layer kernels read (the zero-padded first layer, the
+        transposed hidden layers): handed to bg_optimizer_step, which then writes them together with the parameters.  `flat`: the optimiser's flat
+        parameter buffer (the weights are views of it).  Only buffers that exist are listed (they are created by the first forward / backward)."""
+        out = []
+        if self.SPLIT or not self.FUSED:
+            return out
+        for i, l in enumerate(self.layers):
+            off = (l.weight.data_ptr() - flat.data_ptr()) // 4
+            rows, cols = l.weight.shape
+            if i == 0 and self.w0pad is not None:
+                out.append(_lib.ParamMirror(off, rows, cols, 0, self.w0pad.shape[1], 0, _lib.ptr(self.w0pad)))
+            if self.wt[i] is not None:
+                out.append(_lib.ParamMirror(off, rows, cols, 1, rows, 0, _lib.ptr(self.wt[i])))
+        return out
+
     def _backward_from(self, start, g, finishes=None):
         lib = _lib.load()
         B = self._B
@@ -302,7 +322,9 @@ class MLPTrainer:
                 elif self.FUSED and C_out in (128, 256) and C_in % 128 == 0:
                     if self.wt[i] is None:
                         self.wt[i] = torch.empty(C_in, C_out, dtype=torch.float32, device=g.device)
-                    self.wt[i].copy_(l.weight.t())
+                        self.wt[i].copy_(l.weight.t())
+                    elif not self.mirror_fresh:
+                        self.wt[i].copy_(l.weight.t())
                     if finishes is not None:
                         fin = _lib.ReduceProblem()
                         _lib.check(lib.bg_mlp_layer_backward_partial(B, C_out, C_in, _lib.ptr(g), _lib.ptr(self.wt[i]), _lib.ptr(a_in), _lib.ptr(self.gin[i]),

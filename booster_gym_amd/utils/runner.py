@@ -19,6 +19,7 @@ Reference quirks kept on purpose: GAE recomputed from the cu
 time-out reward overwrite repeated in place (Q4), KL measured with the pre-step distribution (Q6), entropy_coef < 0 (Q7).
 """
 import argparse
+import ctypes
 import glob
 import os
 import random
@@ -73,7 +74,7 @@ class FlatAdam:
                                             _lib.ptr(self.exp_avg_sq), _lib.ptr(self.lr), self.step_count, self.betas[0], self.betas[1], self.eps,
                                             self.max_grad_norm, _lib.ptr(self._gnorm), _lib.current_stream_ptr()), "bg_adam_step")
 
-    def step_fused(self, stats, stats_acc, stats_last, kl_index, count, desired_kl, grad_logstd=None, ls_off=0, lr_min=1e-5, lr_max=1e-2):
+    def step_fused(self, stats, stats_acc, stats_last, kl_index, count, desired_kl, grad_logstd=None, ls_off=0, lr_min=1e-5, lr_max=1e-2, mirrors=None):
         """clip + Adam + KL learning-rate rule + statistics bookkeeping in one launch (bg_optimizer_step): what `step()`, `adapt_lr()` and the
         runner's `stats_acc += stats` / zero fills do as seven dependent launches."""
         self.step_count += 1
@@ -83,7 +84,9 @@ class FlatAdam:
                                                  _lib.ptr(self.lr), self.step_count, self.betas[0], self.betas[1], self.eps, self.max_grad_norm,
                                                  _lib.ptr(grad_logstd), int(ls_off), 0 if grad_logstd is None else grad_logstd.numel(), _lib.ptr(stats),
                                                  _lib.ptr(stats_acc), _lib.ptr(stats_last), stats.numel(), int(kl_index), float(count), desired_kl, lr_min,
-                                                 lr_max, _lib.ptr(self._ticket), _lib.current_stream_ptr()), "bg_optimizer_step")
+                                                 lr_max, _lib.ptr(self._ticket), None if mirrors is None else ctypes.addressof(mirrors),
+                                                 0 if mirrors is None else len(mirrors), _lib.current_stream_ptr()),
+                   "bg_optimizer_step")
 
     def adapt_lr(self, kl_sum, count, desired_kl, lr_min=1e-5, lr_max=1e-2):
         _lib.check(_lib.load().bg_adapt_lr(_lib.ptr(kl_sum), float(count), desired_kl, lr_min, lr_max, _lib.ptr(self.lr), _lib.current_stream_ptr()),
@@ -201,6 +204,8 @@ class Runner:
         # 23.11-23.21 ms deferred against 22.62-22.72 ms with the finishes in the chains, where they already hide under the other network's GEMMs;
         # beside the one-workgroup-per-CU weight-gradient launch they delay its workgroups.  Default off.
         self._defer_finish = os.environ.get("BG_DEFER_FINISH", "0") == "1"
+        # the optimiser launch also writes the transposed / zero-padded weight copies the layer kernels read (bg_param_mirror); 0 = torch copies
+        self._mirror_weights = os.environ.get("BG_MIRROR_WEIGHTS", "1") == "1"
 
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
         # library GEMMs + bg_ppo_loss for these layers (A/B comparisons).
@@ -292,6 +297,7 @@ class Runner:
         alg = cfg["algorithm"]
         act_flat = buf["actions"].reshape(B, A)
         no, npv = self.env.num_obs, self.env.num_privileged_obs
+        self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = False  # weights may have changed outside the loop below (checkpoint, broadcast)
         self._critic_in[:, :, :no].copy_(buf["obses"])
         self._critic_in[:, :, no : no + npv].copy_(buf["privileged_obses"])
         if self._actor_in is not None:
@@ -314,6 +320,7 @@ class Runner:
         self._stats_acc.zero_()
         self._stats.zero_()
         self._grad_logstd.zero_()
+        mirrors = None
         # Two HIP streams: the actor and the critic are independent networks, so the HBM-bound elementwise kernels of one overlap
         # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
         main = torch.cuda.current_stream()
@@ -393,8 +400,14 @@ class Runner:
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
                 if fused_tail:
                     # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch
+                    # ... and the copies of the weights that the layer kernels read (zero-padded first layers, transposed hidden layers): written by the
+                    # same launch instead of six strided torch copies inside the chains of the next mini-epoch
+                    if mirrors is None and self._mirror_weights:
+                        ms = self._critic_tr.mirror_descriptors(self.optimizer.flat) + self._actor_tr.mirror_descriptors(self.optimizer.flat)
+                        mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 8 else None
                     self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
-                                              grad_logstd=None if self.dp.active else self._grad_logstd, ls_off=self._logstd_off)
+                                              grad_logstd=None if self.dp.active else self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
+                    self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = mirrors is not None
                     if self.dp.active:
                         self._grad_logstd.zero_()
                 else:

@@ -259,15 +259,23 @@ int bg_adam_step(int32_t n, float* params, const float* grads, float* exp_avg, f
                  float beta1, float beta2, float eps, float max_grad_norm, double* gnorm_scratch, void* stream);
 /* KL-adaptive learning rate on the device (runner.py:174-180): kl_sum [1] float64 (= stats[4] of bg_ppo_loss), count = samples -> lr_device [1] updated in place */
 int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_min, float lr_max, float* lr_device, void* stream);
+/* A second copy of one [rows][cols] row-major weight matrix of the flat parameter buffer that bg_optimizer_step keeps current while it updates the
+ * parameters: transpose = 0: dst[r * ld + c] (ld >= cols: e.g. the first layer with its input columns zero-padded; the padding is not touched),
+ * transpose = 1: dst[c * ld + r] (ld >= rows: the operand layout of bg_mlp_layer_backward).  offset = index of W[0][0] in params. */
+typedef struct bg_param_mirror {
+    int32_t offset, rows, cols, transpose, ld, pad;
+    float* dst;
+} bg_param_mirror;
 /* The tail of a mini-epoch in one launch (runner.py:162-180): global-norm clip + Adam on the flat buffers (as bg_adam_step), then the KL rule on
  * lr_device (as bg_adapt_lr, with kl_sum = stats[kl_index]), and the bookkeeping of the float64 loss statistics: stats_last = stats,
  * stats_acc += stats, stats = 0 (and grad_logstd = 0) for the next mini-epoch.  grad_logstd (optional, float64 [ls_n]) is the log-std gradient as
  * the head kernels accumulate it; it is written into grads[ls_off .. ls_off + ls_n) first.  stats may be NULL (no learning-rate rule, no
- * bookkeeping).  ticket: one zero-initialised uint32 of device memory owned by the caller.  Deterministic (no float atomics). */
+ * bookkeeping).  ticket: one zero-initialised uint32 of device memory owned by the caller.  mirrors (optional, up to 8): see bg_param_mirror.
+ * Deterministic (no float atomics). */
 int bg_optimizer_step(int32_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr_device, int32_t step, float beta1, float beta2,
                       float eps, float max_grad_norm, double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats, double* stats_acc,
                       double* stats_last, int32_t n_stats, int32_t kl_index, float kl_count, float desired_kl, float lr_min, float lr_max,
-                      uint32_t* ticket, void* stream);
+                      uint32_t* ticket, const bg_param_mirror* mirrors, int32_t n_mirrors, void* stream);
 
 /* MLP backward helper for the ELU layers of utils/model.py:9-26: grad [B][C] <- grad * elu'(.) in place, expressed through the layer OUTPUT
  * act [B][C] (1 if act > 0 else act + 1; act == NULL: identity), and colsum [C] = column sums of the result (= bias gradient).

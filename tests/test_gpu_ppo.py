@@ -144,6 +144,41 @@ def test_adapt_lr_rule():
     assert abs(fa.lr.item() - 1e-2) < 1e-9  # ceiling
 
 
+def test_optimizer_step_keeps_the_weight_mirrors_current():
+    """bg_param_mirror: the optimiser launch writes a zero-padded copy and a transposed copy of chosen weight matrices together with the parameters
+    (what utils/model.py otherwise does with strided torch copies before every forward / backward); bad descriptors are refused."""
+    import ctypes
+    from booster_gym_amd import _lib
+    from booster_gym_amd.utils.runner import FlatAdam
+
+    torch.manual_seed(5)
+    shapes = [(256, 47), (256,), (128, 256), (7,)]
+    ps = [torch.nn.Parameter(torch.randn(*sh, device=DEV)) for sh in shapes]
+    fa = FlatAdam(ps, lr=1e-2)
+    pad = torch.full((256, 64), 7.0, device=DEV)  # columns 47.. are the caller's zero padding: must not be touched
+    pad[:, 47:] = 0.0
+    wt = torch.empty(256, 128, device=DEV)
+    off = lambda p: (p.data_ptr() - fa.flat.data_ptr()) // 4
+    ms = [_lib.ParamMirror(off(ps[0]), 256, 47, 0, 64, 0, _lib.ptr(pad)), _lib.ParamMirror(off(ps[2]), 128, 256, 1, 128, 0, _lib.ptr(wt))]
+    arr = (_lib.ParamMirror * 2)(*ms)
+    stats = torch.zeros(5, dtype=torch.float64, device=DEV); acc = torch.zeros_like(stats); last = torch.zeros_like(stats)
+    for it in range(3):
+        for p in ps:
+            p.grad.copy_(torch.randn_like(p))
+        before = ps[0].detach().clone()
+        fa.step_fused(stats, acc, last, 4, 100.0, 0.01, mirrors=arr)
+        assert not torch.equal(before, ps[0].detach())
+        assert torch.equal(pad[:, :47], ps[0].detach()) and float(pad[:, 47:].abs().sum()) == 0.0, it
+        assert torch.equal(wt, ps[2].detach().t()), it
+    bad = (_lib.ParamMirror * 1)(_lib.ParamMirror(off(ps[2]), 128, 256, 1, 64, 0, _lib.ptr(wt)))  # ld < rows for a transposed mirror
+    with pytest.raises(RuntimeError, match="mirror"):
+        fa.step_fused(stats, acc, last, 4, 100.0, 0.01, mirrors=bad)
+    fa.step_count -= 1
+    bad = (_lib.ParamMirror * 1)(_lib.ParamMirror(fa.flat.numel() - 10, 128, 256, 0, 256, 0, _lib.ptr(wt)))  # runs past the flat buffer
+    with pytest.raises(RuntimeError, match="mirror"):
+        fa.step_fused(stats, acc, last, 4, 100.0, 0.01, mirrors=bad)
+
+
 def test_fused_optimizer_step_equals_the_separate_launches():
     """bg_optimizer_step (clip + Adam + KL learning-rate rule + statistics bookkeeping in one launch) against torch Adam with clip_grad_norm_, the
     reference's learning-rate rule (runner.py:174-180) and plain sums; log-std gradient delivered as float64; deterministic bit for bit."""
