@@ -8,6 +8,7 @@ HIP simulator + 20 full-batch optimiser steps (BASELINE.json configs[1], flat te
 ONE JSON line.  `value` = world * N * T * K / wall (max over ranks).
 """
 import argparse
+import ctypes
 import json
 import os
 import sys
@@ -300,6 +301,7 @@ def main():
         ev_all = runner._critic_tr.timed_events
         ev = [e for e in ev_all if e[5] == 1]
         ev2 = [e for e in ev_all if e[5] == 2]
+        evc = [e for e in ev_all if e[5] == "chain"]
         top_by_time = None
         if ev2:
             us2 = sum(a.elapsed_time(b) for a, b, *_ in ev2) / len(ev2) * 1e3
@@ -309,7 +311,29 @@ def main():
                                      "time in the rocprofv3 summary: the actor's layer 2 runs on it too)", "bound": "mfma", "achieved": fl2 / (us2 * 1e-6) / 1e12,
                            "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "avg_launch_us": us2,
                            "algorithmic_flops_per_launch": fl2, "traffic": pmc_traffic("mlp_fwd_kernel<256, 1, 1>")}
-        if ev:
+        if evc:
+            # the critic's three hidden layers are ONE launch (bg_mlp_chain.hip): timed as a whole, in the loop and alone on the GPU
+            gemm_us = sum(a.elapsed_time(b) for a, b, *_ in evc) / len(evc) * 1e3
+            rows_g, kg, widths = evc[0][2], evc[0][3], evc[0][4]
+            gemm_flop = 2.0 * rows_g * (kg * widths[0] + widths[0] * widths[1] + widths[1] * widths[2])
+            gemm_name = (f"mlp_chain_fwd_kernel<2>: the critic's three fused Linear+bias+ELU layers in one launch, [{rows_g}x{kg}] -> {widths[0]} -> {widths[1]} -> "
+                         f"{widths[2]}, activations handed on in registers, fp32 MFMA 32x32x2 (hand-written HIP, bg_mlp_chain.hip)")
+            tr = runner._critic_tr
+            d = tr._chain_descriptor()
+            lib = _lib.load()
+            solo = lambda: _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, _lib.current_stream_ptr()), "bg_mlp_chain_forward_group")
+            torch.cuda.synchronize()
+            solo_us = float("nan")
+            if not args.no_extra:
+                for _ in range(3):
+                    solo()
+                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                g0.record()
+                for _ in range(30):
+                    solo()
+                g1.record(); torch.cuda.synchronize()
+                solo_us = g0.elapsed_time(g1) / 30 * 1e3
+        elif ev:
             gemm_us = sum(a.elapsed_time(b) for a, b, *_ in ev) / len(ev) * 1e3
             rows_g, kg, ng = ev[0][2], ev[0][3], ev[0][4]
             gemm_name = f"mlp_fwd_kernel<256,1,2>: fused Linear+bias+ELU, critic layer 2, [{rows_g}x{kg}]x[{kg}x{ng}] fp32 MFMA 32x32x2 (hand-written HIP, bg_mlp.hip)"
@@ -345,10 +369,12 @@ def main():
             rows_g, kg, ng = xg.shape[0], lg.weight.shape[1], lg.weight.shape[0]
             gemm_name = f"critic layer-2 forward GEMM [{rows_g}x{kg}]x[{kg}x{ng}] fp32 (hipBLASLt via torch.addmm)"
             solo_us = gemm_us
-        gemm_flop = 2.0 * rows_g * kg * ng
+        if not evc:
+            gemm_flop = 2.0 * rows_g * kg * ng
         gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
         layer_fwd = {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF,
-                     "traffic": pmc_traffic("mlp_fwd_kernel<256, 1, 2>") if rows_g == (T + 1) * 4096 else None, "traffic_source": PMC_SOURCE,
+                     "traffic": pmc_traffic("mlp_chain_fwd_kernel<2>" if evc else "mlp_fwd_kernel<256, 1, 2>") if rows_g == (T + 1) * 4096 else None,
+                     "traffic_source": PMC_SOURCE,
                      "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop,
                      "note": "timed inside the loop, where the actor's kernels run beside it on the second stream",
                      "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,

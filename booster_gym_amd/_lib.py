@@ -60,6 +60,12 @@ class ParamMirror(C.Structure):
                 ("dst", C.c_void_p)]
 
 
+class MlpChain(C.Structure):
+    """bg_mlp_chain: the forward chain of one network for bg_mlp_chain_forward_group (include/booster_gym_amd.h)."""
+    _fields_ = [("M", C.c_int32), ("K0", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("N3", C.c_int32), ("pad", C.c_int32)] + \
+               [(n, C.c_void_p) for n in ("X", "W1", "b1", "W2", "b2", "W3", "b3", "Y1", "Y2", "Y3")]
+
+
 class Rand(C.Structure):
     _fields_ = [("mode", C.c_int32), ("a", C.c_float), ("b", C.c_float)]
 
@@ -105,7 +111,7 @@ SYMBOLS = [
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
     "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
     "bg_env_forward_dynamics", "bg_sim_bind_state", "bg_sim_set_actuation", "bg_sim_apply_body_wrench_local", "bg_sim_simulate",
-    "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_optimizer_step", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_layer_backward", "bg_mlp_split_weights", "bg_mlp_layer_forward_split", "bg_mlp_layer_backward_split", "bg_mlp_weight_grad", "bg_mlp_weight_grad_group", "bg_mlp_weight_grad_group_split",
+    "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_optimizer_step", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_chain_forward", "bg_critic_values_gae", "bg_mlp_chain_forward_group", "bg_mlp_layer_backward", "bg_mlp_split_weights", "bg_mlp_layer_forward_split", "bg_mlp_layer_backward_split", "bg_mlp_weight_grad", "bg_mlp_weight_grad_group", "bg_mlp_weight_grad_group_split",
     "bg_critic_head_forward", "bg_actor_head", "bg_critic_head_backward",
     "bg_reduce_group", "bg_actor_head_partial", "bg_critic_head_backward_partial", "bg_mlp_layer_backward_partial",
     "bg_last_error", "bg_version",
@@ -168,6 +174,9 @@ def load():
         "bg_optimizer_step": (i32, [i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, i32, vp, vp, vp, i32, i32, f32, f32, f32, f32, vp, vp, i32, vp]),
         "bg_elu_backward_colsum": (i32, [i32, i32, vp, vp, vp, vp, vp]),
         "bg_mlp_layer_forward": (i32, [i32, i32, i32, vp, vp, vp, vp, i32, vp]),
+        "bg_mlp_chain_forward": (i32, [i32] * 5 + [vp] * 10 + [vp]),
+        "bg_mlp_chain_forward_group": (i32, [vp, i32, vp]),
+        "bg_critic_values_gae": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]),
         "bg_mlp_layer_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "bg_mlp_split_weights": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, vp]),
         "bg_mlp_layer_forward_split": (i32, [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]),

@@ -410,6 +410,104 @@ __global__ __launch_bounds__(256) void critic_head_forward_kernel(int rows, cons
     }
 }
 
+// values = h w + b for all T + 1 time rows of 16 envs, then the GAE scan of those envs, in ONE launch (what bg_critic_head_forward, a fill and bg_gae do
+// as three dependent launches in front of the actor's loss: ~45 us of small kernels and gaps per mini-epoch).  One workgroup = 16 envs: the value
+// phase is critic_head_forward_kernel's (half a wave per row, same sums: bit-identical values), the values go to LDS and to values_all, threads
+// 0..15 then run gae_kernel's scan on registers (its loads were issued at the top of the kernel).  Moments of the advantages: one float64 triple per
+// workgroup in `partial`; the last workgroup to finish (ticket) adds them up in a fixed order and WRITES sums (no zero fill, no float atomics).
+constexpr int VG_ENVS = 16;
+template <int TMAX>
+__global__ __launch_bounds__(256) void critic_values_gae_kernel(int T, int N, const float* __restrict__ h, const float* __restrict__ w,
+                                                                const float* __restrict__ b, float* __restrict__ rewards,
+                                                                const uint8_t* __restrict__ dones, const uint8_t* __restrict__ touts, float gamma,
+                                                                float lam, float* __restrict__ values_all, float* __restrict__ adv,
+                                                                float* __restrict__ ret, double* __restrict__ partial, unsigned* __restrict__ ticket,
+                                                                double* __restrict__ sums) {
+    __shared__ float sv[(TMAX + 1) * VG_ENVS];
+    __shared__ double sd[3 * 4];
+    __shared__ unsigned s_last;
+    const int e0 = blockIdx.x * VG_ENVS, ne = N - e0 < VG_ENVS ? N - e0 : VG_ENVS;
+    // the scan's operands (threads 0..15: one env each), in flight during the value phase
+    float r[TMAX];
+    uint8_t dn[TMAX], to[TMAX];
+    const bool scan = (int)threadIdx.x < ne;
+    if (scan) {
+#pragma unroll
+        for (int t = 0; t < TMAX; t++)
+            if (t < T) {
+                const size_t k = (size_t)t * N + e0 + threadIdx.x;
+                r[t] = rewards[k]; dn[t] = dones[k]; to[t] = touts[k];
+            }
+    }
+    const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5, R = (T + 1) * VG_ENVS;
+    const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4);
+    const float bias = b[0];
+    for (int r0 = hw * 4; r0 < R; r0 += 32) {
+        float4 x[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int q = r0 + u < R ? r0 + u : R - 1, t = q / VG_ENVS, e = q % VG_ENVS;
+            x[u] = *reinterpret_cast<const float4*>(h + ((size_t)t * N + e0 + (e < ne ? e : ne - 1)) * HK + lane * 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            float s = x[u].x * wv.x;
+            s = fmaf(x[u].y, wv.y, s); s = fmaf(x[u].z, wv.z, s); s = fmaf(x[u].w, wv.w, s);
+            for (int o = 16; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            const int q = r0 + u, t = q / VG_ENVS, e = q % VG_ENVS;
+            if (lane == 0 && q < R) {
+                sv[q] = s + bias;
+                if (e < ne) values_all[(size_t)t * N + e0 + e] = s + bias;
+            }
+        }
+    }
+    __syncthreads();
+    double acc[3] = {0.0, 0.0, 0.0};
+    if (scan) {
+        float next_v = sv[T * VG_ENVS + threadIdx.x], last_adv = 0.f;
+#pragma unroll
+        for (int t = TMAX - 1; t >= 0; t--)
+            if (t < T) {
+                const size_t k = (size_t)t * N + e0 + threadIdx.x;
+                const float v = sv[t * VG_ENVS + threadIdx.x];
+                float rr = r[t];
+                if (to[t]) { rr = v; rewards[k] = v; }  // runner.py:135 (in place, repeated every mini-epoch with the current critic)
+                const float nn = (dn[t] != 0 || to[t] != 0) ? 0.f : 1.f;
+                const float delta = rr + gamma * nn * next_v - v;
+                last_adv = delta + gamma * lam * nn * last_adv;
+                adv[k] = last_adv;
+                ret[k] = v + last_adv;
+                acc[0] += (double)last_adv; acc[1] += (double)last_adv * (double)last_adv; acc[2] += 1.0;
+                next_v = v;
+            }
+    }
+    if (threadIdx.x < 64) {  // the scanning threads all sit in wave 0
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            const double s = wave_sum_d(acc[k]);
+            if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 3 + k] = s;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    }
+    __syncthreads();
+    if (s_last) {  // every workgroup's triple is visible: fixed-order total
+        __threadfence();
+        for (int k = 0; k < 3; k++) {
+            double s = 0.0;
+            for (int g = threadIdx.x; g < (int)gridDim.x; g += 256) s += __builtin_nontemporal_load(&partial[(size_t)g * 3 + k]);
+            s = wave_sum_d(s);
+            if ((threadIdx.x & 63) == 0) sd[k * 4 + (threadIdx.x >> 6)] = s;
+        }
+        __syncthreads();
+        if (threadIdx.x < 3) sums[threadIdx.x] = sd[threadIdx.x * 4] + sd[threadIdx.x * 4 + 1] + sd[threadIdx.x * 4 + 2] + sd[threadIdx.x * 4 + 3];
+        if (threadIdx.x == 0) *ticket = 0u;
+    }
+}
+
 int head_grid(int tiles) { return tiles < HEAD_MAX_GRID ? tiles : HEAD_MAX_GRID; }
 bool aligned16(const void* p) { return ((uintptr_t)p & 15) == 0; }
 
@@ -421,6 +519,20 @@ extern "C" int bg_critic_head_forward(int32_t rows, const float* h, const float*
     int blocks = (rows + 31) / 32;  // 8 half-waves x 4 rows per 256-thread workgroup and pass
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(critic_head_forward_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, rows, h, w, b, values);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_critic_values_gae(int32_t T, int32_t N, const float* h, const float* w, const float* b, float* rewards, const uint8_t* dones,
+                                    const uint8_t* time_outs, float gamma, float lam, float* values_all, float* advantages, float* returns, double* sums,
+                                    double* scratch, void* stream) {
+    if (T <= 0 || N <= 0 || !h || !w || !b || !rewards || !dones || !time_outs || !values_all || !advantages || !returns || !sums || !scratch)
+        return bg_set_error(-1, "bg_critic_values_gae: bad argument");
+    if (!aligned16(h) || !aligned16(w)) return bg_set_error(-1, "bg_critic_values_gae: h and w must be 16-byte aligned");
+    if (T > 32) return bg_set_error(-4, "bg_critic_values_gae: horizon above 32 (use bg_critic_head_forward + bg_gae)");
+    const int grid = (N + VG_ENVS - 1) / VG_ENVS;
+    hipLaunchKernelGGL(critic_values_gae_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, T, N, h, w, b, rewards, dones, time_outs, gamma, lam,
+                       values_all, advantages, returns, scratch, reinterpret_cast<unsigned*>(scratch + (size_t)grid * 3), sums);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -6,6 +6,8 @@ critic (47+14)-256-256-128-1, ELU, state-independent log-std initialised to -2.
 GEMMs run through PyTorch-ROCm (hipBLASLt / rocBLAS, fp32 MFMA); the rollout-time inference + sampling is one
 fused HIP launch (`sample_actions` -> bg_actor_sample).
 """
+import ctypes
+
 import torch
 
 from .. import _lib
@@ -112,6 +114,41 @@ class MLPTrainer:
     def _fusable(cls, k_in, n_out):
         return cls.FUSED and k_in in (64, 128, 256) and n_out % 128 == 0
 
+    # The forward pass of the three hidden layers as one launch (bg_mlp_chain_forward) where the widths are the reference's (BG_MLP_CHAIN=0: one launch
+    # per layer).  
+    CHAIN = __import__("os").environ.get("BG_MLP_CHAIN", "1") == "1"
+
+    def _chainable(self):
+        ls = self.layers
+        return (self.CHAIN and self.FUSED and not self.SPLIT and len(ls) == 4 and self._kin == 64 and self.w0pad is not None
+                and tuple(l.weight.shape[0] for l in ls[:3]) in ((256, 128, 128), (256, 256, 128))
+                and ls[1].weight.shape[1] == ls[0].weight.shape[0] and ls[2].weight.shape[1] == ls[1].weight.shape[0])
+
+    def _chain_descriptor(self):
+        """bg_mlp_chain of this network's hidden layers on the input of the forward pass in progress (self.x)."""
+        ls = self.layers
+        if not self.mirror_fresh:
+            self.w0pad[:, : ls[0].weight.shape[1]].copy_(ls[0].weight)
+        p = _lib.ptr
+        return _lib.MlpChain(self.x.shape[0], self._kin, ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0], 0, p(self.x), p(self.w0pad),
+                             p(ls[0].bias), p(ls[1].weight), p(ls[1].bias), p(ls[2].weight), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]), p(self.acts[2]))
+
+    @staticmethod
+    def forward_hidden_group(jobs):
+        """forward_hidden of several networks: jobs = [(trainer, x, train_rows), ...]; returns the list of last-hidden activations.  Where every
+        network can run the chained kernel they share ONE launch on the current stream (bg_mlp_chain_forward_group): the slabs of the first job are
+        dispatched first, the others fill the machine as those retire.  Otherwise one forward_hidden after the other."""
+        for tr, x, train_rows in jobs:
+            B = x.shape[0] if train_rows is None else train_rows
+            if tr._B != B or tr._rows != x.shape[0] or tr._kin != x.shape[1]:
+                tr._alloc(x.shape[0], B, x.device, x.shape[1])
+            tr.x = x
+        if not all(tr._chainable() for tr, _, _ in jobs) or len(jobs) > 4:
+            return [tr.forward_hidden(x, train_rows) for tr, x, train_rows in jobs]
+        ds = (_lib.MlpChain * len(jobs))(*[tr._chain_descriptor() for tr, _, _ in jobs])
+        _lib.check(_lib.load().bg_mlp_chain_forward_group(ctypes.addressof(ds), len(jobs), _lib.current_stream_ptr()), "bg_mlp_chain_forward_group")
+        return [tr.acts[2] for tr, _, _ in jobs]
+
     def __init__(self, seq, max_split=32):
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
         self.max_split = max_split
@@ -130,7 +167,9 @@ class MLPTrainer:
         rows may ride along in the forward pass (the critic evaluates the T+1'th observation in the same GEMMs).  `k_in` > in_features of
         the first layer means the caller zero-padded the input columns (61 -> 64, 47 -> 64) so that the first layer, too, runs on the fused kernel."""
         self._rows, self._B, self._S, self._kin = rows, B, self._split(B), k_in
-        self.acts = [torch.empty(rows, l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
+        # (rows rounded up to whole 128-row slabs: the chained forward kernel stores every slab in full)
+        rows_pad = (rows + 127) // 128 * 128
+        self.acts = [torch.empty(rows_pad, l.weight.shape[0], dtype=torch.float32, device=dev)[:rows] for l in self.layers]
         self.gin = [None] + [torch.empty(B, l.weight.shape[1], dtype=torch.float32, device=dev) for l in self.layers[1:]]
         self.cs = [torch.empty(((B + 127) // 128) * l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
         # weight gradients: hand-written split-over-the-batch MFMA kernel (bg_mlp_weight_grad) where the shape allows, scratch = slices x dW
@@ -180,7 +219,22 @@ class MLPTrainer:
         self.x, h = x, x
         last = len(self.layers) - 1
         lib, stream = _lib.load(), _lib.current_stream_ptr()
+        first = 0
+        if self._chainable():
+            # the three hidden layers in ONE launch, activations handed on in registers (bg_mlp_chain.hip); bit-identical to the per-layer launches
+            timed = self.timed_layer is not None
+            if timed:  # bench.py: HIP events on the launch stream around this one kernel
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            d = self._chain_descriptor()
+            _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, stream), "bg_mlp_chain_forward_group")
+            if timed:
+                e1.record()
+                self.timed_events.append((e0, e1, x.shape[0], self._kin, tuple(l.weight.shape[0] for l in self.layers[:3]), "chain"))
+            first, h = 3, self.acts[2]
         for i, l in enumerate(self.layers):
+            if i < first:
+                continue
             if i == last and _stop_before_output:
                 break
             n_out, k_in = l.weight.shape

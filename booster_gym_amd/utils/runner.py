@@ -35,7 +35,7 @@ from .config import load_cfg
 from .model import ActorCritic, GroupedWeightGrad, MLPTrainer
 from .parallel import DataParallel
 from .recorder import Recorder
-from .utils import (actor_head_forward, actor_head_loss_backward, critic_head_backward, critic_head_forward, gae, gaussian_logp, head_scratch, reduce_group,
+from .utils import (actor_head_forward, actor_head_loss_backward, critic_head_backward, critic_head_forward, critic_values_gae, gae, gaussian_logp, head_scratch, reduce_group,
                     ppo_loss_fused)
 
 
@@ -206,6 +206,12 @@ class Runner:
         self._defer_finish = os.environ.get("BG_DEFER_FINISH", "0") == "1"
         # the optimiser launch also writes the transposed / zero-padded weight copies the layer kernels read (bg_param_mirror); 0 = torch copies
         self._mirror_weights = os.environ.get("BG_MIRROR_WEIGHTS", "1") == "1"
+        # both networks' forward chains in one launch (see update()); 0 = one launch per network on its own stream
+        self._group_forward = os.environ.get("BG_GROUP_FORWARD", "0") == "1"
+        # critic output layer + GAE in one launch (bg_critic_values_gae); 0 = bg_critic_head_forward, a fill and bg_gae
+        self._fused_gae = os.environ.get("BG_FUSED_GAE", "1") == "1" and self.cfg["runner"]["horizon_length"] <= 32
+        self._gae_scratch = torch.zeros(3 * ((self.env.num_envs + 15) // 16) + 1, dtype=torch.float64, device=self.device)
+        self._actor_after = os.environ.get("BG_ACTOR_AFTER", "0") == "1"
 
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
         # library GEMMs + bg_ppo_loss for these layers (A/B comparisons).
@@ -329,16 +335,32 @@ class Runner:
             for _ in range(cfg["runner"]["mini_epochs"]):
                 # parameters updated by the previous optimiser step; the loss accumulators (_stats, _grad_logstd) were zeroed by it (before the loop
                 # for the first mini-epoch): both heads add into them
+                group_fwd = fused_head and self._group_forward
+                if group_fwd:
+                    # the hidden layers of BOTH networks in one launch (bg_mlp_chain_forward_group): the critic's slabs are dispatched first (the GAE and
+                    # with it the actor's loss wait for its values), the actor's fill the machine as they retire
+                    hc, ha = MLPTrainer.forward_hidden_group([(self._critic_tr, critic_all, B), (self._actor_tr, obs_flat, None)])
                 side.wait_stream(main)
+                if self._actor_after and side is not main and not group_fwd:
+                    # the actor's forward may not start before the side stream has taken up this mini-epoch: the critic's slabs, which the GAE and with
+                    # it the actor's own loss wait for, then reach the CUs first instead of ~15 us behind the actor's
+                    main.wait_event(side.record_event())
                 with torch.cuda.stream(side):
                     if fused_head:
-                        hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
-                        v_all = critic_head_forward(hc, c_out.weight, c_out.bias, self._values_all)
+                        if not group_fwd:
+                            hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
+                        if self._fused_gae:
+                            # output layer + timeout bootstrap + GAE + returns + advantage moments in ONE launch in front of the actor's loss
+                            v_all = critic_values_gae(hc, c_out.weight, c_out.bias, buf["rewards"], buf["dones"], buf["time_outs"], alg["gamma"], alg["lam"],
+                                                      self._values_all, self._adv, self._ret, self._adv_sums, self._gae_scratch)
+                        else:
+                            v_all = critic_head_forward(hc, c_out.weight, c_out.bias, self._values_all)
                     else:
                         v_all = self._critic_tr.forward(critic_all, train_rows=B).squeeze(-1)
                     values, last_values = v_all[:B], v_all[B:]
-                    gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
-                        advantages=self._adv, returns=self._ret, sums=self._adv_sums)
+                    if not (fused_head and self._fused_gae):
+                        gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
+                            advantages=self._adv, returns=self._ret, sums=self._adv_sums)
                     self.dp.sum_(self._adv_sums)  # exchange (1), on the side stream: hidden under the actor forward
                     gae_done = side.record_event()
                 if fused_head:
@@ -350,7 +372,8 @@ class Runner:
                     defer = self._defer_finish and not MLPTrainer.SPLIT
                     fins = [] if defer else None
                     fin_c, fin_a = (_lib.ReduceProblem(), _lib.ReduceProblem()) if defer else (None, None)
-                    ha = self._actor_tr.forward_hidden(obs_flat)
+                    if not group_fwd:
+                        ha = self._actor_tr.forward_hidden(obs_flat)
                     with torch.cuda.stream(side):
                         critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,
                                              c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c, finish=fin_c)

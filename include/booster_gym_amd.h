@@ -285,6 +285,21 @@ int bg_elu_backward_colsum(int32_t B, int32_t C, float* grad, const float* act, 
 /* Fused MLP layer forward: Y [M][N] = act(X [M][K] . W[N][K]^T + bias[N]) in fp32 MFMA with bias + ELU in the GEMM epilogue
  * (utils/model.py:9-26 Linear + ELU).  Supported: K in {64, 128, 256}, N a multiple of 128; other shapes return -4 (caller uses the library GEMM). */
 int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const float* W, const float* bias, float* Y, int32_t elu, void* stream);
+/* The three hidden Linear + ELU layers of one network (utils/model.py:9-26, forward of runner.py:132,147) in ONE launch: Y1 = elu(X W1^T + b1) [M][N1],
+ * Y2 = elu(Y1 W2^T + b2) [M][N2], Y3 = elu(Y2 W3^T + b3) [M][N3], every activation stored for the backward pass; between the layers the
+ * activations stay in registers (bg_mlp_chain.hip).  X [M][K0] with K0 = 64 (zero-padded input columns), W row-major [out][in] as torch's Linear.
+ * Supported widths (N1, N2, N3): (256, 128, 128) and (256, 256, 128), the reference's actor and critic.  Y1 / Y2 / Y3 must hold
+ * ceil(M / 128) * 128 rows (rows >= M of the last slab are written with unspecified values).  Bit-identical to three bg_mlp_layer_forward
+ * launches.  -4: unsupported widths. */
+typedef struct bg_mlp_chain {
+    int32_t M, K0, N1, N2, N3, pad;
+    const float *X, *W1, *b1, *W2, *b2, *W3, *b3;
+    float *Y1, *Y2, *Y3;
+} bg_mlp_chain;
+int bg_mlp_chain_forward(int32_t M, int32_t K0, int32_t N1, int32_t N2, int32_t N3, const float* X, const float* W1, const float* b1, const float* W2,
+                         const float* b2, const float* W3, const float* b3, float* Y1, float* Y2, float* Y3, void* stream);
+/* 1 to 4 networks in one launch; the 128-row slabs of nets[0] are dispatched first, those of the next network fill the machine as they retire. */
+int bg_mlp_chain_forward_group(const bg_mlp_chain* nets, int32_t count, void* stream);
 
 /* Fused MLP layer backward through one Linear and the ELU below it:  Gout [M][N] = (G [M][K] . Wt[N][K]^T) * elu'(act_below [M][N]) and
  * bias_grad_below [N] = column sums of Gout.  G = dL/dz of the upper layer (K = its width), Wt = that layer's weight TRANSPOSED to [N][K]
@@ -344,6 +359,14 @@ int bg_mlp_weight_grad_group_split(const bg_wgrad_problem* problems, int32_t cou
 #define BG_HEAD_SCRATCH_FLOATS (768 * 1720)
 /* critic.6 forward: values [rows] = h w + b   (w [128], b [1]) */
 int bg_critic_head_forward(int32_t rows, const float* h, const float* w, const float* b, float* values, void* stream);
+/* bg_critic_head_forward on all (T + 1) N rows of h (time-major: row t N + e), then bg_gae on the result, in ONE launch (utils/runner.py:132-141: values,
+ * last values, timeout bootstrap, discount_values, returns): values_all [(T + 1) N] (the last N = last_values), advantages / returns [T][N], rewards
+ * overwritten at time-outs as bg_gae does, sums float64 [3] WRITTEN (sum, sum of squares, count; fixed order: deterministic).  scratch: float64
+ * [3 * ceil(N / 16) + 1], its last element zero-initialised once by the caller (the launch leaves it zero).  Values bit-identical to
+ * bg_critic_head_forward, advantages to bg_gae.  -4: T > 32. */
+int bg_critic_values_gae(int32_t T, int32_t N, const float* h, const float* w, const float* b, float* rewards, const uint8_t* dones,
+                         const uint8_t* time_outs, float gamma, float lam, float* values_all, float* advantages, float* returns, double* sums,
+                         double* scratch, void* stream);
 /* actor.6 forward (mode 0: mu_out [B][12] = h W^T + b, nothing else is touched) or forward + PPO actor loss + backward (mode 1), with the
  * argument meaning of bg_ppo_loss: out g_hidden [B][128] = dL/dz of the last hidden layer, grad_W [12][128], grad_b [12],
  * grad_b_hidden [128] (bias gradient of the last hidden layer = column sums of g_hidden), grad_logstd [12] float64 and

@@ -163,3 +163,40 @@ def test_deferred_reductions_equal_the_immediate_finishes():
     assert _lib.load().bg_reduce_group(None, 1, None) == -1
     bad = _lib.ReduceProblem()
     assert _lib.load().bg_reduce_group((_lib.ReduceProblem * 1)(bad), 1, None) == -1
+
+
+@pytest.mark.parametrize("T,N", [(24, 4096), (24, 100), (5, 17), (32, 16)])
+def test_critic_values_and_gae_in_one_launch_equal_the_separate_launches(T, N):
+    """bg_critic_values_gae against bg_critic_head_forward followed by bg_gae on the same inputs (time-outs, dones, ragged env counts): values,
+    advantages, returns and the in-place time-out bootstrap of the rewards bit for bit; the float64 moments to 1e-12 (another fixed summation
+    order); a second call (ticket left at zero, sums overwritten) gives the same bits; T > 32 is refused."""
+    from booster_gym_amd.utils.utils import critic_head_forward, critic_values_gae, gae
+
+    g = torch.Generator(device="cpu").manual_seed(7 + T + N)
+    dev = "cuda:0"
+    h = torch.nn.functional.elu(torch.randn((T + 1) * N, 128, generator=g)).to(dev)
+    w, b = (torch.randn(1, 128, generator=g) * 0.1).to(dev), torch.randn(1, generator=g).to(dev)
+    rew = torch.randn(T, N, generator=g).to(dev)
+    dones = (torch.rand(T, N, generator=g) < 0.05).to(dev)
+    touts = ((torch.rand(T, N, generator=g) < 0.03).to(dev)) & dones
+    r0 = rew.clone()
+    v0 = critic_head_forward(h, w, b, torch.empty((T + 1) * N, device=dev))
+    adv0, ret0, s0 = gae(r0, dones, touts, v0[: T * N].view(T, N), v0[T * N :], 0.995, 0.95)
+    scratch = torch.zeros(3 * ((N + 15) // 16) + 1, dtype=torch.float64, device=dev)
+    for rep in range(2):
+        r1 = rew.clone()
+        v1, adv1, ret1 = torch.full(((T + 1) * N,), float("nan"), device=dev), torch.full((T, N), float("nan"), device=dev), torch.full((T, N), float("nan"), device=dev)
+        s1 = torch.full((3,), 123.0, dtype=torch.float64, device=dev)  # must be overwritten, not added to
+        critic_values_gae(h, w, b, r1, dones, touts, 0.995, 0.95, v1, adv1, ret1, s1, scratch)
+        assert torch.equal(v1, v0) and torch.equal(adv1, adv0) and torch.equal(ret1, ret0) and torch.equal(r1, r0), rep
+        assert torch.allclose(s1, s0, rtol=1e-12, atol=1e-9) and float(s1[2]) == T * N, (s1, s0)
+        assert float(scratch[-1]) == 0.0
+        if rep == 0:
+            s_first = s1.clone()
+        else:
+            assert torch.equal(s1, s_first)
+    if T == 32:
+        big = torch.zeros(33, N, device=dev)
+        with pytest.raises(RuntimeError, match="horizon"):
+            critic_values_gae(torch.zeros(34 * N, 128, device=dev), w, b, big, big.bool(), big.bool(), 0.99, 0.95, torch.zeros(34 * N, device=dev), big.clone(),
+                              big.clone(), s1, scratch)

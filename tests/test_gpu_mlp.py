@@ -176,3 +176,76 @@ def test_mlp_weight_grad_group_small_batches(M):
             ref64 = G.double().t() @ A.double()[:, :cr]
             err, err_t = (dW.double() - ref64).abs().max().item(), ((G.t() @ A[:, :cr]).double() - ref64).abs().max().item()
             assert torch.isfinite(dW).all() and err <= max(4 * err_t, 1e-4), (M, share_rows, co, ci, err, err_t)
+
+
+def _chain_case(M, dims, seed):
+    import ctypes
+    from booster_gym_amd import _lib
+
+    K0, N1, N2, N3 = dims
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    x = torch.randn(M, K0, generator=g).to(DEV)
+    Ws = [(torch.randn(n, k, generator=g) / k**0.5).to(DEV) for k, n in ((K0, N1), (N1, N2), (N2, N3))]
+    for W in Ws:  # asymmetric entries catch transposed / permuted fragment maps
+        W[3, 5] = 3.0; W[W.shape[0] - 1, 0] = -2.0
+    bs = [(torch.randn(n, generator=g) * 0.3).to(DEV) for n in (N1, N2, N3)]
+    pad = (M + 127) // 128 * 128
+    ys = [torch.full((pad, n), float("nan"), device=DEV) for n in (N1, N2, N3)]
+    p = _lib.ptr
+    d = _lib.MlpChain(M, K0, N1, N2, N3, 0, p(x), p(Ws[0]), p(bs[0]), p(Ws[1]), p(bs[1]), p(Ws[2]), p(bs[2]), p(ys[0]), p(ys[1]), p(ys[2]))
+    return d, x, Ws, bs, ys
+
+
+def _chain_check(M, x, Ws, bs, ys):
+    """against torch fp64 on every row, and bit for bit against three per-layer launches (the same sums in the same order)"""
+    from booster_gym_amd import _lib
+
+    lib, st = _lib.load(), _lib.current_stream_ptr()
+    ref, hin = x.double(), x
+    for l in range(3):
+        ref = torch.nn.functional.elu(ref @ Ws[l].double().t() + bs[l].double())
+        y = ys[l][:M]
+        assert torch.isfinite(y).all(), l
+        err = (y.double() - ref).abs().max().item()
+        assert err < 2e-5 * max(1.0, ref.abs().max().item()), (l, err)
+        z = torch.empty(M, Ws[l].shape[0], device=DEV)
+        _lib.check(lib.bg_mlp_layer_forward(M, hin.shape[1], Ws[l].shape[0], _lib.ptr(hin), _lib.ptr(Ws[l]), _lib.ptr(bs[l]), _lib.ptr(z), 1, st))
+        assert torch.equal(y, z), l
+        hin = z
+
+
+@pytest.mark.parametrize("M,dims", [(98304, (64, 256, 128, 128)), (102400, (64, 256, 256, 128)), (1000, (64, 256, 256, 128)), (77, (64, 256, 128, 128))])
+def test_mlp_chain_forward_matches_torch_fp64(M, dims):
+    """bg_mlp_chain_forward_group (three Linear+ELU layers of a network in one launch, activations in registers between them) at the training
+    shapes (M = 98,304 / 102,400) and on ragged batches: every stored activation against torch fp64 and the per-layer kernels."""
+    import ctypes
+    from booster_gym_amd import _lib
+
+    d, x, Ws, bs, ys = _chain_case(M, dims, seed=M + dims[2])
+    _lib.check(_lib.load().bg_mlp_chain_forward_group(ctypes.addressof(d), 1, _lib.current_stream_ptr()))
+    _chain_check(M, x, Ws, bs, ys)
+
+
+def test_mlp_chain_forward_group_of_two_networks_and_bad_arguments():
+    import ctypes
+    from booster_gym_amd import _lib
+
+    lib, st = _lib.load(), _lib.current_stream_ptr()
+    dc, xc, Wc, bc, yc = _chain_case(2400 + 4096, (64, 256, 256, 128), seed=1)
+    da, xa, Wa, ba, ya = _chain_case(2400, (64, 256, 128, 128), seed=2)
+    arr = (_lib.MlpChain * 2)(dc, da)
+    _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(arr), 2, st))
+    _chain_check(2400 + 4096, xc, Wc, bc, yc)
+    _chain_check(2400, xa, Wa, ba, ya)
+    # the flat entry point is the group of one
+    for y in ya:
+        y.fill_(float("nan"))
+    p = _lib.ptr
+    _lib.check(lib.bg_mlp_chain_forward(2400, 64, 256, 128, 128, p(xa), p(Wa[0]), p(ba[0]), p(Wa[1]), p(ba[1]), p(Wa[2]), p(ba[2]), p(ya[0]), p(ya[1]), p(ya[2]), st))
+    _chain_check(2400, xa, Wa, ba, ya)
+    assert lib.bg_mlp_chain_forward(2400, 64, 512, 128, 128, p(xa), p(Wa[0]), p(ba[0]), p(Wa[1]), p(ba[1]), p(Wa[2]), p(ba[2]), p(ya[0]), p(ya[1]), p(ya[2]), st) == -4
+    assert lib.bg_mlp_chain_forward(2400, 47, 256, 128, 128, p(xa), p(Wa[0]), p(ba[0]), p(Wa[1]), p(ba[1]), p(Wa[2]), p(ba[2]), p(ya[0]), p(ya[1]), p(ya[2]), st) == -4
+    assert lib.bg_mlp_chain_forward(0, 64, 256, 128, 128, p(xa), p(Wa[0]), p(ba[0]), p(Wa[1]), p(ba[1]), p(Wa[2]), p(ba[2]), p(ya[0]), p(ya[1]), p(ya[2]), st) == -1
+    assert lib.bg_mlp_chain_forward(2400, 64, 256, 128, 128, p(xa).value + 4, p(Wa[0]), p(ba[0]), p(Wa[1]), p(ba[1]), p(Wa[2]), p(ba[2]), p(ya[0]), p(ya[1]), p(ya[2]), st) == -1
+    assert lib.bg_mlp_chain_forward_group(ctypes.addressof(arr), 5, st) == -1
+    assert b"widths" in lib.bg_last_error() or b"network" in lib.bg_last_error()
