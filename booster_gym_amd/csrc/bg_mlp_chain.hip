@@ -23,6 +23,14 @@
 
 extern int bg_set_error(int code, const char* msg);
 
+#ifdef BG_CHAIN_PROBE_STAMPS  // tools/mlp_chain_stamps.py: shader-clock stamp of every wave behind every chunk barrier (never defined in the product build)
+__device__ long long bg_chain_stamp_buf[2048 * 4 * 24];
+extern "C" int bg_probe_read_chain_stamps(void* dst, size_t bytes) { return (int)hipMemcpyFromSymbol(dst, HIP_SYMBOL(bg_chain_stamp_buf), bytes); }
+#define BG_CHAIN_STAMP(K) stamps[K] = clock64()
+#else
+#define BG_CHAIN_STAMP(K) do { } while (0)
+#endif
+
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -97,6 +105,10 @@ __device__ __forceinline__ void chain_slab(const bg_mlp_chain& a, int slab, floa
         else if (cc < C0 + C1) dma_rows<N1, N2>(W2, cc - C0, dst, wave, lo2);
         else if (cc < C) dma_rows<N2, N3>(W3, cc - C0 - C1, dst, wave, lo3);
     };
+#ifdef BG_CHAIN_PROBE_STAMPS
+    long long stamps[24];
+#endif
+    BG_CHAIN_STAMP(0);
     dma(0);
     dma(1);
     dma(2);
@@ -128,6 +140,7 @@ __device__ __forceinline__ void chain_slab(const bg_mlp_chain& a, int slab, floa
             wait_vm<S::behind(c)>();
             if (c == 0) __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the bias values written to sB above
             asm volatile("s_barrier" ::: "memory");  // no fence: a workgroup fence would drain vmcnt (stores and younger copies included)
+            BG_CHAIN_STAMP(c + 1);
             __builtin_amdgcn_sched_barrier(0);
             dma(c + AHEAD);
             __builtin_amdgcn_sched_barrier(0);
@@ -176,6 +189,11 @@ __device__ __forceinline__ void chain_slab(const bg_mlp_chain& a, int slab, floa
     layer(a1, [&](int s) { return x0[s]; }, std::integral_constant<int, K0>{}, std::integral_constant<int, N1>{}, std::integral_constant<int, 0>{}, 0, a.Y1);
     layer(a2, [&](int s) { return a1[s >> 4][s & 15]; }, std::integral_constant<int, N1>{}, std::integral_constant<int, N2>{}, std::integral_constant<int, C0>{}, N1, a.Y2);
     layer(a3, [&](int s) { return a2[s >> 4][s & 15]; }, std::integral_constant<int, N2>{}, std::integral_constant<int, N3>{}, std::integral_constant<int, C0 + C1>{}, N1 + N2, a.Y3);
+#ifdef BG_CHAIN_PROBE_STAMPS
+    stamps[C + 1] = clock64();
+    if (lane == 0 && blockIdx.x < 2048)
+        for (int k = 0; k < 24; k++) bg_chain_stamp_buf[((size_t)blockIdx.x * 4 + wave) * 24 + k] = k <= C + 1 ? stamps[k] : 0;
+#endif
 }
 
 // TAG: 1 / 2 = one network with N2 = 128 / 256 (the layer shape gets its own kernel symbol: a profiler's per-kernel average is then the average of
