@@ -7,10 +7,10 @@ import torch
 from booster_gym_amd import _lib
 lib = _lib.load(); dev = "cuda:0"
 HERE = os.path.dirname(os.path.abspath(__file__))
-so = os.path.join(HERE, "probe", "libmlp_chain.bin")
+so = os.path.join(HERE, "..", "probe", "libmlp_chain.bin")
 if not os.path.isfile(so):
     subprocess.check_call(["/opt/rocm/bin/hipcc", "-O3", "-std=c++17", "-fPIC", "--offload-arch=gfx950", "-fno-slp-vectorize", "-mllvm",
-                           "-amdgpu-sched-strategy=max-ilp", "-shared", "-o", so, os.path.join(HERE, "probe", "mlp_chain.hip")])
+                           "-amdgpu-sched-strategy=max-ilp", "-shared", "-o", so, os.path.join(HERE, "mlp_chain_probe_v1.hip")])
 ch = C.CDLL(so)
 ch.bg_mlp_chain_forward.restype = C.c_int32
 ch.bg_mlp_chain_forward.argtypes = [C.c_int32] * 5 + [C.c_void_p] * 10 + [C.c_int32, C.c_void_p]
