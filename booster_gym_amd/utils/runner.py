@@ -199,11 +199,13 @@ class Runner:
         # the critic's stream goes ahead of the actor's in workgroup dispatch: its chain is the longer one and the actor's loss waits for its GAE
         # (update 23.17 -> 23.06 ms, tools/archive/ab_prio.sh; BG_SIDE_PRIORITY=0: equal priorities)
         self._side_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("BG_SIDE_PRIORITY", "-1")))
-        # Opt-in (BG_DEFER_FINISH=1): the small fixed-order reductions behind the head / backward-layer kernels as ONE launch on the side stream beside
-        # the weight gradients instead of inside the chains (see update()).  Measured in the loop (tools/ab_env.sh, 3 alternating runs each): update
-        # 23.11-23.21 ms deferred against 22.62-22.72 ms with the finishes in the chains, where they already hide under the other network's GEMMs;
-        # beside the one-workgroup-per-CU weight-gradient launch they delay its workgroups.  Default off.
-        self._defer_finish = os.environ.get("BG_DEFER_FINISH", "0") == "1"
+        # The small fixed-order reductions behind the head / backward-layer kernels run as ONE launch in front of the weight gradients instead of
+        # inside the chains, where each of them waits 20-45 us for a workgroup slot between the other network's resident GEMM workgroups (see
+        # update()).  Measured in the loop (tools/ab_env.sh, 4 alternating runs of 20 iterations each): update 21.68-21.91 ms with the one launch in
+        # front of the weight gradients (BG_DEFER_FINISH=1, the default), 21.85-21.97 ms with it on the side stream BESIDE them (=2: it delays the
+        # one-workgroup-per-CU launch), 21.99-22.04 ms with the finishes inside the chains (=0).
+        self._defer_finish = os.environ.get("BG_DEFER_FINISH", "1") in ("1", "2")
+        self._defer_serial = os.environ.get("BG_DEFER_FINISH", "1") != "2"
         # the optimiser launch also writes the transposed / zero-padded weight copies the layer kernels read (bg_param_mirror); 0 = torch copies
         self._mirror_weights = os.environ.get("BG_MIRROR_WEIGHTS", "1") == "1"
         # both networks' forward chains in one launch (see update()); 0 = one launch per network on its own stream
@@ -366,7 +368,7 @@ class Runner:
                 if fused_head:
                     # Output layers fused with the loss (bg_head.hip): per network ONE pass over the [B][128] hidden activations gives the
                     # output, the loss terms, dL/dz of the hidden layer and the output layer's gradients.  Both heads add into _stats.
-                    # defer (opt-in, see __init__): the small fixed-order reductions behind the head kernels and behind every backward layer
+                    # defer (the default, see __init__): the small fixed-order reductions behind the head kernels and behind every backward layer
                     # (output-layer and bias gradients, loss statistics: nothing a chain needs) run as ONE launch on the side stream beside the
                     # weight-gradient launch (bg_reduce_group) instead of inside the chains.
                     defer = self._defer_finish and not MLPTrainer.SPLIT
@@ -404,7 +406,15 @@ class Runner:
                 if (self.dp.active or not fused_tail) and not defer:
                     self._logstd_grad_view.copy_(self._grad_logstd)  # into the flat bucket before the all-reduce
                 main.wait_stream(side)
-                if defer:  # the deferred reductions (+ what depends on them) on the side stream, beside the weight gradients on the main stream
+                if defer and self._defer_serial:  # the deferred reductions as one launch in FRONT of the weight gradients (the default)
+                    reduce_group([fin_c, fin_a] + fins)
+                    if self.dp.active or not fused_tail:
+                        self._logstd_grad_view.copy_(self._grad_logstd)
+                    if self.dp.active:
+                        side.wait_stream(main)
+                        with torch.cuda.stream(side):
+                            self.dp.sum_(self._stats)  # exchange (3), beside the weight gradients
+                elif defer:  # BG_DEFER_FINISH=2: ... (+ what depends on them) on the side stream, beside the weight gradients on the main stream
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         reduce_group([fin_c, fin_a] + fins)
@@ -418,7 +428,7 @@ class Runner:
                     else:
                         self._critic_tr.weight_grads()
                         self._actor_tr.weight_grads()
-                if defer:
+                if defer and (self.dp.active or not self._defer_serial):
                     main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
                 if fused_tail:

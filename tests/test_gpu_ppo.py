@@ -273,17 +273,17 @@ def test_full_update_matches_reference_loop():
 
 
 def test_update_with_deferred_reductions_equals_update_with_immediate_ones():
-    """Runner.update() with the small reductions deferred to one launch beside the weight gradients (BG_DEFER_FINISH=1) and with every finish
-    inside its chain (the default) from identical weights and rollout data: same parameters after 3 mini-epochs up to the summation order of the
-    hidden layers' bias gradients, same loss statistics."""
+    """Runner.update() with the small reductions deferred to one launch in front of the weight gradients (the default), to one launch on the side
+    stream beside them (BG_DEFER_FINISH=2) and with every finish inside its chain (=0), from identical weights and rollout data: same parameters
+    after 3 mini-epochs up to the summation order of the hidden layers' bias gradients, same loss statistics."""
     from booster_gym_amd.utils.config import load_cfg
     from booster_gym_amd.utils.runner import Runner
 
     res = []
-    for defer in (True, False):
+    for defer, serial in ((True, True), (True, False), (False, True)):
         cfg = load_cfg("T1", {"env.num_envs": 128, "terrain.type": "plane", "runner.mini_epochs": 3})
         r = Runner(cfg=cfg)
-        r._defer_finish = defer
+        r._defer_finish, r._defer_serial = defer, serial
         obs, infos = r.env.reset()
         r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
         r.rollout()
@@ -291,10 +291,12 @@ def test_update_with_deferred_reductions_equals_update_with_immediate_ones():
         torch.cuda.synchronize()
         res.append((r.optimizer.flat.clone(), acc, r._summarize(acc)))
         del r
-    (p1, a1, s1), (p0, a0, s0) = res
-    assert torch.allclose(p1, p0, rtol=1e-5, atol=1e-7), (p1 - p0).abs().max().item()
-    assert torch.allclose(a1, a0, rtol=1e-4)
-    assert abs(s1["lr"] - s0["lr"]) < 1e-12
+    p0, a0, s0 = res[2]
+    for p1, a1, s1 in res[:2]:
+        assert torch.allclose(p1, p0, rtol=1e-5, atol=1e-7), (p1 - p0).abs().max().item()
+        assert torch.allclose(a1, a0, rtol=1e-4)
+        assert abs(s1["lr"] - s0["lr"]) < 1e-12
+    assert torch.equal(res[0][0], res[1][0])  # the two deferred forms run the same launches: identical bits
 
 
 @pytest.mark.parametrize("B,C,with_act", [(98304, 256, True), (98304, 128, True), (3000, 256, True), (1000, 128, True), (777, 12, False), (98304, 1, False),
