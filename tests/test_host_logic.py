@@ -33,14 +33,17 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     from booster_gym_amd import _lib
 
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "booster_gym_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(bg_env_cfg), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "booster_gym_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bg_env_cfg), '
                    "sizeof(bg_model_desc), offsetof(bg_env_cfg, reward_scale), offsetof(bg_env_cfg, terrain_type), offsetof(bg_env_cfg, noise_gravity), "
-                   "offsetof(bg_model_desc, feet_edge_pos));return 0;}\n")
+                   "offsetof(bg_model_desc, feet_edge_pos), sizeof(bg_param_mirror), offsetof(bg_param_mirror, dst), sizeof(bg_mlp_chain), offsetof(bg_mlp_chain, Y1), "
+                   "sizeof(bg_reduce_problem));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     E, M = _lib.EnvCfg, _lib.ModelDesc
-    assert got == [C.sizeof(E), C.sizeof(M), E.reward_scale.offset, E.terrain_type.offset, E.noise_gravity.offset, M.feet_edge_pos.offset]
+    P, Q, R = _lib.ParamMirror, _lib.MlpChain, _lib.ReduceProblem
+    assert got == [C.sizeof(E), C.sizeof(M), E.reward_scale.offset, E.terrain_type.offset, E.noise_gravity.offset, M.feet_edge_pos.offset,
+                   C.sizeof(P), P.dst.offset, C.sizeof(Q), Q.Y1.offset, C.sizeof(R)]
 
 
 def test_abi_argument_errors_without_gpu():
