@@ -213,7 +213,6 @@ class Runner:
         # critic output layer + GAE in one launch (bg_critic_values_gae); 0 = bg_critic_head_forward, a fill and bg_gae
         self._fused_gae = os.environ.get("BG_FUSED_GAE", "1") == "1" and self.cfg["runner"]["horizon_length"] <= 32
         self._gae_scratch = torch.zeros(3 * ((self.env.num_envs + 15) // 16) + 1, dtype=torch.float64, device=self.device)
-        self._actor_after = os.environ.get("BG_ACTOR_AFTER", "0") == "1"
 
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
         # library GEMMs + bg_ppo_loss for these layers (A/B comparisons).
@@ -343,10 +342,6 @@ class Runner:
                     # with it the actor's loss wait for its values), the actor's fill the machine as they retire
                     hc, ha = MLPTrainer.forward_hidden_group([(self._critic_tr, critic_all, B), (self._actor_tr, obs_flat, None)])
                 side.wait_stream(main)
-                if self._actor_after and side is not main and not group_fwd:
-                    # the actor's forward may not start before the side stream has taken up this mini-epoch: the critic's slabs, which the GAE and with
-                    # it the actor's own loss wait for, then reach the CUs first instead of ~15 us behind the actor's
-                    main.wait_event(side.record_event())
                 with torch.cuda.stream(side):
                     if fused_head:
                         if not group_fwd:
