@@ -440,9 +440,15 @@ __global__ __launch_bounds__(256) void critic_values_gae_kernel(int T, int N, co
             }
     }
     const int lane = threadIdx.x & 31, hw = threadIdx.x >> 5, R = (T + 1) * VG_ENVS;
-    const float4 wv = *reinterpret_cast<const float4*>(w + lane * 4);
-    const float bias = b[0];
-    for (int r0 = hw * 4; r0 < R; r0 += 32) {
+    if (!h) {  // the values are an input (the chained forward kernel's value head wrote them)
+        for (int q = threadIdx.x; q < R; q += 256) {
+            const int t = q / VG_ENVS, e = q % VG_ENVS;
+            sv[q] = values_all[(size_t)t * N + e0 + (e < ne ? e : ne - 1)];
+        }
+    }
+    const float4 wv = h ? *reinterpret_cast<const float4*>(w + lane * 4) : float4{0.f, 0.f, 0.f, 0.f};
+    const float bias = h ? b[0] : 0.f;
+    for (int r0 = hw * 4; h && r0 < R; r0 += 32) {
         float4 x[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -526,9 +532,9 @@ extern "C" int bg_critic_head_forward(int32_t rows, const float* h, const float*
 extern "C" int bg_critic_values_gae(int32_t T, int32_t N, const float* h, const float* w, const float* b, float* rewards, const uint8_t* dones,
                                     const uint8_t* time_outs, float gamma, float lam, float* values_all, float* advantages, float* returns, double* sums,
                                     double* scratch, void* stream) {
-    if (T <= 0 || N <= 0 || !h || !w || !b || !rewards || !dones || !time_outs || !values_all || !advantages || !returns || !sums || !scratch)
+    if (T <= 0 || N <= 0 || (h && (!w || !b)) || !rewards || !dones || !time_outs || !values_all || !advantages || !returns || !sums || !scratch)
         return bg_set_error(-1, "bg_critic_values_gae: bad argument");
-    if (!aligned16(h) || !aligned16(w)) return bg_set_error(-1, "bg_critic_values_gae: h and w must be 16-byte aligned");
+    if (h && (!aligned16(h) || !aligned16(w))) return bg_set_error(-1, "bg_critic_values_gae: h and w must be 16-byte aligned");
     if (T > 32) return bg_set_error(-4, "bg_critic_values_gae: horizon above 32 (use bg_critic_head_forward + bg_gae)");
     const int grid = (N + VG_ENVS - 1) / VG_ENVS;
     hipLaunchKernelGGL(critic_values_gae_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, T, N, h, w, b, rewards, dones, time_outs, gamma, lam,

@@ -189,6 +189,21 @@ __device__ __forceinline__ void chain_slab(const bg_mlp_chain& a, int slab, floa
     layer(a1, [&](int s) { return x0[s]; }, std::integral_constant<int, K0>{}, std::integral_constant<int, N1>{}, std::integral_constant<int, 0>{}, 0, a.Y1);
     layer(a2, [&](int s) { return a1[s >> 4][s & 15]; }, std::integral_constant<int, N1>{}, std::integral_constant<int, N2>{}, std::integral_constant<int, C0>{}, N1, a.Y2);
     layer(a3, [&](int s) { return a2[s >> 4][s & 15]; }, std::integral_constant<int, N2>{}, std::integral_constant<int, N3>{}, std::integral_constant<int, C0 + C1>{}, N1 + N2, a.Y3);
+    if (a.v_out) {
+        // scalar output layer on the last activations, straight from the registers that hold them: the lane has 64 of its sample's 128 features
+        // (behind the last wait of the chunk stream: the store below is nobody's business)
+        float part = 0.f;
+#pragma unroll
+        for (int t = 0; t < N3 / 32; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.v_w + 32 * t + 8 * g + 4 * h);
+                part = fmaf(a3[t][4 * g + 0], w4.x, part); part = fmaf(a3[t][4 * g + 1], w4.y, part);
+                part = fmaf(a3[t][4 * g + 2], w4.z, part); part = fmaf(a3[t][4 * g + 3], w4.w, part);
+            }
+        part += __shfl_xor(part, 32);
+        if (h == 0 && row < a.M) a.v_out[row] = part + a.v_b[0];
+    }
 #ifdef BG_CHAIN_PROBE_STAMPS
     stamps[C + 1] = clock64();
     if (lane == 0 && blockIdx.x < 2048)
@@ -219,6 +234,8 @@ static int chain_check(const bg_mlp_chain& q) {
     if ((((uintptr_t)q.X | (uintptr_t)q.W1 | (uintptr_t)q.W2 | (uintptr_t)q.W3 | (uintptr_t)q.Y1 | (uintptr_t)q.Y2 | (uintptr_t)q.Y3 | (uintptr_t)q.b1 |
           (uintptr_t)q.b2 | (uintptr_t)q.b3) & 15) != 0)
         return bg_set_error(-1, "bg_mlp_chain_forward: pointers must be 16-byte aligned");
+    if ((q.v_w || q.v_b || q.v_out) && (!q.v_w || !q.v_b || !q.v_out || ((uintptr_t)q.v_w & 15) != 0))
+        return bg_set_error(-1, "bg_mlp_chain_forward: value head needs v_w (16-byte aligned), v_b and v_out");
     if (!(q.K0 == 64 && q.N1 == 256 && (q.N2 == 128 || q.N2 == 256) && q.N3 == 128))
         return bg_set_error(-4, "bg_mlp_chain_forward: unsupported widths (64-256-128-128 and 64-256-256-128)");
     return 0;
@@ -247,5 +264,6 @@ extern "C" int bg_mlp_chain_forward(int32_t M, int32_t K0, int32_t N1, int32_t N
     bg_mlp_chain q;
     q.M = M; q.K0 = K0; q.N1 = N1; q.N2 = N2; q.N3 = N3; q.pad = 0;
     q.X = X; q.W1 = W1; q.b1 = b1; q.W2 = W2; q.b2 = b2; q.W3 = W3; q.b3 = b3; q.Y1 = Y1; q.Y2 = Y2; q.Y3 = Y3;
+    q.v_w = nullptr; q.v_b = nullptr; q.v_out = nullptr;
     return bg_mlp_chain_forward_group(&q, 1, stream);
 }

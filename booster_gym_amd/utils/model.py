@@ -124,14 +124,25 @@ class MLPTrainer:
                 and tuple(l.weight.shape[0] for l in ls[:3]) in ((256, 128, 128), (256, 256, 128))
                 and ls[1].weight.shape[1] == ls[0].weight.shape[0] and ls[2].weight.shape[1] == ls[1].weight.shape[0])
 
+    def chainable_for(self, x, train_rows=None):
+        """Will forward_hidden(x, train_rows) run the chained kernel (and with it a `value_head`)?"""
+        B = x.shape[0] if train_rows is None else train_rows
+        if self._B != B or self._rows != x.shape[0] or self._kin != x.shape[1]:
+            self._alloc(x.shape[0], B, x.device, x.shape[1])
+        return self._chainable()
+
     def _chain_descriptor(self):
         """bg_mlp_chain of this network's hidden layers on the input of the forward pass in progress (self.x)."""
         ls = self.layers
         if not self.mirror_fresh:
             self.w0pad[:, : ls[0].weight.shape[1]].copy_(ls[0].weight)
         p = _lib.ptr
+        vw, vb, vo = self.value_head if self.value_head is not None else (None, None, None)
+        if vo is not None and (vo.numel() < self.x.shape[0] or vw.numel() != ls[2].weight.shape[0]):
+            raise ValueError("value_head: weight [width of the last hidden layer], bias [1], output [rows]")
         return _lib.MlpChain(self.x.shape[0], self._kin, ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0], 0, p(self.x), p(self.w0pad),
-                             p(ls[0].bias), p(ls[1].weight), p(ls[1].bias), p(ls[2].weight), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]), p(self.acts[2]))
+                             p(ls[0].bias), p(ls[1].weight), p(ls[1].bias), p(ls[2].weight), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]), p(self.acts[2]),
+                             p(vw), p(vb), p(vo))
 
     @staticmethod
     def forward_hidden_group(jobs):
@@ -155,6 +166,8 @@ class MLPTrainer:
         self.x = None
         self._B = self._rows = self._kin = None
         self.timed_layer, self.timed_events = None, []
+        # (weight [N3], bias [1], out [rows]): a scalar output layer evaluated by the chained forward kernel itself (the critic's values); None: not
+        self.value_head = None
 
     def _split(self, B):
         s = self.max_split

@@ -212,6 +212,7 @@ class Runner:
         self._group_forward = os.environ.get("BG_GROUP_FORWARD", "0") == "1"
         # critic output layer + GAE in one launch (bg_critic_values_gae); 0 = bg_critic_head_forward, a fill and bg_gae
         self._fused_gae = os.environ.get("BG_FUSED_GAE", "1") == "1" and self.cfg["runner"]["horizon_length"] <= 32
+        self._chain_values = os.environ.get("BG_CHAIN_VALUES", "1") == "1"  # ... with the values from the chained forward kernel's value head
         self._gae_scratch = torch.zeros(3 * ((self.env.num_envs + 15) // 16) + 1, dtype=torch.float64, device=self.device)
 
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
@@ -337,6 +338,10 @@ class Runner:
                 # parameters updated by the previous optimiser step; the loss accumulators (_stats, _grad_logstd) were zeroed by it (before the loop
                 # for the first mini-epoch): both heads add into them
                 group_fwd = fused_head and self._group_forward
+                # the chained forward kernel also evaluates the value head, from the registers that hold the last activations: the launch between the
+                # critic's forward and the actor's loss then has 400 KB to read instead of 52 MB
+                chain_values = fused_head and self._fused_gae and self._chain_values and self._critic_tr.chainable_for(critic_all, B)
+                self._critic_tr.value_head = (c_out.weight.reshape(-1), c_out.bias, self._values_all) if chain_values else None
                 if group_fwd:
                     # the hidden layers of BOTH networks in one launch (bg_mlp_chain_forward_group): the critic's slabs are dispatched first (the GAE and
                     # with it the actor's loss wait for its values), the actor's fill the machine as they retire
@@ -348,8 +353,8 @@ class Runner:
                             hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
                         if self._fused_gae:
                             # output layer + timeout bootstrap + GAE + returns + advantage moments in ONE launch in front of the actor's loss
-                            v_all = critic_values_gae(hc, c_out.weight, c_out.bias, buf["rewards"], buf["dones"], buf["time_outs"], alg["gamma"], alg["lam"],
-                                                      self._values_all, self._adv, self._ret, self._adv_sums, self._gae_scratch)
+                            v_all = critic_values_gae(None if chain_values else hc, c_out.weight, c_out.bias, buf["rewards"], buf["dones"], buf["time_outs"],
+                                                      alg["gamma"], alg["lam"], self._values_all, self._adv, self._ret, self._adv_sums, self._gae_scratch)
                         else:
                             v_all = critic_head_forward(hc, c_out.weight, c_out.bias, self._values_all)
                     else:

@@ -79,14 +79,15 @@ def gae(rewards, dones, time_outs, values, last_values, gamma, lam, advantages=N
 
 
 def critic_values_gae(h, w, b, rewards, dones, time_outs, gamma, lam, values_all, advantages, returns, sums, scratch):
-    """Output layer of the critic on all (T + 1) N rows of h, then `gae` on the result, in one launch (bg_critic_values_gae).  rewards [T, N] is
+    """Output layer of the critic on all (T + 1) N rows of h, then `gae` on the result, in one launch (bg_critic_values_gae); h = None: values_all is
+    given (the chained forward kernel's value head wrote it) and only the GAE half runs.  rewards [T, N] is
     modified in place as in `gae`; values_all [(T + 1) N], advantages / returns [T, N] and sums float64[3] are written; scratch: float64
     [3 * ceil(N / 16) + 1] whose last element the caller zeroed once."""
     T, N = rewards.shape
     d8 = dones.view(torch.uint8) if dones.dtype == torch.bool else dones
     t8 = time_outs.view(torch.uint8) if time_outs.dtype == torch.bool else time_outs
-    _need_cuda(h, w, b, rewards, d8, t8, values_all, advantages, returns, sums, scratch)
-    if h.shape[0] != (T + 1) * N or values_all.numel() != (T + 1) * N or scratch.numel() < 3 * ((N + 15) // 16) + 1:
+    _need_cuda(rewards, d8, t8, values_all, advantages, returns, sums, scratch, *([] if h is None else [h, w, b]))
+    if (h is not None and h.shape[0] != (T + 1) * N) or values_all.numel() != (T + 1) * N or scratch.numel() < 3 * ((N + 15) // 16) + 1:
         raise ValueError("critic_values_gae: h / values_all must have (T + 1) N rows, scratch 3 ceil(N / 16) + 1 float64")
     _lib.check(_lib.load().bg_critic_values_gae(T, N, _lib.ptr(h), _lib.ptr(w), _lib.ptr(b), _lib.ptr(rewards), _lib.ptr(d8), _lib.ptr(t8), gamma, lam,
                                                 _lib.ptr(values_all), _lib.ptr(advantages), _lib.ptr(returns), _lib.ptr(sums), _lib.ptr(scratch),

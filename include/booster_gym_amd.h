@@ -295,6 +295,10 @@ typedef struct bg_mlp_chain {
     int32_t M, K0, N1, N2, N3, pad;
     const float *X, *W1, *b1, *W2, *b2, *W3, *b3;
     float *Y1, *Y2, *Y3;
+    /* optional scalar output layer on Y3 (the critic's value head, utils/model.py:21): v_out[row] = v_w . Y3[row] + v_b[0], taken from the registers that
+     * hold Y3 (v_w [N3], v_b [1]; v_out [M]); all three NULL: none.  Another summation order than bg_critic_head_forward (same values to fp32 rounding). */
+    const float *v_w, *v_b;
+    float* v_out;
 } bg_mlp_chain;
 int bg_mlp_chain_forward(int32_t M, int32_t K0, int32_t N1, int32_t N2, int32_t N3, const float* X, const float* W1, const float* b1, const float* W2,
                          const float* b2, const float* W3, const float* b3, float* Y1, float* Y2, float* Y3, void* stream);
@@ -363,7 +367,8 @@ int bg_critic_head_forward(int32_t rows, const float* h, const float* w, const f
  * last values, timeout bootstrap, discount_values, returns): values_all [(T + 1) N] (the last N = last_values), advantages / returns [T][N], rewards
  * overwritten at time-outs as bg_gae does, sums float64 [3] WRITTEN (sum, sum of squares, count; fixed order: deterministic).  scratch: float64
  * [3 * ceil(N / 16) + 1], its last element zero-initialised once by the caller (the launch leaves it zero).  Values bit-identical to
- * bg_critic_head_forward, advantages to bg_gae.  -4: T > 32. */
+ * bg_critic_head_forward, advantages to bg_gae.  h == NULL: values_all is an INPUT (e.g. written by bg_mlp_chain_forward's value head) and only the
+ * GAE half runs (w, b unused).  -4: T > 32. */
 int bg_critic_values_gae(int32_t T, int32_t N, const float* h, const float* w, const float* b, float* rewards, const uint8_t* dones,
                          const uint8_t* time_outs, float gamma, float lam, float* values_all, float* advantages, float* returns, double* sums,
                          double* scratch, void* stream);

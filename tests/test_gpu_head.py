@@ -195,6 +195,13 @@ def test_critic_values_and_gae_in_one_launch_equal_the_separate_launches(T, N):
             s_first = s1.clone()
         else:
             assert torch.equal(s1, s_first)
+    # values given (the chained forward kernel's value head wrote them): only the GAE half runs, same results
+    r2 = rew.clone()
+    adv2, ret2 = torch.full((T, N), float("nan"), device=dev), torch.full((T, N), float("nan"), device=dev)
+    s2 = torch.full((3,), 7.0, dtype=torch.float64, device=dev)
+    vin = v0.clone()
+    critic_values_gae(None, w, b, r2, dones, touts, 0.995, 0.95, vin, adv2, ret2, s2, scratch)
+    assert torch.equal(vin, v0) and torch.equal(adv2, adv0) and torch.equal(ret2, ret0) and torch.equal(r2, r0) and torch.equal(s2, s_first)
     if T == 32:
         big = torch.zeros(33, N, device=dev)
         with pytest.raises(RuntimeError, match="horizon"):

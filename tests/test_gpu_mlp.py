@@ -192,8 +192,29 @@ def _chain_case(M, dims, seed):
     pad = (M + 127) // 128 * 128
     ys = [torch.full((pad, n), float("nan"), device=DEV) for n in (N1, N2, N3)]
     p = _lib.ptr
-    d = _lib.MlpChain(M, K0, N1, N2, N3, 0, p(x), p(Ws[0]), p(bs[0]), p(Ws[1]), p(bs[1]), p(Ws[2]), p(bs[2]), p(ys[0]), p(ys[1]), p(ys[2]))
+    d = _lib.MlpChain(M, K0, N1, N2, N3, 0, p(x), p(Ws[0]), p(bs[0]), p(Ws[1]), p(bs[1]), p(Ws[2]), p(bs[2]), p(ys[0]), p(ys[1]), p(ys[2]), None, None, None)
     return d, x, Ws, bs, ys
+
+
+def test_mlp_chain_forward_value_head():
+    """The optional scalar output layer of bg_mlp_chain_forward_group (the critic's values, taken from the registers that hold the last activations)
+    against fp64 on every row, ragged batch included; the activations themselves are unchanged by it; half a descriptor is refused."""
+    import ctypes
+    from booster_gym_amd import _lib
+
+    lib, st, p = _lib.load(), _lib.current_stream_ptr(), _lib.ptr
+    for M in (102400, 1000):
+        d, x, Ws, bs, ys = _chain_case(M, (64, 256, 256, 128), seed=11 + M)
+        g = torch.Generator(device="cpu").manual_seed(5)
+        vw, vb = (torch.randn(128, generator=g) * 0.1).to(DEV), torch.randn(1, generator=g).to(DEV)
+        vo = torch.full((M,), float("nan"), device=DEV)
+        d.v_w, d.v_b, d.v_out = p(vw), p(vb), p(vo)
+        _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, st))
+        _chain_check(M, x, Ws, bs, ys)
+        ref = ys[2][:M].double() @ vw.double() + vb.double()
+        assert torch.isfinite(vo).all() and (vo.double() - ref).abs().max().item() < 2e-5 * max(1.0, ref.abs().max().item())
+    d.v_b = None
+    assert lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, st) == -1 and b"value head" in lib.bg_last_error()
 
 
 def _chain_check(M, x, Ws, bs, ys):
