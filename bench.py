@@ -257,6 +257,7 @@ def main():
     # critic layer 1 (256 -> 256): the single largest kernel of the update; critic layer 2 (256 -> 128): the symbol with the largest TOTAL time
     # (mlp_fwd_kernel<256,1,1>, shared with the actor's layer 1)
     runner._critic_tr.timed_layer = (1, 2)
+    runner._actor_tr.timed_layer = (1, 2)  # (with the chained forward kernel: the two networks' launches overlap; their union is reported too)
     runner._wgrad_group.timed_events = []  # the grouped weight-gradient launch: the kernel with the largest total time of the iteration
     if world > 1:
         runner.dp.timed_events = []  # HIP events around the gradient-bucket all-reduce of every mini-epoch
@@ -333,6 +334,23 @@ def main():
                     solo()
                 g1.record(); torch.cuda.synchronize()
                 solo_us = g0.elapsed_time(g1) / 30 * 1e3
+            # the actor's chained launch runs beside the critic's on the other stream: flops of both over the span from the first start to the last end
+            eva = [e for e in runner._actor_tr.timed_events if e[5] == "chain"]
+            mini = cfg["runner"]["mini_epochs"]
+            both = None
+            if len(eva) == len(evc) // mini * (mini + 1):  # per iteration: the old-mu forward, then one launch per mini-epoch
+                spans = []
+                for i, (c0, c1, *_) in enumerate(evc):
+                    a0, a1 = eva[i // mini * (mini + 1) + 1 + i % mini][:2]
+                    first = a0 if a0.elapsed_time(c0) >= 0 else c0
+                    last = c1 if a1.elapsed_time(c1) >= 0 else a1
+                    spans.append(first.elapsed_time(last))
+                span_us = sum(spans) / len(spans) * 1e3
+                ra, ka, wa = eva[0][2], eva[0][3], eva[0][4]
+                fl_both = gemm_flop + 2.0 * ra * (ka * wa[0] + wa[0] * wa[1] + wa[1] * wa[2])
+                both = {"what": "the critic's and the actor's chained forward launches of a mini-epoch together (they overlap on two streams): flops of both / time from "
+                                "the first start to the last end", "avg_span_us": span_us, "algorithmic_flops": fl_both,
+                        "achieved": fl_both / (span_us * 1e-6) / 1e12, "frac": fl_both / (span_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}
         elif ev:
             gemm_us = sum(a.elapsed_time(b) for a, b, *_ in ev) / len(ev) * 1e3
             rows_g, kg, ng = ev[0][2], ev[0][3], ev[0][4]
@@ -379,6 +397,8 @@ def main():
                      "note": "timed inside the loop, where the actor's kernels run beside it on the second stream",
                      "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,
                                           "frac": gemm_flop / (solo_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}}
+        if evc and both is not None:
+            layer_fwd["both_networks_forward"] = both
         if args.no_extra:
             layer_fwd.pop("alone_on_the_gpu", None)
         wg_ev = runner._wgrad_group.timed_events or []
@@ -428,7 +448,7 @@ def main():
                 from booster_gym_amd.utils.model import MLPTrainer
 
                 runner.rollout, runner.update, runner.env.step_to = orig_rollout, orig_update, orig_step_to
-                runner._critic_tr.timed_layer, runner._wgrad_group.timed_events = None, None
+                runner._critic_tr.timed_layer, runner._actor_tr.timed_layer, runner._wgrad_group.timed_events = None, None, None
                 split, it0 = {}, args.warmup + args.steps
                 for terms in (9, 6):
                     MLPTrainer.SPLIT = terms
