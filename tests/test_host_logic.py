@@ -58,6 +58,17 @@ def test_abi_argument_errors_without_gpu():
     assert lib.bg_model_create(C.byref(d), C.byref(out)) < 0 and b"13-body" in lib.bg_last_error()
     assert lib.bg_gae(0, 4, None, None, None, None, None, 0.9, 0.9, None, None, None, None) < 0
     assert lib.bg_env_step(None, None, None) < 0
+    # round-3 entry points: descriptors are checked on the host before any launch
+    assert lib.bg_mlp_chain_forward_group(None, 1, None) < 0 and b"1 to 4" in lib.bg_last_error()
+    q = _lib.MlpChain(); q.M, q.K0, q.N1, q.N2, q.N3 = 128, 64, 256, 128, 128
+    assert lib.bg_mlp_chain_forward_group(C.addressof(q), 1, None) == -1 and b"bad argument" in lib.bg_last_error()
+    assert lib.bg_mlp_chain_forward_group(C.addressof(q), 5, None) < 0
+    assert lib.bg_critic_values_gae(0, 4, None, None, None, None, None, None, 0.9, 0.9, None, None, None, None, None, None) < 0
+    assert lib.bg_reduce_group(None, 1, None) < 0
+    m1 = _lib.ParamMirror(0, 4, 4, 0, 2, 0, None)  # ld < cols and no destination
+    one = (C.c_float * 16)()
+    assert lib.bg_optimizer_step(16, one, one, one, one, one, 1, 0.9, 0.999, 1e-8, 1.0, None, 0, 0, None, None, None, 0, 0, 1.0, 0.01, 1e-5, 1e-2, one,
+                                 C.addressof(m1), 1, None) < 0 and b"mirror" in lib.bg_last_error()
     if not torch.cuda.is_available():
         from booster_gym_amd.utils.urdf import FlatModel
 
