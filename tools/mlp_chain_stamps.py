@@ -1,5 +1,5 @@
 """Where a slab of the chained forward kernel spends its time: shader-clock stamps of every wave behind every chunk barrier (probe build of the library with
--DBG_CHAIN_PROBE_STAMPS: BG_LIB=tools/probe/libbg_chain_stamps.so python tools/mlp_chain_stamps.py).  Prints, per network, the median over all waves of the
+-DBG_CHAIN_PROBE_STAMPS, built by tools/build_chain_stamps.sh: BG_LIB=tools/probe/libbg_chain_stamps.so python tools/mlp_chain_stamps.py).  Prints, per network, the median over all waves of the
 cycles between consecutive stamps next to the MFMA cycles of that chunk (N / 32 tiles x 16 k-steps x 64 cycles), for the first and a later round of slabs."""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
