@@ -190,6 +190,103 @@ def test_loader_kat_collapsed_trunk(flat_model):
     assert m.dof_effort.tolist() == [45, 30, 30, 60, 24, 15] * 2
 
 
+def _mjcf_fixture():
+    return G("mjcf_model.npz")
+
+
+def _assert_model_matches_mjcf(mass, com, inertia6, body_pos, parent, joint_axis, lower, upper, names, dof_names, g):
+    """Every body, hinge and limit of a flat model against the numbers of the reference's MJCF (tests/golden/make_model_fixture.py)."""
+    assert list(names) == g["body_names"].tolist() and list(dof_names) == g["joint_names"].tolist()
+    assert list(parent) == g["parent"].tolist()
+    # the MJCF prints 6 significant digits (the collapsed trunk is a sum of 12 URDF links: 19.43035778 printed as 19.4304)
+    assert np.allclose(mass, g["mass"], rtol=5e-6, atol=0) and abs(np.sum(mass) - 31.6144) < 1e-4
+    assert np.allclose(com, g["inertial_pos"], rtol=5e-6, atol=5e-10)
+    # body 0 sits at z = 0.7 in the MJCF's world (the keyframe height); its flat-model origin is the free joint's: zero
+    assert np.allclose(np.asarray(body_pos)[1:], g["body_pos"][1:], rtol=0, atol=1e-9) and np.allclose(g["body_pos"][0], [0.0, 0.0, 0.7], atol=1e-7)
+    I = np.asarray(inertia6)
+    T = np.stack([np.array([[r[0], r[3], r[4]], [r[3], r[1], r[5]], [r[4], r[5], r[2]]]) for r in I])
+    # the MJCF prints quat and diaginertia with 6 significant digits: tensors agree to that (legs 4e-8, the 12-link trunk 3e-7)
+    assert np.abs(T[1:] - g["inertia_tensor"][1:]).max() < 1e-7 and np.abs(T[0] - g["inertia_tensor"][0]).max() < 1e-6
+    for b in range(13):
+        assert np.allclose(np.sort(np.linalg.eigvalsh(T[b])), np.sort(g["diaginertia"][b]), rtol=2e-5, atol=2e-9), b
+    ax = np.asarray(joint_axis)
+    assert ax[0] == 0 and g["joint_body"].tolist() == list(range(1, 13))
+    for j in range(12):
+        e = np.zeros(3); e[ax[j + 1] - 1] = 1.0
+        assert g["joint_axis"][j].tolist() == e.tolist(), j
+    assert np.allclose(lower, g["joint_range"][:, 0], atol=1e-9) and np.allclose(upper, g["joint_range"][:, 1], atol=1e-9)
+
+
+def test_flat_model_matches_every_body_of_the_reference_mjcf(flat_model):
+    """SURVEY 8(c) KAT 1 in full: the packaged flat model (what every kernel and the oracle run on) against resources/T1/T1_locomotion.xml:36-139 --
+    all 13 bodies (parent, frame offset, mass, centre of mass, full inertia tensor), the 12 hinges (axis, range), the actuator limits and the 7
+    collision primitives.  The MJCF is the model play_mujoco.py:717-756 steps: the only reference-held statement of the robot's inertial physics."""
+    m, g = flat_model, _mjcf_fixture()
+    _assert_model_matches_mjcf(m.mass, m.com, m.inertia, m.body_pos, m.parent, m.joint_axis, m.dof_lower, m.dof_upper, m.body_names, m.dof_names, g)
+    # torque limits: the training env clips to the URDF effort (t1.py:67,448), the MuJoCo player to ctrlrange (play_mujoco.py:751-755); they
+    # differ for Hip_Roll (30 / 45) and Knee (60 / 65) and agree elsewhere (SURVEY appendix A.1)
+    cr = g["ctrlrange"]
+    assert np.allclose(cr[:, 0], -cr[:, 1])
+    diff = {j: (m.dof_effort[j], cr[j, 1]) for j in range(12) if m.dof_effort[j] != cr[j, 1]}
+    assert diff == {1: (30.0, 45.0), 3: (60.0, 65.0), 7: (30.0, 45.0), 9: (60.0, 65.0)}
+    # collision primitives: MuJoCo half-sizes vs the URDF <collision> extents the flat model keeps; the ground plane is geom 0 of the world
+    assert g["geom_body"][0] == -1 and g["geom_type"][0] == 0
+    mj = sorted((int(b), int(t), tuple(np.round(s, 9)), tuple(np.round(p, 9))) for b, t, s, p in
+                zip(g["geom_body"][1:], g["geom_type"][1:], g["geom_halfsize"][1:], g["geom_pos"][1:]))
+    ours = []
+    for sh in m.shapes:
+        if sh["type"] == "box":
+            ours.append((int(sh["body"]), 1, tuple(np.round(0.5 * np.array(sh["size"]), 9)), tuple(np.round(sh["pos"], 9))))
+        else:
+            assert sh["type"] == "cylinder"
+            ours.append((int(sh["body"]), 2, (round(sh["size"][0], 9), round(0.5 * sh["size"][1], 9), 0.0), tuple(np.round(sh["pos"], 9))))
+    assert sorted(ours) == mj and len(mj) == 7
+    # the sole corners the contact model uses (asset.feet_edge_pos, T1.yaml:79-82) are the bottom corners of the foot boxes
+    from booster_gym_amd.utils.config import load_cfg
+
+    fe = np.array(load_cfg("T1", {})["asset"]["feet_edge_pos"])
+    for b in (6, 12):
+        k = [i for i in range(len(g["geom_body"])) if g["geom_body"][i] == b][0]
+        c, h = g["geom_pos"][k], g["geom_halfsize"][k]
+        corners = sorted((c[0] + sx * h[0], c[1] + sy * h[1], c[2] - h[2]) for sx in (-1, 1) for sy in (-1, 1))
+        assert np.allclose(sorted(map(tuple, fe)), corners, atol=1e-9)
+    # contact spheres and self-collision capsules are derived from exactly these primitives
+    caps = m.self_collision_capsules([6, 12])
+    assert [c[0][0] for c in caps] == [4, 10] and all(abs(c[0][3] - 0.05) < 1e-12 and abs(c[1][3] - 0.05) < 1e-12 for c in caps)
+
+
+def test_urdf_loaders_match_every_body_of_the_reference_mjcf():
+    """The same comparison for both URDF loaders (utils/urdf.py and bg_model_load_urdf through the C ABI) on the reference's URDF: fixed-joint
+    collapsing of the 24-link URDF must land on the MJCF's 13 bodies.  Needs the reference tree (this container; skipped on the GPU box)."""
+    path = "/root/reference/resources/T1/T1_locomotion.urdf"
+    if not os.path.isfile(path):
+        pytest.skip("reference asset not on this machine (GPU box)")
+    import ctypes as C
+
+    from booster_gym_amd import _lib
+    from booster_gym_amd.utils.urdf import load_urdf
+
+    g = _mjcf_fixture()
+    m = load_urdf(path)
+    _assert_model_matches_mjcf(m.mass, m.com, m.inertia, m.body_pos, m.parent, m.joint_axis, m.dof_lower, m.dof_upper, m.body_names, m.dof_names, g)
+    lib = _lib.load()
+    opt = _lib.AssetOptions()
+    opt.collapse_fixed_joints, opt.body_contacts, opt.self_collisions = 1, 1, 1
+    opt.foot_names[0], opt.foot_names[1] = b"left_foot_link", b"right_foot_link"
+    h = C.c_void_p()
+    assert lib.bg_model_load_urdf(path.encode(), C.byref(opt), C.byref(h)) == 0, lib.bg_last_error()
+    d = _lib.ModelDesc()
+    _lib.check(lib.bg_model_get(h, C.byref(d)))
+    f = lambda a: np.array([list(r) if hasattr(r, "__len__") else r for r in a], dtype=np.float64)
+    names = [lib.bg_model_body_name(h, i).decode() for i in range(d.num_bodies)]
+    dofs = [lib.bg_model_dof_name(h, j).decode() for j in range(d.num_dofs)]
+    # the native model holds fp32: one rounding of the MJCF's digits
+    g32 = {k: (g[k].astype(np.float32).astype(np.float64) if g[k].dtype == np.float64 else g[k]) for k in g.files}
+    _assert_model_matches_mjcf(f(d.mass)[:13], f(d.com)[:13], f(d.inertia)[:13], f(d.body_pos)[:13], list(d.parent)[:13], list(d.joint_axis)[:13],
+                               f(d.dof_lower)[:12], f(d.dof_upper)[:12], names, dofs, g32)
+    lib.bg_model_destroy(h)
+
+
 def test_urdf_loader_on_reference_asset_if_present(flat_model):
     from booster_gym_amd.utils.urdf import load_urdf
 
