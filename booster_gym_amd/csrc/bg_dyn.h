@@ -105,6 +105,8 @@ typedef __attribute__((address_space(3))) float lds_f32;  // explicit LDS pointe
 #else
 typedef float lds_f32;
 #endif
+// LDS scratch of the item-parallel leg-against-leg narrow phase (SELF_LDS, self_narrow_phase_lds): poses, segments and pair results of up to 7 envs per pass
+constexpr int SELF_PASS_ENVS = 7, SELF_LDS_FLOATS = (36 * 2 + 13 * 4 + 9 * 4) * SELF_PASS_ENVS;
 struct RegStore {
     // the z-axis specialisation of the sweeps (Phys::zmask) is off here: this store serves the fused env step, one wave per SIMD and latency-bound,
     // where the extra (wave-uniform) branches split the blocks the scheduler overlaps work in: 107.7 -> 109.3 us per env step with it on (measured)
@@ -119,31 +121,47 @@ struct RegStore {
     template <int I, class LP> BG_HD V3 link_pos(const LP& lp) const { return lp.lk[I].pos; }
     template <int I, class LP> BG_HD LinkConst link(const LP& lp) const { return lp.lk[I]; }
 };
-// v / cb / U in registers, the per-env link constants (13 floats per link, computed once per launch) in LDS
+// v / cb / U in registers, the per-env link constants (10 floats per link: mass, m c, inertia about the origin; computed once per launch) in LDS.
+// The link ORIGINS are not per-env (nominal model constants, one set per leg): they sit in a 2 x 6 x 4-float table of the workgroup that every
+// lane of a leg reads at the same address (a broadcast read) -- 18 fewer lane-wide slots, which is what pays for the leg-against-leg scratch
+// below within the 20 KB a workgroup may use when eight of them share a CU.
 struct LdsLinkStore : RegStore {
     static constexpr bool ZSPEC = true;  // the ABA kernel: throughput-bound (two waves per SIMD), fewer issued instructions pay directly
-    static constexpr int SLOTS = 13 * LEG_LINKS, STRIDE = 64;
-    lds_f32* p;
+    static constexpr int PER_LINK = 10, SLOTS = PER_LINK * LEG_LINKS, STRIDE = 64;
+    static constexpr int POS_FLOATS = 2 * LEG_LINKS * 4;  // [leg][link][x y z pad]
+    static constexpr int FLOATS = SLOTS * STRIDE + POS_FLOATS + SELF_LDS_FLOATS;
+    static_assert(FLOATS * 4 <= 20480, "eight workgroups of the ABA kernel share a CU's 160 KB of LDS");
+    lds_f32* p;     // + lane: this lane's slots, STRIDE apart
+    lds_f32* ppos;  // this leg's row of the origin table
+    BG_HD void bind(lds_f32* base, int lane) { p = base + lane; ppos = base + SLOTS * STRIDE + (lane & 1) * (LEG_LINKS * 4); }
+    static BG_HD lds_f32* self_scratch(lds_f32* base) { return base + SLOTS * STRIDE + POS_FLOATS; }
+    // the origin table: written once per workgroup, by ALL its lanes together, before any lane code runs (the lane code may be called from
+    // divergent branches, where the lanes that would write it need not be the first to read it)
+    template <class MD> static BG_HD void write_origins(lds_f32* base, const MD& m, int lane) {
+        if (lane < 2 * LEG_LINKS * 3) {
+            const int leg = lane / (3 * LEG_LINKS), i = (lane % (3 * LEG_LINKS)) / 3, a = lane % 3;
+            base[SLOTS * STRIDE + leg * (LEG_LINKS * 4) + 4 * i + a] = m.pos[1 + leg * LEG_LINKS + i][a];
+        }
+    }
     template <class LP> BG_HD void stash(const LP& lp) const {
         for (int i = 0; i < LEG_LINKS; i++) {
             const LinkConst& k = lp.lk[i];
-            const float f[13] = {k.pos.e[0], k.pos.e[1], k.pos.e[2], k.m, k.mc.e[0], k.mc.e[1], k.mc.e[2],
-                                 k.Io.e[0], k.Io.e[1], k.Io.e[2], k.Io.e[3], k.Io.e[4], k.Io.e[5]};
-            for (int j = 0; j < 13; j++) p[(13 * i + j) * STRIDE] = f[j];
+            const float f[PER_LINK] = {k.m, k.mc.e[0], k.mc.e[1], k.mc.e[2], k.Io.e[0], k.Io.e[1], k.Io.e[2], k.Io.e[3], k.Io.e[4], k.Io.e[5]};
+            for (int j = 0; j < PER_LINK; j++) p[(PER_LINK * i + j) * STRIDE] = f[j];
         }
     }
     // volatile reads: a plain load is forwarded from the stash stores above and the constants stay in registers after all
     template <int I, class LP> BG_HD V3 link_pos(const LP&) const {
-        const volatile lds_f32* q = p;
-        return v3(q[(13 * I) * STRIDE], q[(13 * I + 1) * STRIDE], q[(13 * I + 2) * STRIDE]);
+        const volatile lds_f32* q = ppos;
+        return v3(q[4 * I], q[4 * I + 1], q[4 * I + 2]);
     }
-    template <int I, class LP> BG_HD LinkConst link(const LP&) const {
+    template <int I, class LP> BG_HD LinkConst link(const LP& lp) const {
         const volatile lds_f32* q = p;
         LinkConst k;
-        k.pos = v3(q[(13 * I) * STRIDE], q[(13 * I + 1) * STRIDE], q[(13 * I + 2) * STRIDE]);
-        k.m = q[(13 * I + 3) * STRIDE];
-        k.mc = v3(q[(13 * I + 4) * STRIDE], q[(13 * I + 5) * STRIDE], q[(13 * I + 6) * STRIDE]);
-        for (int j = 0; j < 6; j++) k.Io.e[j] = q[(13 * I + 7 + j) * STRIDE];
+        k.pos = link_pos<I>(lp);
+        k.m = q[(PER_LINK * I) * STRIDE];
+        k.mc = v3(q[(PER_LINK * I + 1) * STRIDE], q[(PER_LINK * I + 2) * STRIDE], q[(PER_LINK * I + 3) * STRIDE]);
+        for (int j = 0; j < 6; j++) k.Io.e[j] = q[(PER_LINK * I + 4 + j) * STRIDE];
         return k;
     }
 };
@@ -162,6 +180,8 @@ struct LegWorkT {  // what the inward sweep leaves behind for the outward sweep
     V3 self_shank, self_foot;
     float self_gap;
     bool self_deferred;
+    lds_f32* self_sc;  // SELF_LDS: the workgroup's scratch (SELF_LDS_FLOATS) and this lane's index, set by the kernel
+    int self_lane;
     SI Bc;             // contact impedance on the foot
     SV f0c;            // contact wrench at the current state (foot coords)
     bool contact;
@@ -455,10 +475,148 @@ BG_HD void self_narrow_phase(const Phys& ph, const SelfCaps& c, const M3& Rsh, V
 // clearance test alone costs the fused env step 1.7 %, the branch around the narrow phase another 7.5 % although it is hardly ever taken
 // (register allocation around a large block in the middle of the sweeps), and it makes the two-waves-per-SIMD ABA kernel spill:
 //   SELF_INLINE  clearance test and narrow phase between the outward and the inward sweep (fused env step, granular simulate, second kernels)
-//   SELF_DEFER   clearance test only; an env whose legs can meet is marked (w.self_deferred) and left to the launch's second kernel (ABA kernel)
+//   SELF_DEFER   clearance test only; an env whose legs can meet is marked (w.self_deferred) and left to the launch's second kernel (ABA kernel
+//                with the trunk-low gate, where a second kernel exists anyway)
 // (Also measured for the fused env step: looking for the contacts at the TOP of the substep loop instead, from a kinematics-only walk, only when
 // the clearance of the substep before was small: 111.8 us per env step against 107.8 for SELF_INLINE and 98.5 without the contacts.  Not kept.)
-enum { SELF_INLINE = 0, SELF_DEFER = 1 };
+//   SELF_LDS     clearance test per lane; the narrow phase ITEM-parallel through LDS (below): what a wave spends on it follows the number of its
+//                envs whose legs can meet, not the number of its lanes (ABA kernel)
+enum { SELF_INLINE = 0, SELF_DEFER = 1, SELF_LDS = 2 };
+
+#if defined(__HIP_DEVICE_COMPILE__)
+// bit 2k of a wave mask -> bit k (the two lanes of an env vote alike).  Wave-uniform: scalar ALU.
+__device__ __forceinline__ unsigned even_bits(unsigned long long m) {
+    m &= 0x5555555555555555ull;
+    m = (m | (m >> 1)) & 0x3333333333333333ull;
+    m = (m | (m >> 2)) & 0x0F0F0F0F0F0F0F0Full;
+    m = (m | (m >> 4)) & 0x00FF00FF00FF00FFull;
+    m = (m | (m >> 8)) & 0x0000FFFF0000FFFFull;
+    m = (m | (m >> 16)) & 0x00000000FFFFFFFFull;
+    return (unsigned)m;
+}
+// The narrow phase of a whole wave (one 64-lane workgroup = 32 envs), item-parallel.  In the lane-per-leg form every lane of a wave walks through
+// the four pair evaluations as soon as ONE of its 32 envs has its legs close (with 9 % of the envs close that is 93 % of the waves), which is why the
+// ABA kernel used to leave such envs to a second kernel that gathered their scattered state again (3.2 x their bytes in fabric traffic).  Here the
+// wave compacts instead, in five steps that hand over through LDS, up to PE = 7 close envs per pass (rank among the close envs from the vote mask):
+//   P0  the lanes of the close envs put the poses and velocities of their shank and foot into LDS (no arithmetic);
+//   P1  lane 4 s + 2 leg + k builds ONE capsule segment (env slot s, link k of that leg);
+//   P2  lane 4 s + 2 k0 + k1 evaluates ONE pair (link k0 of the left leg against link k1 of the right leg): one evaluation serves both legs --
+//       the force on the right leg's link is minus the one on the left's, at the same point, so momentum is conserved to the bit -- and gives the
+//       torques about both links' origins;
+//   P3  lane 4 s + 2 leg + k adds the two pairs its link takes part in and rotates force and torque into link coordinates;
+//   P4  the owning lanes read their two wrenches (and world-frame forces) back.
+// What a wave spends follows the number of its close envs (one instruction stream of ~45 + 145 + 35 VALU per pass) and not its 64 lanes' (the
+// lane-per-leg narrow phase is ~500).  One wave per workgroup: the LDS operations of a wave execute in order, so the hand-overs need no barrier,
+// only compiler fences.
+struct SelfLds {
+    static constexpr int PE = SELF_PASS_ENVS, NL = 2 * PE, NS = 4 * PE;
+    static constexpr int RAW = 0, SEG = 36 * NL, RES = SEG + 13 * NS, END = RES + 9 * NS;  // the P3 results reuse the segments' space
+    static_assert(END <= SELF_LDS_FLOATS, "leg-against-leg scratch");
+};
+__device__ __forceinline__ void self_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+template <class W>
+__device__ __forceinline__ void self_narrow_phase_lds(const Phys& ph, const ModelDev& M, int leg, bool need, W& w, V3 pfoot_rel, SV vfoot) {
+    constexpr int PE = SelfLds::PE, NL = SelfLds::NL, NS = SelfLds::NS;
+    const unsigned long long vote = __ballot(need);
+    if (vote == 0ull) return;  // wave-uniform
+    const unsigned envs = even_bits(vote | (vote >> 1));
+    const int cnt = __popc(envs);
+    const int lane = w.self_lane;
+    const int rank = __popc(envs & ((1u << (lane >> 1)) - 1u));
+    lds_f32* raw = w.self_sc + SelfLds::RAW;
+    lds_f32* seg = w.self_sc + SelfLds::SEG;
+    lds_f32* res = w.self_sc + SelfLds::RES;
+    const int gs = lane >> 2, gl = (lane >> 1) & 1, gk = lane & 1;  // this lane as worker of P1 / P3 (slot, leg, link) and of P2 (slot, k0, k1)
+    for (int base = 0; base < cnt; base += PE) {  // wave-uniform trip count (one pass unless more than PE envs of the wave are close)
+        const int slot = rank - base;
+        const bool mine = need && slot >= 0 && slot < PE;
+        const bool worker = lane < NS && base + gs < cnt;
+        BG_PHASE("self_p0_poses");
+        if (mine) {
+            const int j = 2 * slot + leg;
+            const SV vsh = w.st.template get_v<SELF_SHANK>();
+            for (int r = 0; r < 3; r++) for (int cidx = 0; cidx < 3; cidx++) { raw[(3 * r + cidx) * NL + j] = w.Rsh.e[r][cidx]; raw[(18 + 3 * r + cidx) * NL + j] = w.Rfoot.e[r][cidx]; }
+            for (int a = 0; a < 3; a++) {
+                raw[(9 + a) * NL + j] = w.psh.e[a]; raw[(27 + a) * NL + j] = pfoot_rel.e[a];
+                raw[(12 + a) * NL + j] = vsh.a.e[a]; raw[(15 + a) * NL + j] = vsh.l.e[a];
+                raw[(30 + a) * NL + j] = vfoot.a.e[a]; raw[(33 + a) * NL + j] = vfoot.l.e[a];
+            }
+        }
+        self_lds_fence();
+        BG_PHASE("self_p1_segments");
+        if (worker) {
+            const volatile lds_f32* vr = raw + 18 * gk * NL + 2 * gs + gl;
+            M3 R; V3 p; SV v;
+            for (int r = 0; r < 3; r++) for (int cidx = 0; cidx < 3; cidx++) R.e[r][cidx] = vr[(3 * r + cidx) * NL];
+            for (int a = 0; a < 3; a++) { p.e[a] = vr[(9 + a) * NL]; v.a.e[a] = vr[(12 + a) * NL]; v.l.e[a] = vr[(15 + a) * NL]; }
+            const V3 c = v3(M.cap_c[gl][gk][0], M.cap_c[gl][gk][1], M.cap_c[gl][gk][2]);
+            const float h = M.cap_h[gl][gk], rad = M.cap_r[gl][gk];
+            // the shank's capsule lies along its z axis, the foot's along its x axis
+            const V3 ax = gk ? v3(R.e[0][0], R.e[1][0], R.e[2][0]) : v3(R.e[0][2], R.e[1][2], R.e[2][2]);
+            const V3 mid = p + mul(R, c);
+            const V3 A = mid - h * ax, B = mid + h * ax;
+            V3 a_loc = c;
+            if (gk) a_loc.e[0] -= h; else a_loc.e[2] -= h;
+            const V3 wv = mul(R, v.a), vA = mul(R, v.l + cross(v.a, a_loc));
+            for (int a = 0; a < 3; a++) { seg[a * NS + lane] = A.e[a]; seg[(3 + a) * NS + lane] = B.e[a]; seg[(6 + a) * NS + lane] = wv.e[a]; seg[(9 + a) * NS + lane] = vA.e[a]; }
+            seg[12 * NS + lane] = rad;
+        }
+        self_lds_fence();
+        BG_PHASE("self_p2_pairs");
+        if (worker) {
+            const int k0 = gl, k1 = gk;  // (the same bit positions, read as left-leg link / right-leg link)
+            SelfSeg o, q;
+            const volatile lds_f32* so = seg + 4 * gs + k0;
+            const volatile lds_f32* sq = seg + 4 * gs + 2 + k1;
+            for (int a = 0; a < 3; a++) {
+                o.A.e[a] = so[a * NS]; o.B.e[a] = so[(3 + a) * NS]; o.w.e[a] = so[(6 + a) * NS]; o.vA.e[a] = so[(9 + a) * NS];
+                q.A.e[a] = sq[a * NS]; q.B.e[a] = sq[(3 + a) * NS]; q.w.e[a] = sq[(6 + a) * NS]; q.vA.e[a] = sq[(9 + a) * NS];
+            }
+            o.r = so[12 * NS]; q.r = sq[12 * NS];
+            const volatile lds_f32* po = raw + (18 * k0 + 9) * NL + 2 * gs;
+            const volatile lds_f32* pq = raw + (18 * k1 + 9) * NL + 2 * gs + 1;
+            const V3 org_o = v3(po[0], po[NL], po[2 * NL]), org_q = v3(pq[0], pq[NL], pq[2 * NL]);
+            V3 F = v3(0.f, 0.f, 0.f), xc = v3(0.f, 0.f, 0.f);
+            if (!self_pair(ph, o, q, &F, &xc)) { F = v3(0.f, 0.f, 0.f); xc = org_o; }
+            const V3 To = cross(xc - org_o, F), Tq = cross(org_q - xc, F);  // torque of +F about the left link's origin, of -F about the right link's
+            for (int a = 0; a < 3; a++) { res[a * NS + lane] = F.e[a]; res[(3 + a) * NS + lane] = To.e[a]; res[(6 + a) * NS + lane] = Tq.e[a]; }
+        }
+        self_lds_fence();
+        BG_PHASE("self_p3_wrenches");
+        if (worker) {
+            // link gk of leg gl: the left leg's link k takes part in pairs (k, 0) and (k, 1), the right leg's in (0, k) and (1, k)
+            const int i0 = 4 * gs + (gl == 0 ? 2 * gk : gk), i1 = i0 + (gl == 0 ? 1 : 2);
+            const volatile lds_f32* r0 = res + i0;
+            const volatile lds_f32* r1 = res + i1;
+            const int to = gl == 0 ? 3 : 6;
+            const float sgn = gl == 0 ? 1.0f : -1.0f;
+            const V3 Fs = sgn * (v3(r0[0], r0[NS], r0[2 * NS]) + v3(r1[0], r1[NS], r1[2 * NS]));
+            const V3 Ts = v3(r0[to * NS], r0[(to + 1) * NS], r0[(to + 2) * NS]) + v3(r1[to * NS], r1[(to + 1) * NS], r1[(to + 2) * NS]);
+            const volatile lds_f32* vr = raw + 18 * gk * NL + 2 * gs + gl;
+            M3 R;
+            for (int r = 0; r < 3; r++) for (int cidx = 0; cidx < 3; cidx++) R.e[r][cidx] = vr[(3 * r + cidx) * NL];
+            const V3 fl = mulT(R, Fs), fa = mulT(R, Ts);
+            for (int a = 0; a < 3; a++) { seg[a * NS + lane] = fl.e[a]; seg[(3 + a) * NS + lane] = fa.e[a]; seg[(6 + a) * NS + lane] = Fs.e[a]; }
+        }
+        self_lds_fence();
+        BG_PHASE("self_p4_read_back");
+        if (mine) {
+            const volatile lds_f32* f0 = seg + 4 * slot + 2 * leg;
+            for (int k = 0; k < 2; k++) {
+                w.self_fx[k].l = v3(f0[k], f0[NS + k], f0[2 * NS + k]);
+                w.self_fx[k].a = v3(f0[3 * NS + k], f0[4 * NS + k], f0[5 * NS + k]);
+                const V3 Fs = v3(f0[6 * NS + k], f0[7 * NS + k], f0[8 * NS + k]);
+                if (k == 0) w.self_shank = Fs; else w.self_foot = Fs;
+            }
+        }
+        self_lds_fence();  // the next pass overwrites the scratch
+    }
+    BG_PHASE("self_done");
+}
+#endif
 
 template <int MODE, class W, class X>
 BG_HD void self_contacts(const Phys& ph, const ModelDev& M, int leg, W& w, const M3& R0, V3 pfoot_rel, SV vfoot, X& x) {
@@ -471,6 +629,10 @@ BG_HD void self_contacts(const Phys& ph, const ModelDev& M, int leg, W& w, const
     w.self_gap = self_clearance(c, leg, w.Rsh, w.psh, w.Rfoot, pfoot_rel, R0, x);
     if constexpr (MODE == SELF_DEFER) {
         w.self_deferred = w.self_gap < 0.f;
+    } else if constexpr (MODE == SELF_LDS) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        self_narrow_phase_lds(ph, M, leg, w.self_gap < 0.f, w, pfoot_rel, vfoot);
+#endif
     } else if constexpr (MODE == SELF_INLINE) {
 #ifndef BG_SELF_NORARE   // (timing experiment: the per-substep part only)
         if (w.self_gap < 0.f)

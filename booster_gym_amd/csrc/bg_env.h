@@ -183,6 +183,7 @@ BG_HD float quat_yaw(const float q[4]) {
 
 // Sink: where obs / privileged obs values go.  put(row_local, k, v).
 struct GlobalSink {
+    static constexpr int SELF = SELF_INLINE;  // how the sink's kernel runs the leg-against-leg narrow phase (bg_dyn.h)
     float* obs; float* priv; int e;
     BG_HD void put_obs(int k, float v) { obs[(size_t)e * BG_NUM_OBS + k] = v; }
     BG_HD void put_priv(int k, float v) { priv[(size_t)e * BG_NUM_PRIV + k] = v; }
@@ -279,7 +280,7 @@ BG_HD void env_step_lane(const EnvDev& E, X& x, Sink& sink, int e, int leg, bool
                 tmean[i] += tau[i];
             }
             BodyContactOut bo;
-            BaseContribution mine = substep_pre<BODY>(ph, E.terrain, M, leg, lp, ls, tau, bs, cx, x, (const SV*)nullptr, &bo);
+            BaseContribution mine = substep_pre<BODY, Sink::SELF>(ph, E.terrain, M, leg, lp, ls, tau, bs, cx, x, (const SV*)nullptr, &bo);
             // contact forces of the LAST substep are the ones the task logic sees (contact_collection: last substep, T1.yaml:56): how many
             // penalised / terminating non-foot bodies of this leg carry more than 1 N (t1.py:553,629); the trunk is counted once (leg 0)
             body_pen = 0.f; body_term = 0.f;

@@ -64,12 +64,17 @@ struct DppSwap {
     }
 };
 
+#ifndef BG_ENV_SELF_MODE
+#define BG_ENV_SELF_MODE SELF_INLINE
+#endif
 struct LdsSink {
+    static constexpr int SELF = BG_ENV_SELF_MODE;
     float* obs; float* priv; int el;
+    lds_f32* self_sc; int lane;
     // sweep work space of the fused step: everything in registers.  (Staging the link constants in LDS as forward_dynamics_kernel does
     // removes all spills here too, but the 10 substeps re-read them and the step got 3-5 % slower at every N: measured, not adopted.)
     using Ctx = SubstepCtx;
-    __device__ __forceinline__ void bind(Ctx&, const LegParams&) const {}
+    __device__ __forceinline__ void bind(Ctx& cx, const LegParams&) const { cx.w.self_sc = self_sc; cx.w.self_lane = lane; }
     __device__ __forceinline__ void put_obs(int k, float v) { obs[el * BG_NUM_OBS + k] = v; }
     __device__ __forceinline__ void put_priv(int k, float v) { priv[el * BG_NUM_PRIV + k] = v; }
 };
@@ -97,6 +102,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __r
                                                       unsigned* __restrict__ lowmask) {
     __shared__ float s_obs[ENVS_PER_BLOCK * BG_NUM_OBS];
     __shared__ float s_priv[ENVS_PER_BLOCK * BG_NUM_PRIV];
+    __shared__ float s_self[SELF_LDS_FLOATS];
     __shared__ unsigned s_low;
     const int lane = threadIdx.x;
     const int e0 = blockIdx.x * ENVS_PER_BLOCK;
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(64) void env_step_kernel(EnvDev E, const float* __r
     if (lane == 0) s_low = 0u;
     __syncthreads();
     DppSwap x;
-    LdsSink sink{s_obs, s_priv, lane >> 1};
+    LdsSink sink{s_obs, s_priv, lane >> 1, (lds_f32*)s_self, lane};
     // decided once per env step from the trunk height at its start; both lanes of an env agree
     const V3 p0 = v3(E.f[(size_t)(F_ROOT + 0) * E.n + e], E.f[(size_t)(F_ROOT + 1) * E.n + e], E.f[(size_t)(F_ROOT + 2) * E.n + e]);
     const bool low = GATED && mode == 0 && body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, p0);
@@ -133,6 +139,7 @@ __global__ __launch_bounds__(64) void env_step_body_kernel(EnvDev E, const float
                                                            const unsigned* __restrict__ lowmask, int nblocks) {
     __shared__ float s_obs[ENVS_PER_BLOCK * BG_NUM_OBS];
     __shared__ float s_priv[ENVS_PER_BLOCK * BG_NUM_PRIV];
+    __shared__ float s_self[SELF_LDS_FLOATS];
     const int lane = threadIdx.x;
     for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
         const unsigned lowm = lowmask[b];
@@ -142,7 +149,7 @@ __global__ __launch_bounds__(64) void env_step_body_kernel(EnvDev E, const float
         const bool valid = e < E.n;
         if (!valid) e = E.n - 1;
         DppSwap x;
-        LdsSink sink{s_obs, s_priv, lane >> 1};
+        LdsSink sink{s_obs, s_priv, lane >> 1, (lds_f32*)s_self, lane};
         if ((lowm >> (lane >> 1)) & 1u) env_step_lane<DppSwap, LdsSink, H16, true>(E, x, sink, e, lane & 1, valid, act, step, 0, out);
         __syncthreads();
         copy_out_rows(out, e0, min(ENVS_PER_BLOCK, E.n - e0), lowm, s_obs, s_priv);
@@ -239,10 +246,10 @@ __global__ __launch_bounds__(RS_BLOCK) void resample_apply_kernel(EnvDev E, cons
 // and dependency latency).  Keeping the per-env link constants (13 floats x 6 links per lane, computed once per launch) in LDS brings it to
 // 248 registers with no spill, two waves share a SIMD and cover each other's stalls: 88 % VALU-busy, +14 % throughput at 1M envs.
 template <bool BODY, int SELF>
-__device__ __forceinline__ bool forward_dynamics_lane(const EnvDev& E, int e, bool valid, float* s_work, const float* __restrict__ root,
+__device__ __forceinline__ bool forward_dynamics_lane(const EnvDev& E, int lane, int e, bool valid, float* s_work, const float* __restrict__ root,
                                                       const float* __restrict__ q, const float* __restrict__ qd, const float* __restrict__ tau,
                                                       const float* __restrict__ wrench, float* __restrict__ qacc) {
-    const int lane = threadIdx.x, leg = lane & 1;
+    const int leg = lane & 1;
     const int n = E.n;
     BG_PHASE("load_state_and_link_constants");
     Phys ph = make_phys(E.cfg);
@@ -265,8 +272,9 @@ __device__ __forceinline__ bool forward_dynamics_lane(const EnvDev& E, int e, bo
     if (wrench) { const float* w = wrench + (size_t)e * 6; wr.l = v3(w[0], w[1], w[2]); wr.a = v3(w[3], w[4], w[5]); }
     DppSwap x;
     SubstepCtxLdsLink cx;
-    cx.w.st.p = (lds_f32*)(s_work + lane);
+    cx.w.st.bind((lds_f32*)s_work, lane);
     cx.w.st.stash(lp);
+    cx.w.self_sc = LdsLinkStore::self_scratch((lds_f32*)s_work); cx.w.self_lane = lane;
     BaseContribution mine = substep_pre<BODY, SELF>(ph, E.terrain, *E.model, leg, lp, ls, t6, bs, cx, x), both;
     if constexpr (SELF == SELF_DEFER) { if (cx.w.self_deferred) return true; }  // the legs can meet: the second kernel's env (both lanes agree)
     bg_pin(mine.I); bg_pin(mine.p);
@@ -286,19 +294,22 @@ __device__ __forceinline__ bool forward_dynamics_lane(const EnvDev& E, int e, bo
     for (int a = 0; a < 3; a++) E.f[(size_t)(F_CONTACT + 3 * leg + a) * n + e] = fw.e[a];
     return false;
 }
-// Kernel A of the ABA launch.  An env is LEFT to kernel B when its legs can meet (lateral clearance test inside the sweeps, SELF_DEFER: the
-// leg-against-leg narrow phase never enters this kernel) or, GATED only, when its trunk is low (non-foot body contacts).  Kernel A records
-// such envs in a 32-bit mask per block; aba_compact_kernel turns the masks into a compact env list, so that kernel B's cost follows the
-// NUMBER of such envs and not the number of 32-env blocks that contain one (joint angles drawn around the standing pose with sigma = 0.1 rad
-// cross the legs of 8 % of the envs: 93 % of the blocks).  (One atomic per wave straight into the list was tried first: 30 k returning
-// atomics on one address doubled this kernel's time.)  left_mask may be null when nothing can be left (no self-collision geometry, GATED = false).
+// The ABA kernel.  Leg-against-leg contacts: the clearance test per lane, the narrow phase item-parallel through LDS inside this kernel
+// (SELF_LDS, bg_dyn.h:self_narrow_phase_lds) -- one launch, no second pass over the envs whose legs are close.  (Rounds 2-3 left those envs to a
+// second kernel that re-read their scattered state: 79 us and 3.2 x their bytes for 9 % of the envs.)
+// GATED (only when the non-foot body contacts can occur, i.e. contact.body_gate_height > rewards.terminate_height): an env whose trunk is low is
+// LEFT to kernel B, which carries the body-contact code; there kernel A also leaves the envs whose legs can meet (SELF_DEFER), records both in a
+// 32-bit mask per block, aba_compact_kernel turns the masks into a compact env list and kernel B walks it.  left_mask is null otherwise.
 template <bool GATED>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void forward_dynamics_kernel(EnvDev E, const float* __restrict__ root, const float* __restrict__ q,
                                                               const float* __restrict__ qd, const float* __restrict__ tau,
                                                               const float* __restrict__ wrench, float* __restrict__ qacc,
                                                               unsigned* __restrict__ left_mask) {
-    __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
+    __shared__ float s_work[LdsLinkStore::FLOATS];
     const int lane = threadIdx.x;
+    LdsLinkStore::write_origins((lds_f32*)s_work, *E.model, lane);
+    // (A persistent form -- 2,048 workgroups walking the blocks, per-lane constants kept from being hoisted -- was measured on one box against this
+    // one-workgroup-per-block form: 263 / 243 us against 257 / 243-248 us for the two bench states.  The wave slots' turnover is not what the launch waits for.)
     int e = blockIdx.x * ENVS_PER_BLOCK + (lane >> 1);
     const bool valid = e < E.n;
     if (!valid) e = E.n - 1;
@@ -307,8 +318,9 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
         const float* r = root + (size_t)e * 13;
         left = body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]));
     }
-    if (!left) left = forward_dynamics_lane<false, SELF_DEFER>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
-    if (left_mask) {
+    if constexpr (GATED) { if (!left) left = forward_dynamics_lane<false, SELF_DEFER>(E, lane, e, valid, s_work, root, q, qd, tau, wrench, qacc); }
+    else forward_dynamics_lane<false, SELF_LDS>(E, lane, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+    if (GATED && left_mask) {
         const unsigned long long m = __ballot(left && valid && !(lane & 1));  // bit 2k = env k of the block
         if (lane == 0) {
             unsigned packed = 0u;
@@ -348,8 +360,9 @@ __global__ __launch_bounds__(64) void forward_dynamics_body_kernel(EnvDev E, con
                                                                    const float* __restrict__ qd, const float* __restrict__ tau,
                                                                    const float* __restrict__ wrench, float* __restrict__ qacc,
                                                                    const int* __restrict__ left_list, unsigned* __restrict__ left_count) {
-    __shared__ float s_work[LdsLinkStore::SLOTS * LdsLinkStore::STRIDE];
+    __shared__ float s_work[LdsLinkStore::FLOATS];
     const int lane = threadIdx.x;
+    LdsLinkStore::write_origins((lds_f32*)s_work, *E.model, lane);
     const int cnt = (int)__builtin_nontemporal_load(left_count);
     for (int w = blockIdx.x; w * ENVS_PER_BLOCK < cnt; w += gridDim.x) {
         const int idx = w * ENVS_PER_BLOCK + (lane >> 1);
@@ -359,8 +372,8 @@ __global__ __launch_bounds__(64) void forward_dynamics_body_kernel(EnvDev E, con
         const float* r = root + (size_t)e * 13;
         bool low = false;
         if constexpr (GATED) low = body_contacts_active(make_phys(E.cfg), E.terrain, *E.model, v3(r[0], r[1], r[2]));
-        if (low) { if constexpr (GATED) forward_dynamics_lane<true, SELF_INLINE>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc); }
-        else forward_dynamics_lane<false, SELF_INLINE>(E, e, valid, s_work, root, q, qd, tau, wrench, qacc);
+        if (low) { if constexpr (GATED) forward_dynamics_lane<true, SELF_INLINE>(E, lane, e, valid, s_work, root, q, qd, tau, wrench, qacc); }
+        else forward_dynamics_lane<false, SELF_INLINE>(E, lane, e, valid, s_work, root, q, qd, tau, wrench, qacc);
     }
     __syncthreads();
     if (lane == 0 && atomicAdd(left_count + 1, 1u) == gridDim.x - 1u) { left_count[0] = 0u; left_count[1] = 0u; }
@@ -685,7 +698,7 @@ static int env_create_fill(bg_env* e, const bg_env_cfg* cfg, const bg_model* mod
     // a step below terminate_height >= body_gate_height (the shipped T1.yaml: 0.45 / 0.45) no env can ever start a step that low, and the whole
     // two-kernel scheme (mask bookkeeping + the second launch) is left out: the launch sequence is then exactly that of a model without spheres.
     e->body_two_kernel = model->desc.num_body_spheres > 0 && cfg->body_gate_height > cfg->terminate_height;
-    if (e->body_two_kernel || e->cfg.self_collisions) {  // the ABA launch's second kernel also takes the envs whose legs can meet
+    if (e->body_two_kernel) {  // the ABA launch's second kernel (trunk-low envs; there also the envs whose legs can meet)
         HIP_OK(hipMalloc(&e->fd_mask, sizeof(unsigned) * ((n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK)));
         HIP_OK(hipMalloc(&e->fd_list, sizeof(int) * n));
         HIP_OK(hipMalloc(&e->fd_count, sizeof(unsigned) * 2));
@@ -915,17 +928,15 @@ extern "C" int bg_env_set_step_count(bg_env* e, int64_t c) {
 extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float* q, const float* qd, const float* tau, const float* wrench,
                                        float* qacc, void* stream) {
     if (!e || !root || !q || !qd || !tau || !qacc) return fail(-1, "bg_env_forward_dynamics: null argument");
-    dim3 grid((e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK), block(64);
-    if (!e->fd_list) hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, (unsigned*)nullptr);
+    const int nb = (e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
+    dim3 grid(nb), block(64);
+    if (!e->body_two_kernel) hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, (unsigned*)nullptr);
     else {
-        if (e->body_two_kernel) hipLaunchKernelGGL(forward_dynamics_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->fd_mask);
-        else hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->fd_mask);
-        const int nb = (int)grid.x;  // one wave per SIMD: 1024 resident workgroups walk the list (two per SIMD spill 480 B per lane: 286 against 268 us)
+        hipLaunchKernelGGL(forward_dynamics_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->fd_mask);
+        // kernel B: one wave per SIMD, 1024 resident workgroups walk the list
         hipLaunchKernelGGL(aba_compact_kernel, dim3((nb + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const unsigned*)e->fd_mask, nb, e->fd_list, e->fd_count);
-        if (e->body_two_kernel) hipLaunchKernelGGL(forward_dynamics_body_kernel<true>, dim3(nb < 1024 ? nb : 1024), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
-                                                   wrench, qacc, (const int*)e->fd_list, e->fd_count);
-        else hipLaunchKernelGGL(forward_dynamics_body_kernel<false>, dim3(nb < 1024 ? nb : 1024), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
-                                wrench, qacc, (const int*)e->fd_list, e->fd_count);
+        hipLaunchKernelGGL(forward_dynamics_body_kernel<true>, dim3(nb < 1024 ? nb : 1024), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
+                           wrench, qacc, (const int*)e->fd_list, e->fd_count);
     }
     HIP_OK(hipGetLastError());
     return 0;
