@@ -144,6 +144,45 @@ class MLPTrainer:
                              p(ls[0].bias), p(ls[1].weight), p(ls[1].bias), p(ls[2].weight), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]), p(self.acts[2]),
                              p(vw), p(vb), p(vo))
 
+    def prepare(self, x, train_rows=None):
+        """Workspaces for a forward pass on x (first `train_rows` rows = the batch the backward pass differentiates) without running it."""
+        B = x.shape[0] if train_rows is None else train_rows
+        if self._B != B or self._rows != x.shape[0] or self._kin != x.shape[1]:
+            self._alloc(x.shape[0], B, x.device, x.shape[1])
+        self.x = x
+
+    def refresh_mirrors(self):
+        """Rewrite the copies of the weights that the layer kernels read (zero-padded first layer, transposed hidden layers) from the parameters, on
+        the current stream.  The optimiser launch keeps them current; this covers weights changed by other means (checkpoint, broadcast, a test)."""
+        ls = self.layers
+        if self.w0pad is not None:
+            self.w0pad[:, : ls[0].weight.shape[1]].copy_(ls[0].weight)
+        for i, w in enumerate(self.wt):
+            if w is not None:
+                w.copy_(ls[i].weight.t())
+        self.mirror_fresh = True
+
+    def chain_rows_descriptor(self, row0, nrows):
+        """bg_mlp_chain of rows [row0, row0 + nrows) of the pass prepared by `prepare` (whole 128-row slabs: the kernel stores every slab in full):
+        the same launch the full-batch forward makes, restricted to these slabs -- bit-identical outputs in the same places of the activation buffers
+        (and of the value head's output).  Used by the rollout, which evaluates each step's rows as soon as the simulator has produced them."""
+        if row0 % 128 or nrows % 128 or row0 + nrows > self.x.shape[0]:
+            raise ValueError("chain_rows_descriptor: row0 and nrows must be multiples of 128 inside the prepared batch")
+        d = self._chain_descriptor()
+        d.M = nrows
+        d.X = d.X + 4 * row0 * self._kin
+        ls = self.layers
+        d.Y1, d.Y2, d.Y3 = (y + 4 * row0 * l.weight.shape[0] for y, l in zip((d.Y1, d.Y2, d.Y3), ls[:3]))
+        if d.v_out:
+            d.v_out = d.v_out + 4 * row0
+        return d
+
+    @staticmethod
+    def forward_rows_group(jobs):
+        """jobs = [(trainer, row0, nrows), ...]: the chained forward of those rows of every trainer's prepared pass in ONE launch (at most 4)."""
+        ds = (_lib.MlpChain * len(jobs))(*[tr.chain_rows_descriptor(r0, nr) for tr, r0, nr in jobs])
+        _lib.check(_lib.load().bg_mlp_chain_forward_group(ctypes.addressof(ds), len(jobs), _lib.current_stream_ptr()), "bg_mlp_chain_forward_group")
+
     @staticmethod
     def forward_hidden_group(jobs):
         """forward_hidden of several networks: jobs = [(trainer, x, train_rows), ...]; returns the list of last-hidden activations.  Where every

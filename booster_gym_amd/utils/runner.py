@@ -223,6 +223,15 @@ class Runner:
         self._values_all = torch.zeros(B + N, device=dev)
         self._head_scratch_a, self._head_scratch_c = head_scratch(dev), head_scratch(dev)
         self._act_counter = 0
+        # The forward passes of the first mini-epoch run DURING the rollout (see rollout()): 1 = on (default where the chained kernels apply), 0 = off
+        self._rollout_forward = (os.environ.get("BG_ROLLOUT_FORWARD", "1") == "1" and self._fused_head and self._fused_gae and self._chain_values
+                                 and self._pad_in is not None and N % 128 == 0 and not MLPTrainer.SPLIT)
+        # ... the rows of this many consecutive steps per group of side-stream launches.  Every group costs the main stream one event record (2.9 us, 5.7
+        # with a waiter on another queue: tools/event_cost_probe.py), and from four steps per group on the chained launches need more than the 128 CUs
+        # the env step leaves idle and slow it down (110 against 102.5 us).  Same box, 20 iterations each, ms per iteration: off 24.78-24.92, one step
+        # per group 24.46-24.49, two 24.39-24.41, three 24.42-24.47, four 24.55-24.66, eight 24.58-24.65 (profiles/r04_rollout_forward_ab.txt).
+        self._rollout_group = max(1, int(os.environ.get("BG_ROLLOUT_FORWARD_GROUP", "2")))
+        self._fwd_ready = False  # rollout() has left the activations / values / old mu of the whole batch in the trainers' buffers
         self.timers = {"rollout": 0.0, "update": 0.0}
 
     # ------------------------------------------------------------------ config / seed / checkpoint (runner.py:44-97)
@@ -287,15 +296,78 @@ class Runner:
 
     # ------------------------------------------------------------------ one PPO iteration
     def rollout(self):
-        """runner.py:106-121: horizon_length env steps with sampled actions, outputs written in place."""
+        """runner.py:106-121: horizon_length env steps with sampled actions, outputs written in place.
+
+        While the simulator steps -- one wave per CU on half of the CUs, latency-bound -- the side stream evaluates what the FIRST mini-epoch of the
+        update needs and what does not change until the first optimiser step: the critic's hidden layers and values (runner.py:123-125, 132) and the
+        actor's hidden layers and old mu (runner.py:126-129) on each step's 4,096 rows as soon as they exist, with the kernels and weights the
+        update would use (32 slabs per network and step on the idle CUs: bit-identical to the full-batch launches, asserted in
+        tests/test_gpu_ppo.py), and the old log-probabilities one step behind.  update() then starts at the GAE: no old-mu pass, no forward chains
+        in mini-epoch 0.  Nothing on the main stream waits for the side stream here; update()'s own hand-overs order the two."""
         buf, T = self.buffer, self.cfg["runner"]["horizon_length"]
         obses, priv = buf["obses"], buf["privileged_obses"]
         seed = int(self.cfg["basic"]["seed"]) + 1000003 * (self.rank + 1)
+        ahead = self._rollout_forward and self._prepare_rollout_forward()
+        main = torch.cuda.current_stream()
+        g, start = self._rollout_group, 0
         with torch.no_grad():
             for n in range(T):
+                if ahead and n + 1 - start >= g:
+                    self._forward_rows(start, n, main)  # rows of steps start .. n: on the side stream, beside this step's launches
+                    start = n + 1
                 self.model.sample_actions(obses[n], buf["actions"][n], seed, self._act_counter)
                 self._act_counter += 1
                 self.env.step_to(buf["actions"][n], obses[n + 1], priv[n + 1], buf["rewards"][n], buf["dones"][n], buf["time_outs"][n])
+            if ahead:
+                self._forward_rows(start, T, main)  # ... and the observation after the last step: the critic's last_values rows
+                self._fwd_ready = True
+
+    def _prepare_rollout_forward(self):
+        T, N = self.cfg["runner"]["horizon_length"], self.env.num_envs
+        ct, at = self._critic_tr, self._actor_tr
+        ct.prepare(self._critic_in.reshape((T + 1) * N, -1), train_rows=T * N)
+        at.prepare(self._actor_in.reshape(T * N, -1))
+        if not (ct._chainable() and at._chainable()):
+            return False
+        c_out = ct.layers[-1]
+        ct.value_head = (c_out.weight.reshape(-1), c_out.bias, self._values_all)
+        at.value_head = None
+        return True
+
+    def _forward_rows(self, a, b, main):
+        """Side stream: pad the observation rows of steps a .. b (b = T: the observation after the last step, critic only) into the network inputs
+        and run both networks' chained forward (+ value head, + the actor's output layer = old mu) on them; old log-probabilities of the steps
+        whose actions have been sampled by now.  A row block exists once the env step before it has finished: the side stream waits for the main
+        stream's work enqueued so far."""
+        T, N = self.cfg["runner"]["horizon_length"], self.env.num_envs
+        no, npv = self.env.num_obs, self.env.num_privileged_obs
+        buf, side = self.buffer, self._side_stream
+        ct, at = self._critic_tr, self._actor_tr
+        ba = min(b, T - 1)  # last actor step of the range
+        side.wait_stream(main)
+        with torch.cuda.stream(side), torch.no_grad():
+            logstd = self.model.logstd.reshape(-1)
+            if a == 0:  # weights may have changed since the last optimiser step by other means (checkpoint, broadcast): six small copies, off the critical path
+                ct.refresh_mirrors(); at.refresh_mirrors()
+                self._logp_done = 0
+            if self._logp_done < a:  # steps of earlier calls: their actions were sampled on the main stream after their rows were enqueued here
+                r0, r1 = self._logp_done * N, a * N
+                gaussian_logp(self._old_mu[r0:r1], logstd, buf["actions"][self._logp_done : a].reshape(-1, self.env.num_actions), out=self._old_logp[r0:r1])
+                self._logp_done = a
+            self._critic_in[a : b + 1, :, :no].copy_(buf["obses"][a : b + 1])
+            self._critic_in[a : b + 1, :, no : no + npv].copy_(buf["privileged_obses"][a : b + 1])
+            jobs = [(ct, a * N, (b + 1 - a) * N)]
+            if a <= ba:
+                self._actor_in[a : ba + 1, :, :no].copy_(buf["obses"][a : ba + 1])
+                jobs.append((at, a * N, (ba + 1 - a) * N))
+            MLPTrainer.forward_rows_group(jobs)
+            if a <= ba:
+                a_out = at.layers[-1]
+                actor_head_forward(at.acts[2][a * N : (ba + 1) * N], a_out.weight, a_out.bias, self._old_mu[a * N : (ba + 1) * N])
+            if b == T and self._logp_done < T:  # the last call: every action has been sampled
+                r0 = self._logp_done * N
+                gaussian_logp(self._old_mu[r0:], logstd, buf["actions"][self._logp_done :].reshape(-1, self.env.num_actions), out=self._old_logp[r0:])
+                self._logp_done = T
 
     def update(self):
         """runner.py:123-189: old log-probs, then mini_epochs full-batch optimiser steps."""
@@ -305,26 +377,30 @@ class Runner:
         alg = cfg["algorithm"]
         act_flat = buf["actions"].reshape(B, A)
         no, npv = self.env.num_obs, self.env.num_privileged_obs
-        self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = False  # weights may have changed outside the loop below (checkpoint, broadcast)
-        self._critic_in[:, :, :no].copy_(buf["obses"])
-        self._critic_in[:, :, no : no + npv].copy_(buf["privileged_obses"])
-        if self._actor_in is not None:
-            self._actor_in[:, :, :no].copy_(buf["obses"][:T])
-            obs_flat = self._actor_in.reshape(B, -1)
-        else:
-            obs_flat = buf["obses"][:T].reshape(B, -1)
+        # rollout() may have run the first mini-epoch's forward passes already (activations, values and old mu of every row are in place)
+        ahead, self._fwd_ready = self._fwd_ready, False
+        if not ahead:
+            self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = False  # weights may have changed outside the loop below (checkpoint, broadcast)
+            self._critic_in[:, :, :no].copy_(buf["obses"])
+            self._critic_in[:, :, no : no + npv].copy_(buf["privileged_obses"])
+            if self._actor_in is not None:
+                self._actor_in[:, :, :no].copy_(buf["obses"][:T])
+        obs_flat = self._actor_in.reshape(B, -1) if self._actor_in is not None else buf["obses"][:T].reshape(B, -1)
         critic_all = self._critic_in.reshape((T + 1) * N, -1)  # rows [B, B+N) = the observation after the last step (last_values)
         fused_head = self._fused_head
         logstd_flat = self.model.logstd.reshape(-1)
         a_out, c_out = self._actor_tr.layers[-1], self._critic_tr.layers[-1]
         with torch.no_grad():
             # old mu through the same kernels as the mini-epochs: the first ratio is exactly 1
-            if fused_head:
+            if ahead:
+                old_mu = self._old_mu
+            elif fused_head:
                 old_mu = actor_head_forward(self._actor_tr.forward_hidden(obs_flat), a_out.weight, a_out.bias, self._old_mu)
             else:
                 old_mu = self._actor_tr.forward(obs_flat).clone()
             old_logstd = self.model.logstd.detach().reshape(-1).clone()
-            gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
+            if not ahead:
+                gaussian_logp(old_mu, old_logstd, act_flat, out=self._old_logp)
         self._stats_acc.zero_()
         self._stats.zero_()
         self._grad_logstd.zero_()
@@ -334,10 +410,11 @@ class Runner:
         main = torch.cuda.current_stream()
         side = self._side_stream if os.environ.get("BG_TWO_STREAMS", "1") == "1" else main
         with torch.no_grad():
-            for _ in range(cfg["runner"]["mini_epochs"]):
+            for epoch in range(cfg["runner"]["mini_epochs"]):
+                have_fwd = ahead and epoch == 0  # this mini-epoch's hidden activations and values are the rollout's: same kernels, same weights
                 # parameters updated by the previous optimiser step; the loss accumulators (_stats, _grad_logstd) were zeroed by it (before the loop
                 # for the first mini-epoch): both heads add into them
-                group_fwd = fused_head and self._group_forward
+                group_fwd = fused_head and self._group_forward and not have_fwd
                 # the chained forward kernel also evaluates the value head, from the registers that hold the last activations: the launch between the
                 # critic's forward and the actor's loss then has 400 KB to read instead of 52 MB
                 chain_values = fused_head and self._fused_gae and self._chain_values and self._critic_tr.chainable_for(critic_all, B)
@@ -349,7 +426,9 @@ class Runner:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     if fused_head:
-                        if not group_fwd:
+                        if have_fwd:
+                            hc = self._critic_tr.acts[2]
+                        elif not group_fwd:
                             hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
                         if self._fused_gae:
                             # output layer + timeout bootstrap + GAE + returns + advantage moments in ONE launch in front of the actor's loss
@@ -374,7 +453,9 @@ class Runner:
                     defer = self._defer_finish and not MLPTrainer.SPLIT
                     fins = [] if defer else None
                     fin_c, fin_a = (_lib.ReduceProblem(), _lib.ReduceProblem()) if defer else (None, None)
-                    if not group_fwd:
+                    if have_fwd:
+                        ha = self._actor_tr.acts[2]
+                    elif not group_fwd:
                         ha = self._actor_tr.forward_hidden(obs_flat)
                     with torch.cuda.stream(side):
                         critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,

@@ -272,6 +272,33 @@ def test_full_update_matches_reference_loop():
     assert abs(summ["lr"] - lr_ref) < 1e-9
 
 
+def test_forward_passes_run_during_the_rollout_change_no_bit():
+    """Runner.rollout() evaluates the first mini-epoch's forward passes (critic hidden layers + values, actor hidden layers + old mu, old log-probs)
+    on every step's rows while the simulator runs the next step (side stream, the update's own kernels on 128-row slabs).  Against the same runner with
+    that switched off (the passes run at the start of update(), reference order runner.py:123-133): identical bits in the parameters, the Adam
+    moments, the loss statistics and the old log-probabilities after two whole iterations (the second rollout reads the weight copies the optimiser
+    launch wrote), on 256 envs (two slabs per step and network) and with the command curriculum and rough terrain on."""
+    from booster_gym_amd.utils.config import load_cfg
+    from booster_gym_amd.utils.runner import Runner
+
+    for over in ({"terrain.type": "plane"}, {"terrain.type": "trimesh", "commands.curriculum": True}):
+        res = []
+        for ahead in (True, False):
+            cfg = load_cfg("T1", dict({"env.num_envs": 256, "runner.mini_epochs": 3, "basic.seed": 7}, **over))
+            r = Runner(cfg=cfg)
+            assert r._rollout_forward, "the default path must be the overlapped one at this shape"
+            r._rollout_forward = ahead
+            obs, infos = r.env.reset()
+            r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+            for _ in range(2):
+                stats = r.iteration().clone()
+            torch.cuda.synchronize()
+            res.append((r.optimizer.flat.clone(), r.optimizer.exp_avg_sq.clone(), stats, r._old_logp.clone(), r._old_mu.clone(), r._values_all.clone(), r.buffer["obses"].clone()))
+            del r
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+
+
 def test_update_with_deferred_reductions_equals_update_with_immediate_ones():
     """Runner.update() with the small reductions deferred to one launch in front of the weight gradients (the default), to one launch on the side
     stream beside them (BG_DEFER_FINISH=2) and with every finish inside its chain (=0), from identical weights and rollout data: same parameters

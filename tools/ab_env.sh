@@ -1,17 +1,15 @@
 #!/bin/bash
-# Same-box A/B of bench.py under two environment settings, alternating, REPS times each:
-#   bash tools/ab_env.sh "BG_DEFER_FINISH=1" "BG_DEFER_FINISH=0" [reps]      (AB_ARGS="--steps 30": extra bench.py arguments)
-# prints value / ms per iteration / phase split of every run (bench.py --no-cpu-baseline --no-extra).
-A="$1"; B="$2"; REPS=${3:-3}
+# Same-box A/B of the whole training loop under environment switches: alternating runs of `bench.py --steps 20 --warmup 3` (no CPU baseline, no
+# extras), one line per run.   gpurun -- bash tools/ab_env.sh "BG_X=1" "BG_X=0" [repeats=2]
 R=${GRAFT_REPO_ROOT:-/root/repo}
-mkdir -p $R/gpurun_out
-for i in $(seq 1 $REPS); do
-  for cfg in "$A" "$B"; do
-    env $cfg python3 $R/bench.py --no-cpu-baseline --no-extra ${AB_ARGS:-} > $R/gpurun_out/ab_tmp.json 2> $R/gpurun_out/ab_tmp.err
-    python3 - "$cfg" <<'PY'
-import json, sys
-d = json.loads([l for l in open(__import__("os").environ.get("GRAFT_REPO_ROOT", "/root/repo") + "/gpurun_out/ab_tmp.json") if l.startswith("{")][-1])
-print(f"{sys.argv[1]:28s} {d['value']/1e6:6.3f} M env-steps/s  {d['ms_per_step']:7.3f} ms  rollout {d['phase_ms']['rollout']:.3f}  update {d['phase_ms']['update']:.3f}", flush=True)
-PY
+cd $R
+N=${@: -1}
+if [[ "$N" =~ ^[0-9]+$ ]]; then set -- "${@:1:$(($#-1))}"; else N=2; fi
+for rep in $(seq 1 $N); do
+  for v in "$@"; do
+    env $v timeout -k 10 300 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-extra 2>/dev/null | python -c "
+import sys, json
+d = json.loads(sys.stdin.read().strip().splitlines()[-1])
+print('$v', round(d['value']), round(d['ms_per_step'], 3), {k: round(v, 3) for k, v in d['phase_ms'].items()}, 'env step us', round(d['roofline_env_step']['avg_launch_us'], 1))"
   done
 done
