@@ -57,7 +57,7 @@ class GroupedWeightGrad:
         self.workgroups = workgroups or MLPTrainer.WGRAD_WORKGROUPS
         # waves of a workgroup on the same rows, different tiles (plan_wgrad_slices): measured no faster alone (329.6 vs 329.2 us for the six layers) and
         # 0.3 ms slower per update in the loop (4x the partial-tile traffic for the 256 x 256 layer), so the pure split over rows stays the default
-        self.share_rows = __import__("os").environ.get("BG_WGRAD_SHARE_ROWS", "0") == "1"
+        self.share_rows = False
         self._key, self._arr, self._scratch = None, None, None
         self.timed_events = None
 
@@ -103,8 +103,9 @@ class MLPTrainer:
 
     # Hidden layers with K in {64, 128, 256} and N % 128 == 0 run on the hand-written fused fp32-MFMA layer (bg_mlp.hip: bias + ELU in the GEMM
     # epilogue).  Measured on MI355X at M = 98,304 (tools/mlp_probe.py): 131.8 vs 151.3 us (256x256), 63.9 vs 76.3 us (256x128), 37.5 vs 55.8 us
-    # (128x128) against hipBLASLt addmm + elu_.  BG_FUSED_MLP=0 falls back to the library GEMM + elementwise ELU.
-    FUSED = __import__("os").environ.get("BG_FUSED_MLP", "1") == "1"
+    # (128x128) against hipBLASLt addmm + elu_.  Other shapes, or FUSED = False (a class attribute, for the tests that compare the two forms): the
+    # library GEMM + elementwise ELU.
+    FUSED = True
 
     # Opt-in (BG_GEMM_SPLIT=9 or 6): the same layers on the bf16 matrix pipe, every fp32 operand split exactly into three bf16 numbers and all 9
     # (or the 6 largest) cross products accumulated in fp32 (bg_mlp_split.hip).  0 = the fp32 MFMA kernels.
@@ -114,9 +115,9 @@ class MLPTrainer:
     def _fusable(cls, k_in, n_out):
         return cls.FUSED and k_in in (64, 128, 256) and n_out % 128 == 0
 
-    # The forward pass of the three hidden layers as one launch (bg_mlp_chain_forward) where the widths are the reference's (BG_MLP_CHAIN=0: one launch
-    # per layer).  
-    CHAIN = __import__("os").environ.get("BG_MLP_CHAIN", "1") == "1"
+    # The forward pass of the three hidden layers as one launch (bg_mlp_chain_forward) where the widths are the reference's (CHAIN = False: one launch
+    # per layer)
+    CHAIN = True
 
     def _chainable(self):
         ls = self.layers
@@ -183,22 +184,6 @@ class MLPTrainer:
         ds = (_lib.MlpChain * len(jobs))(*[tr.chain_rows_descriptor(r0, nr) for tr, r0, nr in jobs])
         _lib.check(_lib.load().bg_mlp_chain_forward_group(ctypes.addressof(ds), len(jobs), _lib.current_stream_ptr()), "bg_mlp_chain_forward_group")
 
-    @staticmethod
-    def forward_hidden_group(jobs):
-        """forward_hidden of several networks: jobs = [(trainer, x, train_rows), ...]; returns the list of last-hidden activations.  Where every
-        network can run the chained kernel they share ONE launch on the current stream (bg_mlp_chain_forward_group): the slabs of the first job are
-        dispatched first, the others fill the machine as those retire.  Otherwise one forward_hidden after the other."""
-        for tr, x, train_rows in jobs:
-            B = x.shape[0] if train_rows is None else train_rows
-            if tr._B != B or tr._rows != x.shape[0] or tr._kin != x.shape[1]:
-                tr._alloc(x.shape[0], B, x.device, x.shape[1])
-            tr.x = x
-        if not all(tr._chainable() for tr, _, _ in jobs) or len(jobs) > 4:
-            return [tr.forward_hidden(x, train_rows) for tr, x, train_rows in jobs]
-        ds = (_lib.MlpChain * len(jobs))(*[tr._chain_descriptor() for tr, _, _ in jobs])
-        _lib.check(_lib.load().bg_mlp_chain_forward_group(ctypes.addressof(ds), len(jobs), _lib.current_stream_ptr()), "bg_mlp_chain_forward_group")
-        return [tr.acts[2] for tr, _, _ in jobs]
-
     def __init__(self, seq, max_split=32):
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
         self.max_split = max_split
@@ -239,12 +224,12 @@ class MLPTrainer:
         self.dw0sum = torch.empty(l0.weight.shape[0], k_in, dtype=torch.float32, device=dev) if self.w0pad is not None else None
 
     # Weight gradients (the dW part of loss.backward(), runner.py:163): hand-written fp32-MFMA kernel, ALL hidden layers of both networks in one
-    # launch pair after both backward chains (bg_mlp_weight_grad_group, GroupedWeightGrad; DEFER_WGRAD below).  Measured on MI355X, round 2
+    # launch pair after both backward chains (bg_mlp_weight_grad_group, GroupedWeightGrad).  Measured on MI355X, round 2
     # (tools/archive/ab_defer.sh, update phase per iteration): library split-K bmm + sum inside the chains 24.13 ms; the hand-written kernel one layer at a
     # time inside the chains 26.46 ms (its 512-register, 128 KB-LDS workgroups cannot share a CU with the other stream's kernels); the library
-    # path deferred 24.39 ms; the grouped hand-written launch 23.01 ms = 3.77 M env-steps/s against 3.61 M.  BG_FUSED_WGRAD=0 selects the library path.
-    FUSED_WGRAD = __import__("os").environ.get("BG_FUSED_WGRAD", "1") == "1"
-    WGRAD_WORKGROUPS = int(__import__("os").environ.get("BG_WGRAD_WORKGROUPS", "256"))  # one 4-wave workgroup per CU
+    # path deferred 24.39 ms; the grouped hand-written launch 23.01 ms = 3.77 M env-steps/s against 3.61 M.  FUSED_WGRAD = False selects the library path.
+    FUSED_WGRAD = True
+    WGRAD_WORKGROUPS = 256  # one 4-wave workgroup per CU
 
     @classmethod
     def _wgrad_slices(cls, B, c_out, c_in):
@@ -346,8 +331,7 @@ class MLPTrainer:
         self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g, finishes)
 
     # The backward chain computes only dL/dz; the weight gradients of all layers run afterwards, when both networks' chains are done and nothing
-    # else competes for the GPU (grouped launch, or `weight_grads()` layer by layer).  BG_DEFER_WGRAD=0: inside the chain, as in round 1.
-    DEFER_WGRAD = __import__("os").environ.get("BG_DEFER_WGRAD", "1") == "1"
+    # else competes for the GPU: the grouped launch (GroupedWeightGrad.run); shapes outside its range run as library GEMMs there.
 
     def pending_wgrad_problems(self):
         """(G, A, dW, C_out, C_in (padded), C_in_real) of every deferred weight gradient, and clears the list (for the grouped launch)."""
@@ -361,12 +345,6 @@ class MLPTrainer:
             out.append((g, a_in, l.weight.grad, l.weight.shape[0], a_in.shape[1], l.weight.shape[1]))
         self._pending_wgrad = []
         return out
-
-    def weight_grads(self):
-        """The deferred weight gradients of `_backward_from` (DEFER_WGRAD): layers in the order the chain visited them."""
-        for i, g in self._pending_wgrad:
-            self._weight_grad(i, g)
-        self._pending_wgrad = []
 
     def _weight_grad(self, i, g):
         lib, stream = _lib.load(), _lib.current_stream_ptr()
@@ -411,10 +389,7 @@ class MLPTrainer:
             l = self.layers[i]
             a_in = (self.acts[i - 1] if i > 0 else self.x)[:B]
             C_out, C_in = l.weight.shape
-            if self.DEFER_WGRAD:
-                self._pending_wgrad.append((i, g))
-            else:
-                self._weight_grad(i, g)
+            self._pending_wgrad.append((i, g))
             if i > 0:
                 below = self.layers[i - 1]
                 if self.SPLIT and self.FUSED and C_out in (128, 256) and C_in % 128 == 0:

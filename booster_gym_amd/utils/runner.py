@@ -111,24 +111,9 @@ class FlatAdam:
         self.lr.fill_(float(sd["param_groups"][0]["lr"]))
 
 
-def enable_gemm_tuning():
-    """Opt-in (BG_TUNE_GEMM=1): let PyTorch's TunableOp time the hipBLASLt / rocBLAS solutions for every GEMM shape of the update on
-    first use (about 15 s at start-up on MI355X, measured gain 3-4 % on the update phase).  Off by default: reproducible kernel choice."""
-    if os.environ.get("BG_TUNE_GEMM", "0") != "1":
-        return False
-    from torch.cuda import tunable
-
-    tunable.enable(True)
-    tunable.tuning_enable(True)
-    tunable.set_max_tuning_duration(50)
-    tunable.write_file_on_exit(False)
-    return True
-
-
 class Runner:
     def __init__(self, test=False, args=None, cfg=None):
         self.test = test
-        self.tuned_gemms = enable_gemm_tuning()
         self.dp = DataParallel()
         self.world_size, self.rank, self.local_rank = self.dp.world_size, self.dp.rank, self.dp.local_rank
         if cfg is None:
@@ -184,8 +169,9 @@ class Runner:
         self._stats = torch.zeros(5, dtype=torch.float64, device=dev)
         self._stats_acc = torch.zeros(5, dtype=torch.float64, device=dev)
         self._stats_last = torch.zeros(5, dtype=torch.float64, device=dev)  # the last mini-epoch's sums (kl_mean of the log, runner.py:199)
-        # BG_FUSED_OPT=0: the mini-epoch tail as separate launches (bg_adam_step, bg_adapt_lr, torch adds / fills) for A/B comparisons
-        self._fused_opt = os.environ.get("BG_FUSED_OPT", "1") == "1"
+        # False: the mini-epoch tail as separate launches (bg_adam_step, bg_adapt_lr, torch adds / fills): what the first optimiser step after a
+        # checkpoint restore runs (see update()); as an attribute for the tests that compare the two forms
+        self._fused_opt = True
         self._old_logp = torch.zeros(B, device=dev)
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
         self._logstd_off = (self._logstd_grad_view.data_ptr() - self.optimizer.grad.data_ptr()) // 4  # position of logstd in the flat buffers
@@ -197,8 +183,8 @@ class Runner:
             MLPTrainer.SPLIT = int(gs)
         self._wgrad_group = GroupedWeightGrad()
         # the critic's stream goes ahead of the actor's in workgroup dispatch: its chain is the longer one and the actor's loss waits for its GAE
-        # (update 23.17 -> 23.06 ms, tools/archive/ab_prio.sh; BG_SIDE_PRIORITY=0: equal priorities)
-        self._side_stream = torch.cuda.Stream(device=self.device, priority=int(os.environ.get("BG_SIDE_PRIORITY", "-1")))
+        # (update 23.17 -> 23.06 ms in round 2, 21.83-21.91 -> 21.55-21.65 ms in round 3 against equal priorities, tools/archive/ab_prio.sh)
+        self._side_stream = torch.cuda.Stream(device=self.device, priority=-1)
         # The small fixed-order reductions behind the head / backward-layer kernels run as ONE launch in front of the weight gradients instead of
         # inside the chains, where each of them waits 20-45 us for a workgroup slot between the other network's resident GEMM workgroups (see
         # update()).  Measured in the loop (tools/ab_env.sh, 4 alternating runs of 20 iterations each): update 21.68-21.91 ms with the one launch in
@@ -206,26 +192,20 @@ class Runner:
         # one-workgroup-per-CU launch), 21.99-22.04 ms with the finishes inside the chains (=0).
         self._defer_finish = os.environ.get("BG_DEFER_FINISH", "1") in ("1", "2")
         self._defer_serial = os.environ.get("BG_DEFER_FINISH", "1") != "2"
-        # the optimiser launch also writes the transposed / zero-padded weight copies the layer kernels read (bg_param_mirror); 0 = torch copies
-        self._mirror_weights = os.environ.get("BG_MIRROR_WEIGHTS", "1") == "1"
-        # both networks' forward chains in one launch (see update()); 0 = one launch per network on its own stream
-        self._group_forward = os.environ.get("BG_GROUP_FORWARD", "0") == "1"
-        # critic output layer + GAE in one launch (bg_critic_values_gae); 0 = bg_critic_head_forward, a fill and bg_gae
-        self._fused_gae = os.environ.get("BG_FUSED_GAE", "1") == "1" and self.cfg["runner"]["horizon_length"] <= 32
-        self._chain_values = os.environ.get("BG_CHAIN_VALUES", "1") == "1"  # ... with the values from the chained forward kernel's value head
+        # critic output layer + GAE in one launch (bg_critic_values_gae: horizons up to 32 steps); otherwise bg_critic_head_forward, a fill and bg_gae
+        self._fused_gae = self.cfg["runner"]["horizon_length"] <= 32
+        self._chain_values = True  # ... with the values from the chained forward kernel's value head (False: from the stored activations)
         self._gae_scratch = torch.zeros(3 * ((self.env.num_envs + 15) // 16) + 1, dtype=torch.float64, device=self.device)
 
-        # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value.  BG_FUSED_HEAD=0 keeps the
-        # library GEMMs + bg_ppo_loss for these layers (A/B comparisons).
-        self._fused_head = (os.environ.get("BG_FUSED_HEAD", "1") == "1" and A == 12
-                            and self.model.actor[-1].in_features == 128 and self.model.critic[-1].in_features == 128)
+        # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value (utils/model.py); a model of
+        # other widths runs the output layers as library GEMMs + bg_ppo_loss (as an attribute for the test that compares the two forms)
+        self._fused_head = A == 12 and self.model.actor[-1].in_features == 128 and self.model.critic[-1].in_features == 128
         self._old_mu = torch.zeros(B, A, device=dev)
         self._values_all = torch.zeros(B + N, device=dev)
         self._head_scratch_a, self._head_scratch_c = head_scratch(dev), head_scratch(dev)
         self._act_counter = 0
         # The forward passes of the first mini-epoch run DURING the rollout (see rollout()): 1 = on (default where the chained kernels apply), 0 = off
-        self._rollout_forward = (os.environ.get("BG_ROLLOUT_FORWARD", "1") == "1" and self._fused_head and self._fused_gae and self._chain_values
-                                 and self._pad_in is not None and N % 128 == 0 and not MLPTrainer.SPLIT)
+        self._rollout_forward = os.environ.get("BG_ROLLOUT_FORWARD", "1") == "1" and self._pad_in is not None and N % 128 == 0
         # ... the rows of this many consecutive steps per group of side-stream launches.  Every group costs the main stream one event record (2.9 us, 5.7
         # with a waiter on another queue: tools/event_cost_probe.py), and from four steps per group on the chained launches need more than the 128 CUs
         # the env step leaves idle and slow it down (110 against 102.5 us).  Same box, 20 iterations each, ms per iteration: off 24.78-24.92, one step
@@ -307,7 +287,8 @@ class Runner:
         buf, T = self.buffer, self.cfg["runner"]["horizon_length"]
         obses, priv = buf["obses"], buf["privileged_obses"]
         seed = int(self.cfg["basic"]["seed"]) + 1000003 * (self.rank + 1)
-        ahead = self._rollout_forward and self._prepare_rollout_forward()
+        ahead = (self._rollout_forward and self._fused_head and self._fused_gae and self._chain_values and not MLPTrainer.SPLIT
+                 and self._prepare_rollout_forward())
         main = torch.cuda.current_stream()
         g, start = self._rollout_group, 0
         with torch.no_grad():
@@ -408,27 +389,22 @@ class Runner:
         # Two HIP streams: the actor and the critic are independent networks, so the HBM-bound elementwise kernels of one overlap
         # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
         main = torch.cuda.current_stream()
-        side = self._side_stream if os.environ.get("BG_TWO_STREAMS", "1") == "1" else main
+        side = self._side_stream
         with torch.no_grad():
             for epoch in range(cfg["runner"]["mini_epochs"]):
                 have_fwd = ahead and epoch == 0  # this mini-epoch's hidden activations and values are the rollout's: same kernels, same weights
                 # parameters updated by the previous optimiser step; the loss accumulators (_stats, _grad_logstd) were zeroed by it (before the loop
                 # for the first mini-epoch): both heads add into them
-                group_fwd = fused_head and self._group_forward and not have_fwd
                 # the chained forward kernel also evaluates the value head, from the registers that hold the last activations: the launch between the
                 # critic's forward and the actor's loss then has 400 KB to read instead of 52 MB
                 chain_values = fused_head and self._fused_gae and self._chain_values and self._critic_tr.chainable_for(critic_all, B)
                 self._critic_tr.value_head = (c_out.weight.reshape(-1), c_out.bias, self._values_all) if chain_values else None
-                if group_fwd:
-                    # the hidden layers of BOTH networks in one launch (bg_mlp_chain_forward_group): the critic's slabs are dispatched first (the GAE and
-                    # with it the actor's loss wait for its values), the actor's fill the machine as they retire
-                    hc, ha = MLPTrainer.forward_hidden_group([(self._critic_tr, critic_all, B), (self._actor_tr, obs_flat, None)])
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
                     if fused_head:
                         if have_fwd:
                             hc = self._critic_tr.acts[2]
-                        elif not group_fwd:
+                        else:
                             hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
                         if self._fused_gae:
                             # output layer + timeout bootstrap + GAE + returns + advantage moments in ONE launch in front of the actor's loss
@@ -453,10 +429,7 @@ class Runner:
                     defer = self._defer_finish and not MLPTrainer.SPLIT
                     fins = [] if defer else None
                     fin_c, fin_a = (_lib.ReduceProblem(), _lib.ReduceProblem()) if defer else (None, None)
-                    if have_fwd:
-                        ha = self._actor_tr.acts[2]
-                    elif not group_fwd:
-                        ha = self._actor_tr.forward_hidden(obs_flat)
+                    ha = self._actor_tr.acts[2] if have_fwd else self._actor_tr.forward_hidden(obs_flat)
                     with torch.cuda.stream(side):
                         critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,
                                              c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c, finish=fin_c)
@@ -503,12 +476,9 @@ class Runner:
                             self.dp.sum_(self._stats)  # exchange (3)
                         if self.dp.active or not fused_tail:
                             self._logstd_grad_view.copy_(self._grad_logstd)
-                if MLPTrainer.DEFER_WGRAD:  # all weight gradients after both backward chains, alone on the GPU
-                    if MLPTrainer.FUSED_WGRAD and MLPTrainer.FUSED:
-                        self._wgrad_group.run((self._critic_tr, self._actor_tr))  # one launch pair for the six layers
-                    else:
-                        self._critic_tr.weight_grads()
-                        self._actor_tr.weight_grads()
+                # all weight gradients after both backward chains, alone on the GPU: one launch pair for the six hidden layers (shapes outside the
+                # kernel's range, or MLPTrainer.FUSED_WGRAD = False: library GEMMs, layer by layer)
+                self._wgrad_group.run((self._critic_tr, self._actor_tr))
                 if defer and (self.dp.active or not self._defer_serial):
                     main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
@@ -516,7 +486,7 @@ class Runner:
                     # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch
                     # ... and the copies of the weights that the layer kernels read (zero-padded first layers, transposed hidden layers): written by the
                     # same launch instead of six strided torch copies inside the chains of the next mini-epoch
-                    if mirrors is None and self._mirror_weights:
+                    if mirrors is None:
                         ms = self._critic_tr.mirror_descriptors(self.optimizer.flat) + self._actor_tr.mirror_descriptors(self.optimizer.flat)
                         mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 8 else None
                     self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
@@ -526,6 +496,7 @@ class Runner:
                         self._grad_logstd.zero_()
                 else:
                     self.optimizer.step()
+                    self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = False  # this launch does not write the weight copies: the next pass copies them
                     if self._lr_restart:  # first step after a checkpoint load: see __init__
                         self.optimizer.lr.fill_(float(cfg["algorithm"]["learning_rate"]))
                         self._lr_restart = False
