@@ -6,6 +6,11 @@
 A "step" is one PPO iteration on synthetic (randomly initialised) policy weights: 24 env-steps x 4096 envs per GPU through the
 HIP simulator + 20 full-batch optimiser steps (BASELINE.json configs[1], flat terrain).  Rank 0 prints
 ONE JSON line.  `value` = world * N * T * K / wall (max over ranks).
+
+`roofline` = the symbols with the largest total time in this round's rocprofv3 summary of this command (profiles/r04_bench_kernel_stats.csv): the
+two networks' chained forward launches, priced over the span of each mini-epoch's pair; `roofline_wgrad` = the grouped weight gradients (the largest
+single launch); `roofline_env_step`, `roofline_aba` = the simulator kernels against the HBM roof; `other_configs` = BASELINE configs[2] and [4]
+through the same loop; `cpu_baseline` = the oracle's CPU restatement of the same workload on the host cores.
 """
 import argparse
 import ctypes
@@ -53,7 +58,7 @@ ABA_BYTES = 4 * (13 + 12 + 12 + 12 + 6 + 18 + 6 + 58)  # forward_dynamics_kernel
 from booster_gym_amd import _lib  # noqa: E402  (raw ABI calls for the kernel-level timings)
 
 
-PMC_TAG = "r03"
+PMC_TAG = "r04"
 PMC_SOURCE = (f"profiles/{PMC_TAG}_bench_pmc.json / profiles/{PMC_TAG}_env_pmc.json: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes of "
               "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra` and `tools/prof_env.py 4096 plane` (tools/profile.sh); "
               "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE for the 16-byte-per-lane MFMA layer kernels (the guide's gfx950 correction), FETCH_SIZE + WRITE_SIZE otherwise")
@@ -73,7 +78,7 @@ def pmc_traffic(kernel_prefix, which="bench"):
 def _aba_pmc():
     """Per-launch HBM bytes and VALU instructions per wave of the ABA launch's kernels from this round's rocprofv3 passes (tools/profile_aba.sh)."""
     try:
-        ks = json.load(open(os.path.join(ROOT, "profiles", "r03_a_aba_pmc.json")))["kernels"]
+        ks = json.load(open(os.path.join(ROOT, "profiles", "r04_a_aba_pmc.json")))["kernels"]
         return {k.split("<")[0]: {"hbm_bytes": v.get("hbm_bytes"), "valu_per_wave": v.get("valu_per_wave")} for k, v in ks.items()}
     except (OSError, KeyError, ValueError):
         return None
@@ -82,10 +87,10 @@ def _aba_pmc():
 def aba_roofline(n=1 << 20, launches=30):
     """HBM roofline of the ABA launch on a FULL chip: bg_env_forward_dynamics (one substep's accelerations per launch) on n synthetic states, HIP
     events on the launch stream.  At the training size (4096 envs = 128 waves on 1024 SIMDs) no kernel can approach a bandwidth roof.
-    The launch is forward_dynamics_kernel (every env) + aba_compact_kernel + forward_dynamics_body_kernel (the envs whose legs can meet: the
-    leg-against-leg narrow phase) -- `achieved` prices the WHOLE launch.  Two state distributions:
-      `standing_noise_0.1` (the headline entry, the state of rounds 1 and 2): joints = default pose + N(0, 0.1 rad), trunk upright at 0.66 m.  The
-          0.1 rad of hip-roll noise crosses the legs of 8 % of the envs, which now go through the second kernel;
+    The launch is ONE kernel, forward_dynamics_kernel; the envs whose legs can meet get the leg-against-leg narrow phase inside it, item-parallel
+    through LDS (round 3: a second kernel).  Two state distributions:
+      `standing_noise_0.1` (the headline entry, the state of rounds 1 to 3): joints = default pose + N(0, 0.1 rad), trunk upright at 0.66 m.  The
+          0.1 rad of hip-roll noise brings the legs of 9 % of the envs close to each other (93 % of the 32-env waves have at least one);
       `survey_8d_state`: SURVEY section 8(d)'s K1 inputs (joints ~ U(limits), trunk at 0.72 m within 0.3 rad of upright, torques ~ U(+-effort))."""
     from booster_gym_amd.envs import T1
     from booster_gym_amd.utils.config import load_cfg
@@ -127,19 +132,21 @@ def aba_roofline(n=1 << 20, launches=30):
     gbs, gbs2 = n * ABA_BYTES / us / 1e3, n * ABA_BYTES / us2 / 1e3
     pmc = _aba_pmc()
     traffic = sum(v["hbm_bytes"] for v in pmc.values() if v.get("hbm_bytes")) if pmc else None
-    return {"kernel": "bg_env_forward_dynamics: forward_dynamics_kernel (hand-written HIP: one ABA substep with contact and limits, per-step joint accelerations) + "
-                      "aba_compact_kernel + forward_dynamics_body_kernel (leg-against-leg narrow phase for the envs whose legs can meet)",
+    return {"kernel": "bg_env_forward_dynamics = forward_dynamics_kernel (hand-written HIP, ONE launch: an ABA substep with sole contact, joint limits and the "
+                      "leg-against-leg narrow phase item-parallel through LDS; per-step joint accelerations)",
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/r03_a_aba_pmc.json (tools/profile_aba.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in separate passes "
+            "traffic_source": "profiles/r04_a_aba_pmc.json (tools/profile_aba.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in separate passes "
                               "of tools/aba_only.py, the same launch); FETCH_SIZE + WRITE_SIZE as reported: dword-per-lane accesses, whose width the guide "
                               "calls uncalibrated on gfx950, and inputs that stay in the 256 MB Infinity Cache between launches -- indicative only",
             "avg_launch_us": us, "num_envs": n, "algorithmic_bytes_per_launch": n * ABA_BYTES, "state": "standing_noise_0.1",
-            "kernels_per_launch_rocprof": "profiles/r03_a_aba_kernel_stats.csv: forward_dynamics_kernel 210.4 us (3,120 VALU per wave, was 3,331 in round 2), "
-                                          "forward_dynamics_body_kernel 78.6 us, aba_compact_kernel 3 us",
+            "kernels_per_launch_rocprof": "profiles/r04_a_aba_kernel_stats.csv: forward_dynamics_kernel 226-259 us over 12 launches from a cold start (the clock "
+                                          "settles after ~10 launches; avg_launch_us here is the settled rate), 3,460 VALU per wave; round 3: 210 us + a "
+                                          "second kernel of 79 us for the envs whose legs are close",
             "survey_8d_state": {"avg_launch_us": us2, "achieved": gbs2, "frac": gbs2 / HBM_PEAK_GBS,
                                 "state": "joints ~ U(limits), trunk at 0.72 m within 0.3 rad of upright, torques ~ U(+-effort), qd ~ N(0, 1)"},
             "note": "VALU-issue bound (SQ counters in the PMC file: the SIMDs issue VALU 100 % of the wave cycles of forward_dynamics_kernel at 4 cycles per "
-                    "instruction); itemised instruction budget: tools/isa_census.py, DESIGN.md section 6"}
+                    "instruction, at the ~2.15 GHz the part sustains under this load); itemised instruction budget: tools/isa_census.py, "
+                    "profiles/r04_aba_isa_census_plane_t1.json, DESIGN.md section 6"}
 
 
 def cpu_baseline(n_envs=4096):
@@ -254,13 +261,12 @@ def main():
         step_events.append((e0, e1))
 
     runner.env.step_to = timed_step_to
-    # critic layer 1 (256 -> 256): the single largest kernel of the update; critic layer 2 (256 -> 128): the symbol with the largest TOTAL time
-    # (mlp_fwd_kernel<256,1,1>, shared with the actor's layer 1)
+    # HIP events (on the launch stream) around both networks' chained forward launches and around the grouped weight-gradient launch pair
     runner._critic_tr.timed_layer = (1, 2)
-    runner._actor_tr.timed_layer = (1, 2)  # (with the chained forward kernel: the two networks' launches overlap; their union is reported too)
-    runner._wgrad_group.timed_events = []  # the grouped weight-gradient launch: the kernel with the largest total time of the iteration
-    if world > 1:
-        runner.dp.timed_events = []  # HIP events around the gradient-bucket all-reduce of every mini-epoch
+    runner._actor_tr.timed_layer = (1, 2)
+    runner._wgrad_group.timed_events = []
+    if runner.dp.active:  # ... and around every exchange of the collective path (also in a world of one rank, BG_DIST_FORCE=1)
+        runner.dp.timed_events = {"moments": [], "bucket": [], "stats": []}
     barrier()
     t0 = time.perf_counter()
     orig_rollout, orig_update = runner.rollout, runner.update
@@ -291,127 +297,85 @@ def main():
         step_ms = sum(a.elapsed_time(b) for a, b in step_events) / max(len(step_events), 1)
         roll_ms = sum(a.elapsed_time(b) for a, b, _ in phase_events) / len(phase_events)
         upd_ms = sum(b.elapsed_time(c) for _, b, c in phase_events) / len(phase_events)
-        # gradient-bucket all-reduce (712 kB, SURVEY 8e exchange 2), per mini-epoch, rank 0's view: collective + waiting for the slowest rank
-        ar = runner.dp.timed_events or []
-        ar_ms = sum(a.elapsed_time(b) for a, b in ar) / len(ar) if ar else 0.0
+        # exchanges of the collective path per mini-epoch, rank 0's view: collective + waiting for the slowest rank (advantage moments,
+        # the 712 kB gradient bucket, loss / KL sums)
+        ex = runner.dp.timed_events or {}
+        ex_ms = {k: (sum(a.elapsed_time(b) for a, b in v) / len(v) if v else 0.0) for k, v in ex.items()}
+        ar_ms = ex_ms.get("bucket", 0.0)
         env_bytes = N * ENV_STEP_BYTES
         sim_gbs = env_bytes / (step_ms * 1e-3) / 1e9
         flops = gemm_flops_per_iteration(N, T, E)
-        # dominant kernel by GPU time (rocprof, profiles/): the hand-written fused Linear+ELU layer mlp_fwd_kernel<256,1>; its largest instance
-        # (critic 256 -> 256, [rows x 256] x [256 x 256]) is timed inside the timed region with HIP events on the stream it is launched on
-        ev_all = runner._critic_tr.timed_events
-        ev = [e for e in ev_all if e[5] == 1]
-        ev2 = [e for e in ev_all if e[5] == 2]
-        evc = [e for e in ev_all if e[5] == "chain"]
-        top_by_time = None
-        if ev2:
-            us2 = sum(a.elapsed_time(b) for a, b, *_ in ev2) / len(ev2) * 1e3
-            r2_, k2_, n2_ = ev2[0][2], ev2[0][3], ev2[0][4]
-            fl2 = 2.0 * r2_ * k2_ * n2_
-            top_by_time = {"kernel": f"mlp_fwd_kernel<256,1,1>: fused Linear+bias+ELU, critic layer 3, [{r2_}x{k2_}]x[{k2_}x{n2_}] (the symbol with the largest total "
-                                     "time in the rocprofv3 summary: the actor's layer 2 runs on it too)", "bound": "mfma", "achieved": fl2 / (us2 * 1e-6) / 1e12,
-                           "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl2 / (us2 * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "avg_launch_us": us2,
-                           "algorithmic_flops_per_launch": fl2, "traffic": pmc_traffic("mlp_fwd_kernel<256, 1, 1>")}
-        if evc:
-            # the critic's three hidden layers are ONE launch (bg_mlp_chain.hip): timed as a whole, in the loop and alone on the GPU
-            gemm_us = sum(a.elapsed_time(b) for a, b, *_ in evc) / len(evc) * 1e3
-            rows_g, kg, widths = evc[0][2], evc[0][3], evc[0][4]
-            gemm_flop = 2.0 * rows_g * (kg * widths[0] + widths[0] * widths[1] + widths[1] * widths[2])
-            gemm_name = (f"mlp_chain_fwd_kernel<2>: the critic's three fused Linear+bias+ELU layers in one launch, [{rows_g}x{kg}] -> {widths[0]} -> {widths[1]} -> "
-                         f"{widths[2]}, activations handed on in registers, fp32 MFMA 32x32x2 (hand-written HIP, bg_mlp_chain.hip)")
-            tr = runner._critic_tr
-            d = tr._chain_descriptor()
-            lib = _lib.load()
-            solo = lambda: _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, _lib.current_stream_ptr()), "bg_mlp_chain_forward_group")
-            torch.cuda.synchronize()
-            solo_us = float("nan")
-            if not args.no_extra:
-                for _ in range(3):
-                    solo()
-                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                g0.record()
-                for _ in range(30):
-                    solo()
-                g1.record(); torch.cuda.synchronize()
-                solo_us = g0.elapsed_time(g1) / 30 * 1e3
-            # the actor's chained launch runs beside the critic's on the other stream: flops of both over the span from the first start to the last end
-            eva = [e for e in runner._actor_tr.timed_events if e[5] == "chain"]
-            mini = cfg["runner"]["mini_epochs"]
-            both = None
-            if len(eva) == len(evc) // mini * (mini + 1):  # per iteration: the old-mu forward, then one launch per mini-epoch
-                spans = []
-                for i, (c0, c1, *_) in enumerate(evc):
-                    a0, a1 = eva[i // mini * (mini + 1) + 1 + i % mini][:2]
-                    first = a0 if a0.elapsed_time(c0) >= 0 else c0
-                    last = c1 if a1.elapsed_time(c1) >= 0 else a1
-                    spans.append(first.elapsed_time(last))
-                span_us = sum(spans) / len(spans) * 1e3
-                ra, ka, wa = eva[0][2], eva[0][3], eva[0][4]
-                fl_both = gemm_flop + 2.0 * ra * (ka * wa[0] + wa[0] * wa[1] + wa[1] * wa[2])
-                both = {"what": "the critic's and the actor's chained forward launches of a mini-epoch together (they overlap on two streams): flops of both / time from "
-                                "the first start to the last end", "avg_span_us": span_us, "algorithmic_flops": fl_both,
-                        "achieved": fl_both / (span_us * 1e-6) / 1e12, "frac": fl_both / (span_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}
-        elif ev:
-            gemm_us = sum(a.elapsed_time(b) for a, b, *_ in ev) / len(ev) * 1e3
-            rows_g, kg, ng = ev[0][2], ev[0][3], ev[0][4]
-            gemm_name = f"mlp_fwd_kernel<256,1,2>: fused Linear+bias+ELU, critic layer 2, [{rows_g}x{kg}]x[{kg}x{ng}] fp32 MFMA 32x32x2 (hand-written HIP, bg_mlp.hip)"
-            # the same launch with nothing else on the GPU (in the loop the actor's kernels run beside it on the second stream)
-            tr = runner._critic_tr
-            xg, lg, og = tr.acts[0], tr.layers[1], tr.acts[1]
-            lib = _lib.load()
-            solo = lambda: _lib.check(lib.bg_mlp_layer_forward(rows_g, kg, ng, _lib.ptr(xg), _lib.ptr(lg.weight), _lib.ptr(lg.bias), _lib.ptr(og), 1,
-                                                               _lib.current_stream_ptr()), "bg_mlp_layer_forward")
-            torch.cuda.synchronize()
-            solo_us = float("nan")
-            if not args.no_extra:
-                for _ in range(3):
-                    solo()
-                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                g0.record()
-                for _ in range(30):
-                    solo()
-                g1.record(); torch.cuda.synchronize()
-                solo_us = g0.elapsed_time(g1) / 30 * 1e3
-        else:  # BG_FUSED_MLP=0: the library GEMM of the same layer
-            tr = runner._critic_tr
-            xg, lg, og = tr.acts[0], tr.layers[1], torch.empty_like(tr.acts[1])
-            with torch.no_grad():
-                for _ in range(5):
-                    torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
-                g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                g0.record()
-                for _ in range(50):
-                    torch.addmm(lg.bias, xg, lg.weight.t(), out=og)
-                g1.record(); torch.cuda.synchronize()
-            gemm_us = g0.elapsed_time(g1) / 50 * 1e3
-            rows_g, kg, ng = xg.shape[0], lg.weight.shape[1], lg.weight.shape[0]
-            gemm_name = f"critic layer-2 forward GEMM [{rows_g}x{kg}]x[{kg}x{ng}] fp32 (hipBLASLt via torch.addmm)"
-            solo_us = gemm_us
-        if not evc:
-            gemm_flop = 2.0 * rows_g * kg * ng
-        gemm_tf = gemm_flop / (gemm_us * 1e-6) / 1e12
-        layer_fwd = {"kernel": gemm_name, "bound": "mfma", "achieved": gemm_tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": gemm_tf / MFMA_F32_PEAK_TF,
-                     "traffic": pmc_traffic("mlp_chain_fwd_kernel<2>" if evc else "mlp_fwd_kernel<256, 1, 2>") if rows_g == (T + 1) * 4096 else None,
-                     "traffic_source": PMC_SOURCE,
-                     "avg_launch_us": gemm_us, "algorithmic_flops_per_launch": gemm_flop,
-                     "note": "timed inside the loop, where the actor's kernels run beside it on the second stream",
-                     "alone_on_the_gpu": {"avg_launch_us": solo_us, "achieved": gemm_flop / (solo_us * 1e-6) / 1e12,
-                                          "frac": gemm_flop / (solo_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}}
-        if evc and both is not None:
-            layer_fwd["both_networks_forward"] = both
-        if args.no_extra:
-            layer_fwd.pop("alone_on_the_gpu", None)
+
+        def chain_flop(tr, rows):
+            """algorithmic flops of a network's chained forward launch: the REAL input columns (47 / 61 of the zero-padded 64)"""
+            w = [l.weight.shape for l in tr.layers[:3]]
+            return 2.0 * rows * sum(o * i for o, i in w)
+
+        def solo_us(fn, reps=30):
+            for _ in range(3):
+                fn()
+            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            g0.record()
+            for _ in range(reps):
+                fn()
+            g1.record(); torch.cuda.synchronize()
+            return g0.elapsed_time(g1) / reps * 1e3
+
+        lib = _lib.load()
+        evc = [e for e in runner._critic_tr.timed_events if e[5] == "chain"]
+        eva = [e for e in runner._actor_tr.timed_events if e[5] == "chain"]
+        if not (evc and len(evc) == len(eva)):
+            raise SystemExit("bench.py expects the chained forward kernels (the default path) on both networks")
+        # The symbols with the largest total time of the iteration (profiles/<PMC_TAG>_bench_kernel_stats.csv) are the two networks' chained forward
+        # launches.  They run side by side on two streams and share the machine by slabs, so neither launch's own duration prices its work:
+        # the figure is the flops of both over the time from the first start to the last end of each mini-epoch's pair.
+        spans, c_us, a_us = [], [], []
+        for (c0, c1, *_), (a0, a1, *_) in zip(evc, eva):
+            first = a0 if a0.elapsed_time(c0) >= 0 else c0
+            last = c1 if a1.elapsed_time(c1) >= 0 else a1
+            spans.append(first.elapsed_time(last)); c_us.append(c0.elapsed_time(c1)); a_us.append(a0.elapsed_time(a1))
+        span_us, c_loop_us, a_loop_us = (sum(v) / len(v) * 1e3 for v in (spans, c_us, a_us))
+        rows_c, rows_a = evc[0][2], eva[0][2]
+        fl_c, fl_a = chain_flop(runner._critic_tr, rows_c), chain_flop(runner._actor_tr, rows_a)
+        full = rows_c == (T + 1) * 4096
+        tr_c = (pmc_traffic("mlp_chain_fwd_kernel<2>"), pmc_traffic("mlp_chain_fwd_kernel<1>")) if full else (None, None)
+        tf = (fl_c + fl_a) / (span_us * 1e-6) / 1e12
+        headline = {"kernel": f"mlp_chain_fwd_kernel<2> + mlp_chain_fwd_kernel<1>: the critic's and the actor's three fused Linear+bias+ELU hidden layers, one launch per "
+                              f"network ([{rows_c}x61] -> 256 -> 256 -> 128 and [{rows_a}x47] -> 256 -> 128 -> 128, activations handed on in registers, fp32 MFMA 32x32x2, "
+                              "hand-written HIP, bg_mlp_chain.hip); the two launches of a mini-epoch overlap on two streams",
+                    "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+                    "traffic": (tr_c[0] + tr_c[1]) if all(tr_c) else None, "traffic_source": PMC_SOURCE,
+                    "avg_launch_us": span_us, "algorithmic_flops_per_launch": fl_c + fl_a,
+                    "note": "flops of both launches (real input columns) / time from the first start to the last end of the pair, HIP events on the two launch "
+                            "streams inside the timed loop; the pair's own durations are in per_kernel_in_the_loop",
+                    "per_kernel_in_the_loop": {"mlp_chain_fwd_kernel<2>": {"avg_launch_us": c_loop_us, "algorithmic_flops": fl_c, "traffic": tr_c[0]},
+                                               "mlp_chain_fwd_kernel<1>": {"avg_launch_us": a_loop_us, "algorithmic_flops": fl_a, "traffic": tr_c[1]}}}
+        layer_fwd = {"kernel": f"mlp_chain_fwd_kernel<2>: the critic's chained forward launch, [{rows_c}x61] -> 256 -> 256 -> 128", "bound": "mfma",
+                     "achieved": fl_c / (c_loop_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl_c / (c_loop_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+                     "traffic": tr_c[0], "traffic_source": PMC_SOURCE, "avg_launch_us": c_loop_us, "algorithmic_flops_per_launch": fl_c,
+                     "note": "timed inside the loop, where the actor's launch runs beside it on the second stream"}
+        if not args.no_extra:
+            # the same launches with nothing beside them (hidden layers only: the critic's value head is left out of the stand-alone launch)
+            alone = {}
+            for name, tr, fl in (("mlp_chain_fwd_kernel<2>", runner._critic_tr, fl_c), ("mlp_chain_fwd_kernel<1>", runner._actor_tr, fl_a)):
+                keep, tr.value_head = tr.value_head, None
+                d = tr._chain_descriptor()
+                tr.value_head = keep
+                us = solo_us(lambda: _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, _lib.current_stream_ptr()), "bg_mlp_chain_forward_group"))
+                alone[name] = {"avg_launch_us": us, "achieved": fl / (us * 1e-6) / 1e12, "frac": fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}
+            headline["alone_on_the_gpu"] = alone
+            layer_fwd["alone_on_the_gpu"] = alone["mlp_chain_fwd_kernel<2>"]
         wg_ev = runner._wgrad_group.timed_events or []
-        headline = layer_fwd
-        if wg_ev:  # the dominant kernel of the iteration by total time (profiles/r02_bench_kernel_stats.csv): all six hidden-layer weight gradients
+        wgrad = None
+        if wg_ev:  # all six hidden-layer weight gradients of both networks: one launch pair per mini-epoch, alone on the GPU
             wus = sum(a.elapsed_time(b) for a, b, *_ in wg_ev) / len(wg_ev) * 1e3
             wfl = wg_ev[0][2]
-            headline = {"kernel": "mlp_wgrad_group_kernel (+ its fixed-order finish): dW = G^T A of all six hidden layers of both networks in one launch pair, " +
-                                  " + ".join(f"[{co}x{m}]x[{m}x{ci}]" for m, co, ci in wg_ev[0][3]) + ", fp32 MFMA 32x32x2 (hand-written HIP, bg_wgrad.hip)",
-                        "bound": "mfma", "achieved": wfl / (wus * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": wfl / (wus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("mlp_wgrad_group_kernel") if N == 4096 else None,
-                        "traffic_source": PMC_SOURCE, "avg_launch_us": wus, "algorithmic_flops_per_launch": wfl,
-                        "note": "launch pair (main kernel + finish) timed inside the loop with HIP events on its stream; it runs after both backward chains, alone on the GPU"}
+            wgrad = {"kernel": "mlp_wgrad_group_kernel (+ its fixed-order finish): dW = G^T A of all six hidden layers of both networks in one launch pair, " +
+                               " + ".join(f"[{co}x{m}]x[{m}x{ci}]" for m, co, ci in wg_ev[0][3]) + ", fp32 MFMA 32x32x2 (hand-written HIP, bg_wgrad.hip)",
+                     "bound": "mfma", "achieved": wfl / (wus * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
+                     "frac": wfl / (wus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("mlp_wgrad_group_kernel") if N == 4096 else None,
+                     "traffic_source": PMC_SOURCE, "avg_launch_us": wus, "algorithmic_flops_per_launch": wfl,
+                     "note": "launch pair (main kernel + finish) timed inside the loop with HIP events on its stream; it runs after both backward chains, alone on the GPU"}
         # HBM traffic per launch comes from PMC counters, which rocprofv3 collects in separate passes of the same command (tools/profile.sh
         # -> profiles/<PMC_TAG>_*_pmc.json, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes); the JSON line names the file it cites
         traffic = pmc_traffic("env_step_kernel", which="env") if N == 4096 else None
@@ -426,6 +390,7 @@ def main():
                                            6: "fp32 operands as exact 3-way bf16 splits, 6 largest products, fp32 accumulate (BG_GEMM_SPLIT=6)"}[split_mode]},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms, "all_reduce_ms": ar_ms},
+            "exchange_ms_per_mini_epoch": ex_ms or None,
             "roofline": headline,
             "roofline_layer_forward": layer_fwd,
             "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",
@@ -437,8 +402,8 @@ def main():
                                 "note": "all actor+critic GEMM flops of the update phase / update-phase wall time (which also holds GAE, loss, ELU, Adam)"},
             "nonfinite_resets": runner.nonfinite_resets_total,
         }
-        if top_by_time is not None:
-            out["roofline_top_by_time"] = top_by_time
+        if wgrad is not None:
+            out["roofline_wgrad"] = wgrad
         if world == 1 and not args.no_extra:
             try:
                 # Opt-in form of the layer kernels, measured beside the headline and NOT part of `value`: BG_GEMM_SPLIT (bg_mlp_split.hip) runs the
@@ -469,6 +434,35 @@ def main():
                 out["opt_in_split_bf16_layers"] = split
             except Exception as ex:
                 out["opt_in_split_bf16_layers"] = {"error": repr(ex)}
+            try:
+                # The other single-GPU configurations of BASELINE.json, the same loop (Runner.train_iteration) timed the same way after the headline;
+                # not part of `value`.  configs[2]: the shipped rough terrain with the command curriculum on; configs[4]: full randomisation,
+                # 16,384 envs, simulator state stored in fp16.
+                others = {}
+                for key, over, what in (
+                        ("configs[2]", {"env.num_envs": 4096, "terrain.type": "trimesh", "commands.curriculum": True},
+                         "T1 heightfield terrain (utils/terrain.py) with the command curriculum, 4096 envs"),
+                        ("configs[4]", {"env.num_envs": 16384, "terrain.type": "trimesh", "sim.state_dtype": "fp16"},
+                         "T1 full domain randomisation (mass / friction / latency / push), 16384 envs per GPU, fp16 state")):
+                    c2 = load_cfg("T1", dict({"basic.seed": 42}, **over))
+                    c2["runner"]["save_interval"] = 10 ** 9
+                    r2 = Runner(cfg=c2)
+                    r2.begin_training(Recorder(c2, root=log_root, rank=rank))
+                    for w in range(args.warmup):
+                        r2.train_iteration(w)
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for k in range(args.steps):
+                        r2.train_iteration(args.warmup + k)
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - ts
+                    r2._flush_log()
+                    others[key] = {"workload": what, "value": r2.env.num_envs * T * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3,
+                                   "ppo_iters_per_s": args.steps / dt, "steps": args.steps, "warmup": args.warmup, "nonfinite_resets": r2.nonfinite_resets_total}
+                    del r2
+                out["other_configs"] = others
+            except Exception as ex:
+                out["other_configs"] = {"error": repr(ex)}
             try:
                 del runner.env
                 out["roofline_aba"] = aba_roofline()

@@ -288,6 +288,17 @@ int bg_wgrad_group_finish_launch(const WgradGroup& grp, int fin, hipStream_t st)
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// the main kernel only: the fixed-order finish over the slices is left to bg_update_tail (bg_tail.hip), which runs it inside the mini-epoch's last launch
+extern "C" int bg_mlp_weight_grad_group_partial(const bg_wgrad_problem* problems, int32_t count, void* stream) {
+    WgradGroup grp;
+    int wg = 0, fin = 0;
+    const int rc = bg_wgrad_group_fill(problems, count, grp, wg, fin, "bg_mlp_weight_grad_group_partial");
+    if (rc) return rc;
+    hipLaunchKernelGGL(mlp_wgrad_group_kernel, dim3(wg), dim3(256), 0, (hipStream_t)stream, grp);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
 extern "C" int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream) {
     WgradGroup grp;
     int wg = 0, fin = 0;

@@ -61,10 +61,13 @@ class GroupedWeightGrad:
         self._key, self._arr, self._scratch = None, None, None
         self.timed_events = None
 
-    def run(self, trainers):
+    def run(self, trainers, finish=True):
+        """finish = False: the main kernel only (bg_mlp_weight_grad_group_partial); returns (descriptor array, count) for bg_update_tail, which sums the
+        slices inside the mini-epoch's last launch -- or None where that form does not apply (split mode, no supported layer) and the finished
+        gradients have been written as usual."""
         probs = [p for tr in trainers for p in tr.pending_wgrad_problems()]
         if not probs:
-            return
+            return None
         key = (MLPTrainer.SPLIT,) + tuple((g.data_ptr(), a.data_ptr(), dw.data_ptr(), g.shape[0], co, ci, cr) for g, a, dw, co, ci, cr in probs)
         if key != self._key:  # buffers are static: built once
             rows = probs[0][0].shape[0]
@@ -81,14 +84,18 @@ class GroupedWeightGrad:
         if ev is not None:  # bench.py: HIP events on the launch stream around the launch pair
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
+        partial = not finish and not self.split
         if self.split:
             _lib.check(_lib.load().bg_mlp_weight_grad_group_split(self._arr, len(probs), self.split, _lib.current_stream_ptr()), "bg_mlp_weight_grad_group_split")
+        elif partial:
+            _lib.check(_lib.load().bg_mlp_weight_grad_group_partial(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group_partial")
         else:
             _lib.check(_lib.load().bg_mlp_weight_grad_group(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group")
         if ev is not None:
             e1.record()
             # algorithmic flops: the REAL input columns (47 / 61 of the zero-padded 64 of the first layers)
             ev.append((e0, e1, sum(2.0 * g.shape[0] * co * cr for g, _, _, co, _, cr in probs), [(g.shape[0], co, cr) for g, _, _, co, _, cr in probs]))
+        return (self._arr, len(probs)) if partial else None
 
 
 class MLPTrainer:

@@ -24,6 +24,7 @@ class DataParallel:
         self.backend = os.environ.get("BG_DIST_BACKEND", backend or "nccl")
         self.owns_group = False
         self.force = os.environ.get("BG_DIST_FORCE", "0") == "1"
+        # bench.py: {"moments": [], "bucket": [], "stats": []} -- every exchange of that kind is then bracketed by HIP events on the stream it is issued on
         self.timed_events = None
         # device of this rank: LOCAL_RANK, unless the launcher already narrowed the visible devices to one per process
         # (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES), or a test shares one GPU between ranks (BG_LOCAL_DEVICE)
@@ -34,6 +35,21 @@ class DataParallel:
                 torch.cuda.set_device(self.device_index)
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
+            if self.backend == "nccl":
+                # The process group's streams beside this build's two need more than ROCm's default of 4 hardware queues per process (50 % of the update's
+                # speed).  booster_gym_amd/__init__.py sets GPU_MAX_HW_QUEUES=8 at import for processes that will join a group; the
+                # variable is read when the HIP runtime starts, so say so if that could not have worked.
+                import warnings
+
+                import booster_gym_amd
+
+                q = os.environ.get("GPU_MAX_HW_QUEUES")
+                if booster_gym_amd.HW_QUEUES_SET_TOO_LATE:
+                    warnings.warn("GPU_MAX_HW_QUEUES=8 was set after this process had started the HIP runtime and has no effect; import booster_gym_amd (or "
+                                  "export the variable) before the first CUDA call")
+                elif q is None or (int(q) < 8 and int(q) != 2):
+                    warnings.warn(f"GPU_MAX_HW_QUEUES={q!r}: with RCCL's streams beside the update's two, fewer than 8 hardware queues per process cost up to "
+                                  "50 % of the update phase on MI355X; export GPU_MAX_HW_QUEUES=8 before the process starts")
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size)
             self.owns_group = True
 
@@ -41,28 +57,36 @@ class DataParallel:
     def active(self):
         return self.world_size > 1 or self.force
 
-    def sum_(self, t):
-        """In-place SUM all-reduce (no-op for a single process)."""
+    def _timed(self, tag, t):
+        ev = self.timed_events
+        if ev is None or tag not in ev or not t.is_cuda:
+            return None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        ev[tag].append((e0, e1))
+        return e1
+
+    def sum_(self, t, tag=None):
+        """In-place SUM all-reduce (no-op for a single process).  tag: which exchange this is, for bench.py's per-exchange timing."""
         if self.active:
+            e1 = self._timed(tag, t)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if e1 is not None:
+                e1.record()
         return t
 
     def average_(self, t):
-        """In-place mean over ranks: the flat gradient bucket.  With `timed_events` set to a list (bench.py) every call is bracketed by
-        events on the current stream: the span is the collective plus the wait for the slowest rank to arrive."""
+        """In-place mean over ranks: the flat gradient bucket.  With `timed_events` armed (bench.py) every call is bracketed by events on the
+        current stream: the span is the collective plus the wait for the slowest rank to arrive."""
         if self.active:
-            ev = self.timed_events
-            if ev is not None and t.is_cuda:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
+            e1 = self._timed("bucket", t)
             if self.backend == "nccl":  # RCCL averages inside the collective: no second launch on the critical path of every mini-epoch
                 dist.all_reduce(t, op=dist.ReduceOp.AVG)
             else:                       # gloo has no AVG
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 t.mul_(1.0 / self.world_size)
-            if ev is not None and t.is_cuda:
+            if e1 is not None:
                 e1.record()
-                ev.append((e0, e1))
         return t
 
     def sync_grid(self, cur, last):

@@ -88,6 +88,24 @@ class FlatAdam:
                                                  0 if mirrors is None else len(mirrors), _lib.current_stream_ptr()),
                    "bg_optimizer_step")
 
+    def step_tail(self, wgrad, reductions, stats, stats_acc, stats_last, kl_index, count, desired_kl, grad_logstd=None, ls_off=0, lr_min=1e-5, lr_max=1e-2,
+                  mirrors=None):
+        """`step_fused` together with the sums in front of it (bg_update_tail: two launches for four): wgrad = (descriptor array, count) of a weight-gradient
+        launch made without its finish (GroupedWeightGrad.run(..., finish=False)) or None, reductions = the deferred _lib.ReduceProblem descriptors."""
+        self.step_count += 1
+        if not hasattr(self, "_tail_sync"):
+            self._tail_sync = torch.zeros(4, dtype=torch.int32, device=self.flat.device)
+            self._tail_norm = torch.zeros(8192, dtype=torch.float64, device=self.flat.device)
+        warr, wn = wgrad if wgrad is not None else (None, 0)
+        rarr = (_lib.ReduceProblem * len(reductions))(*reductions) if reductions else None
+        _lib.check(_lib.load().bg_update_tail(warr, wn, rarr, len(reductions) if reductions else 0, self.flat.numel(), _lib.ptr(self.flat), _lib.ptr(self.grad),
+                                              _lib.ptr(self.exp_avg), _lib.ptr(self.exp_avg_sq), _lib.ptr(self.lr), self.step_count, self.betas[0], self.betas[1],
+                                              self.eps, self.max_grad_norm, _lib.ptr(grad_logstd), int(ls_off), 0 if grad_logstd is None else grad_logstd.numel(),
+                                              _lib.ptr(stats), _lib.ptr(stats_acc), _lib.ptr(stats_last), stats.numel(), int(kl_index), float(count), desired_kl,
+                                              lr_min, lr_max, _lib.ptr(self._tail_sync), _lib.ptr(self._tail_norm),
+                                              None if mirrors is None else ctypes.addressof(mirrors), 0 if mirrors is None else len(mirrors),
+                                              _lib.current_stream_ptr()), "bg_update_tail")
+
     def adapt_lr(self, kl_sum, count, desired_kl, lr_min=1e-5, lr_max=1e-2):
         _lib.check(_lib.load().bg_adapt_lr(_lib.ptr(kl_sum), float(count), desired_kl, lr_min, lr_max, _lib.ptr(self.lr), _lib.current_stream_ptr()),
                    "bg_adapt_lr")
@@ -172,6 +190,10 @@ class Runner:
         # False: the mini-epoch tail as separate launches (bg_adam_step, bg_adapt_lr, torch adds / fills): what the first optimiser step after a
         # checkpoint restore runs (see update()); as an attribute for the tests that compare the two forms
         self._fused_opt = True
+        # ... and, single process only, the sums in front of it (weight-gradient finish, deferred reductions) as ONE launch that also leaves the squared
+        # gradient norm in pieces, so that the optimiser launch need not read the whole gradient in every workgroup (bg_update_tail); False:
+        # reduce_group, weight gradients + finish, optimizer_step as separate launches (what the ranks of a multi-GPU job run: the norm is the averaged gradient's)
+        self._one_launch_tail = os.environ.get("BG_ONE_LAUNCH_TAIL", "1") == "1"
         self._old_logp = torch.zeros(B, device=dev)
         self._logstd_grad_view = self.model.logstd.grad.view(-1)
         self._logstd_off = (self._logstd_grad_view.data_ptr() - self.optimizer.grad.data_ptr()) // 4  # position of logstd in the flat buffers
@@ -418,7 +440,7 @@ class Runner:
                     if not (fused_head and self._fused_gae):
                         gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
                             advantages=self._adv, returns=self._ret, sums=self._adv_sums)
-                    self.dp.sum_(self._adv_sums)  # exchange (1), on the side stream: hidden under the actor forward
+                    self.dp.sum_(self._adv_sums, tag="moments")  # exchange (1), on the side stream: hidden under the actor forward
                     gae_done = side.record_event()
                 if fused_head:
                     # Output layers fused with the loss (bg_head.hip): per network ONE pass over the [B][128] hidden activations gives the
@@ -442,7 +464,7 @@ class Runner:
                     if self.dp.active and not defer:
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
-                            self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
+                            self.dp.sum_(self._stats, tag="stats")  # exchange (3): loss / KL sums, hidden under the backward passes
                     self._actor_tr.backward_hidden(finishes=fins)
                 else:
                     defer = False
@@ -453,32 +475,39 @@ class Runner:
                                    self._grad_logstd, self._stats)
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        self.dp.sum_(self._stats)  # exchange (3): loss / KL sums, hidden under the backward passes
+                        self.dp.sum_(self._stats, tag="stats")  # exchange (3): loss / KL sums, hidden under the backward passes
                         self._critic_tr.backward(self._grad_val.view(B, 1))
                     self._actor_tr.backward(self._grad_mu)
                 fused_tail = self._fused_opt and not self._lr_restart
+                # the sums of the tail as one launch behind the main weight-gradient kernel + a lean optimiser launch (single process, see __init__)
+                # (its norm is assembled from the sums' own pieces: every gradient element must come out of that launch -- all hidden-layer weight
+                # gradients from the grouped kernel, everything else from the deferred reductions)
+                one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and not self.dp.active and len(fins) + 2 <= 8
+                            and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr)))
                 if (self.dp.active or not fused_tail) and not defer:
                     self._logstd_grad_view.copy_(self._grad_logstd)  # into the flat bucket before the all-reduce
                 main.wait_stream(side)
-                if defer and self._defer_serial:  # the deferred reductions as one launch in FRONT of the weight gradients (the default)
+                if one_tail:
+                    pass  # the deferred reductions run inside bg_update_tail
+                elif defer and self._defer_serial:  # the deferred reductions as one launch in FRONT of the weight gradients (the default)
                     reduce_group([fin_c, fin_a] + fins)
                     if self.dp.active or not fused_tail:
                         self._logstd_grad_view.copy_(self._grad_logstd)
                     if self.dp.active:
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
-                            self.dp.sum_(self._stats)  # exchange (3), beside the weight gradients
+                            self.dp.sum_(self._stats, tag="stats")  # exchange (3), beside the weight gradients
                 elif defer:  # BG_DEFER_FINISH=2: ... (+ what depends on them) on the side stream, beside the weight gradients on the main stream
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         reduce_group([fin_c, fin_a] + fins)
                         if self.dp.active:
-                            self.dp.sum_(self._stats)  # exchange (3)
+                            self.dp.sum_(self._stats, tag="stats")  # exchange (3)
                         if self.dp.active or not fused_tail:
                             self._logstd_grad_view.copy_(self._grad_logstd)
                 # all weight gradients after both backward chains, alone on the GPU: one launch pair for the six hidden layers (shapes outside the
                 # kernel's range, or MLPTrainer.FUSED_WGRAD = False: library GEMMs, layer by layer)
-                self._wgrad_group.run((self._critic_tr, self._actor_tr))
+                wg_partial = self._wgrad_group.run((self._critic_tr, self._actor_tr), finish=not one_tail)
                 if defer and (self.dp.active or not self._defer_serial):
                     main.wait_stream(side)
                 self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
@@ -489,8 +518,12 @@ class Runner:
                     if mirrors is None:
                         ms = self._critic_tr.mirror_descriptors(self.optimizer.flat) + self._actor_tr.mirror_descriptors(self.optimizer.flat)
                         mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 8 else None
-                    self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
-                                              grad_logstd=None if self.dp.active else self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
+                    if one_tail:
+                        self.optimizer.step_tail(wg_partial, [fin_c, fin_a] + fins, self._stats, self._stats_acc, self._stats_last, 4, B, alg["desired_kl"],
+                                                 grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
+                    else:
+                        self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
+                                                  grad_logstd=None if self.dp.active else self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
                     self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = mirrors is not None
                     if self.dp.active:
                         self._grad_logstd.zero_()

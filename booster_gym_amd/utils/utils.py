@@ -185,10 +185,10 @@ def critic_head_backward(h, weight, values, returns, g_hidden, grad_weight, grad
 
 def reduce_group(problems):
     """Run the deferred reductions of a list of _lib.ReduceProblem descriptors in one launch on the current stream (bg_reduce_group)."""
-    if not problems:
-        return
-    arr = (_lib.ReduceProblem * len(problems))(*problems)
-    _lib.check(_lib.load().bg_reduce_group(arr, len(problems), _lib.current_stream_ptr()), "bg_reduce_group")
+    for k in range(0, len(problems), 8):  # the launch takes up to 8 descriptors (networks with more hidden layers than the reference's: several launches)
+        part = problems[k : k + 8]
+        arr = (_lib.ReduceProblem * len(part))(*part)
+        _lib.check(_lib.load().bg_reduce_group(arr, len(part), _lib.current_stream_ptr()), "bg_reduce_group")
 
 
 def surrogate_loss(old_actions_log_prob, actions_log_prob, advantages, e_clip=0.2):

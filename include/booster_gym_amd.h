@@ -350,6 +350,8 @@ typedef struct {
                                   * this many tiles x 4 / this many sub-ranges of the slice's rows; waves on the same rows share the fetched rows */
 } bg_wgrad_problem;
 int bg_mlp_weight_grad_group(const bg_wgrad_problem* problems, int32_t count, void* stream);
+/* bg_mlp_weight_grad_group without its finishing launch: the per-slice partial tiles stay in the problems' scratch, to be summed by bg_update_tail. */
+int bg_mlp_weight_grad_group_partial(const bg_wgrad_problem* problems, int32_t count, void* stream);
 /* Split form of the grouped launch (opt-in, see bg_mlp_layer_forward_split): the same sums with every fp32 operand split exactly into three bf16
  * numbers on the bf16 matrix pipe, terms = 9 or 6.  The waves of a workgroup that work on the same rows share them through LDS, so here
  * tiles_per_workgroup must equal the layer's tile count (1, 2 or 4).  Shapes: 256 x 256, 128 x 256, 128 x 128, 256 x 64 (C_out x C_in padded), M a
@@ -402,6 +404,19 @@ typedef struct {
     uint64_t stat_base; int32_t n_stat, n_ls; uint32_t stat_skip; double entropy_coef; double* grad_logstd; double* stats;
 } bg_reduce_problem;
 int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stream); /* count <= 8 */
+/* The tail of a mini-epoch behind bg_mlp_weight_grad_group_partial (runner.py:162-180: the last sums of loss.backward(), clip_grad_norm_,
+ * optimizer.step(), the KL rule) as two launches: (1) the weight gradients' fixed-order finish over their slices (wgrad: the problems handed to the
+ * _partial launch; 0: none) and the deferred reductions (reduce: as bg_reduce_group; 0: none), every block also leaving the sum of the squares of the
+ * gradient values it wrote; (2) everything bg_optimizer_step does (same arguments), with the global norm taken from those sums instead of a pass over
+ * the whole gradient per workgroup.  REQUIRES that the two lists together produce every element of grads except the log-std slice (true for the
+ * reference's networks: hidden-layer weights from the weight gradients, all biases and the output layers from the reductions); elements they do not
+ * write must be zero.  Gradients: the same bits as the separate launches; the norm is summed in another (fixed) order.  sync: uint32 [1],
+ * zero-initialised once by the caller (the launch leaves it zero); norm_scratch: float64 [8192]. */
+int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, const bg_reduce_problem* reduce, int32_t n_reduce, int32_t n, float* params, float* grads,
+                   float* exp_avg, float* exp_avg_sq, float* lr_device, int32_t step, float beta1, float beta2, float eps, float max_grad_norm,
+                   double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats, double* stats_acc, double* stats_last, int32_t n_stats, int32_t kl_index,
+                   float kl_count, float desired_kl, float lr_min, float lr_max, uint32_t* sync, double* norm_scratch, const bg_param_mirror* mirrors,
+                   int32_t n_mirrors, void* stream);
 /* bg_actor_head mode 1 / bg_critic_head_backward / bg_mlp_layer_backward without their finishing launch: same arguments, plus the descriptor
  * of the reduction that produces grad_W, grad_b, grad_b_hidden, grad_logstd, stats / bias_grad_below when handed to bg_reduce_group. */
 int bg_actor_head_partial(int32_t B, const float* h, const float* W, const float* bias, const float* logstd, const float* actions,

@@ -319,6 +319,7 @@ def test_forward_passes_run_during_the_rollout_change_no_bit():
 SWITCHES = {
     # name: (runner attributes, MLPTrainer class attributes) -- every branch of Runner.update() / MLPTrainer that a switch or a shape can select
     "default": ({}, {}),
+    "tail_as_three_launches": ({"_one_launch_tail": False}, {}),                  # reduce_group, weight gradients + finish, optimizer_step (what ranks of a job run)
     "separate_optimizer_tail": ({"_fused_opt": False}, {}),                      # bg_adam_step + bg_adapt_lr + torch adds (first step after a restore)
     "gae_as_three_launches": ({"_fused_gae": False}, {}),                        # bg_critic_head_forward + fill + bg_gae (horizons beyond 32 steps)
     "values_from_stored_activations": ({"_chain_values": False}, {}),            # bg_critic_values_gae with its own output layer

@@ -69,6 +69,19 @@ def test_abi_argument_errors_without_gpu():
     one = (C.c_float * 16)()
     assert lib.bg_optimizer_step(16, one, one, one, one, one, 1, 0.9, 0.999, 1e-8, 1.0, None, 0, 0, None, None, None, 0, 0, 1.0, 0.01, 1e-5, 1e-2, one,
                                  C.addressof(m1), 1, None) < 0 and b"mirror" in lib.bg_last_error()
+    # round-4 entry points
+    assert lib.bg_mlp_weight_grad_group_partial(None, 1, None) < 0 and b"bg_mlp_weight_grad_group_partial" in lib.bg_last_error()
+    tail = lambda **kw: lib.bg_update_tail(kw.get("wg"), kw.get("nwg", 0), kw.get("rd"), kw.get("nrd", 0), 16, one, one, one, one, one, kw.get("step", 1), 0.9, 0.999,
+                                           1e-8, 1.0, None, 0, 0, None, None, None, 0, 0, 1.0, 0.01, 1e-5, 1e-2, kw.get("sync", one), one,
+                                           kw.get("mir"), kw.get("nmir", 0), None)
+    assert tail(sync=None) == -1 and b"bg_update_tail: bad argument" in lib.bg_last_error()
+    assert tail(step=0) == -1
+    assert tail(nrd=9) == -1 and b"at most 8 reductions" in lib.bg_last_error()
+    assert tail(mir=C.addressof(m1), nmir=1) == -1 and b"mirror" in lib.bg_last_error()
+    rp = _lib.ReduceProblem()  # an empty descriptor
+    assert tail(rd=(_lib.ReduceProblem * 1)(rp), nrd=1) == -1 and b"bad reduction descriptor" in lib.bg_last_error()
+    wp = (_lib.WgradProblem * 1)()  # an empty weight-gradient problem: refused by the shared descriptor check, under this entry's name
+    assert tail(wg=wp, nwg=1) < 0 and b"bg_update_tail" in lib.bg_last_error()
     if not torch.cuda.is_available():
         from booster_gym_amd.utils.urdf import FlatModel
 

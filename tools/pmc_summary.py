@@ -23,9 +23,20 @@ def summarise(passes, keep, command):
             for r in csv.DictReader(open(f)):
                 name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
                 if any(k in name for k in keep):
-                    acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
+                    acc[(name, int(r.get("Grid_Size", 0) or 0))][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    # a kernel launched with several grid sizes (the chained forward: whole-batch launches in the update, 64-slab launches during the rollout) is listed
+    # per grid size; the plain name stands for its LARGEST grid (what the bench's roofline entries cite)
+    grids = collections.defaultdict(list)
+    for name, g in acc:
+        grids[name].append(g)
+    named = {}
+    for (name, g), cs in acc.items():
+        if g == max(grids[name]):
+            named[name] = cs
+        if len(grids[name]) > 1:
+            named[f"{name} [grid={g}]"] = cs
     ks = {}
-    for k, cs in sorted(acc.items()):
+    for k, cs in sorted(named.items()):
         e = {c: {"mean": sum(v) / len(v), "launches": len(v)} for c, v in sorted(cs.items())}
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
             wide = any(s in k for s in ("mlp_fwd_kernel", "mlp_chain_fwd_kernel", "mlp_wgrad"))

@@ -1,9 +1,9 @@
 """One mini-epoch of the update phase out of a rocprofv3 --kernel-trace CSV: start / end / duration (us) and queue of every kernel between two
-consecutive optimizer_step_kernel launches (the last complete pair of the trace).  python tools/timeline.py <kernel_trace.csv>"""
+consecutive optimiser launches (tail_adam_kernel, or optimizer_step_kernel; the last complete pair of the trace).  python tools/timeline.py <kernel_trace.csv>"""
 import csv, re, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-idx = [i for i, r in enumerate(rows) if r["Kernel_Name"].startswith("optimizer_step")]
+idx = [i for i, r in enumerate(rows) if "tail_adam_kernel" in r["Kernel_Name"] or r["Kernel_Name"].startswith("optimizer_step")]
 a, b = idx[-3], idx[-2]
 t0 = int(rows[a]["Start_Timestamp"])
 def short(n):
