@@ -183,8 +183,10 @@ class Runner:
         self._adv_sums = torch.zeros(3, dtype=torch.float64, device=dev)
         self._grad_mu = torch.zeros(B, A, device=dev)
         self._grad_val = torch.zeros(B, device=dev)
-        self._grad_logstd = torch.zeros(A, dtype=torch.float64, device=dev)
-        self._stats = torch.zeros(5, dtype=torch.float64, device=dev)
+        # the float64 sums of a mini-epoch that every rank needs in full: loss / KL statistics [5] and the log-std gradient [A], contiguous so that ONE
+        # collective carries both (exchange (3); the log-std gradient then enters the optimiser launch in float64 and not through the fp32 bucket)
+        self._sums = torch.zeros(5 + A, dtype=torch.float64, device=dev)
+        self._stats, self._grad_logstd = self._sums[:5], self._sums[5:]
         self._stats_acc = torch.zeros(5, dtype=torch.float64, device=dev)
         self._stats_last = torch.zeros(5, dtype=torch.float64, device=dev)  # the last mini-epoch's sums (kl_mean of the log, runner.py:199)
         # False: the mini-epoch tail as separate launches (bg_adam_step, bg_adapt_lr, torch adds / fills): what the first optimiser step after a
@@ -464,7 +466,7 @@ class Runner:
                     if self.dp.active and not defer:
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
-                            self.dp.sum_(self._stats, tag="stats")  # exchange (3): loss / KL sums, hidden under the backward passes
+                            self._exchange_sums()  # exchange (3): loss / KL sums, hidden under the backward passes
                     self._actor_tr.backward_hidden(finishes=fins)
                 else:
                     defer = False
@@ -475,7 +477,7 @@ class Runner:
                                    self._grad_logstd, self._stats)
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
-                        self.dp.sum_(self._stats, tag="stats")  # exchange (3): loss / KL sums, hidden under the backward passes
+                        self._exchange_sums()  # exchange (3): loss / KL sums, hidden under the backward passes
                         self._critic_tr.backward(self._grad_val.view(B, 1))
                     self._actor_tr.backward(self._grad_mu)
                 fused_tail = self._fused_opt and not self._lr_restart
@@ -484,27 +486,21 @@ class Runner:
                 # gradients from the grouped kernel, everything else from the deferred reductions)
                 one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and not self.dp.active and len(fins) + 2 <= 8
                             and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr)))
-                if (self.dp.active or not fused_tail) and not defer:
-                    self._logstd_grad_view.copy_(self._grad_logstd)  # into the flat bucket before the all-reduce
                 main.wait_stream(side)
                 if one_tail:
                     pass  # the deferred reductions run inside bg_update_tail
                 elif defer and self._defer_serial:  # the deferred reductions as one launch in FRONT of the weight gradients (the default)
                     reduce_group([fin_c, fin_a] + fins)
-                    if self.dp.active or not fused_tail:
-                        self._logstd_grad_view.copy_(self._grad_logstd)
                     if self.dp.active:
                         side.wait_stream(main)
                         with torch.cuda.stream(side):
-                            self.dp.sum_(self._stats, tag="stats")  # exchange (3), beside the weight gradients
+                            self._exchange_sums()  # exchange (3), beside the weight gradients
                 elif defer:  # BG_DEFER_FINISH=2: ... (+ what depends on them) on the side stream, beside the weight gradients on the main stream
                     side.wait_stream(main)
                     with torch.cuda.stream(side):
                         reduce_group([fin_c, fin_a] + fins)
                         if self.dp.active:
-                            self.dp.sum_(self._stats, tag="stats")  # exchange (3)
-                        if self.dp.active or not fused_tail:
-                            self._logstd_grad_view.copy_(self._grad_logstd)
+                            self._exchange_sums()  # exchange (3)
                 # all weight gradients after both backward chains, alone on the GPU: one launch pair for the six hidden layers (shapes outside the
                 # kernel's range, or MLPTrainer.FUSED_WGRAD = False: library GEMMs, layer by layer)
                 wg_partial = self._wgrad_group.run((self._critic_tr, self._actor_tr), finish=not one_tail)
@@ -523,11 +519,10 @@ class Runner:
                                                  grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
                     else:
                         self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
-                                                  grad_logstd=None if self.dp.active else self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
+                                                  grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
                     self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = mirrors is not None
-                    if self.dp.active:
-                        self._grad_logstd.zero_()
                 else:
+                    self._logstd_grad_view.copy_(self._grad_logstd)  # (behind the bucket's all-reduce, which carries a stale value in this slot)
                     self.optimizer.step()
                     self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = False  # this launch does not write the weight copies: the next pass copies them
                     if self._lr_restart:  # first step after a checkpoint load: see __init__
@@ -539,6 +534,13 @@ class Runner:
                     self._stats.zero_()
                     self._grad_logstd.zero_()
         return self._stats_acc
+
+    def _exchange_sums(self):
+        """Exchange (3), on the current (side) stream: the loss / KL sums and the log-std gradient of all ranks in one float64 all-reduce; the gradient
+        is then the mean over ranks like the bucket's."""
+        self.dp.sum_(self._sums, tag="stats")
+        if self.world_size > 1:
+            self._grad_logstd.mul_(1.0 / self.world_size)
 
     def iteration(self):
         buf, T = self.buffer, self.cfg["runner"]["horizon_length"]
