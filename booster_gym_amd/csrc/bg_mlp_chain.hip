@@ -69,6 +69,11 @@ __device__ __forceinline__ void dma_rows(const float* __restrict__ W, int kc, fl
         // Scalar base + 32-bit lane offset: no 64-bit address registers per copy.
         const float* base = W + (size_t)q * 8 * K + kc * KC;
         const unsigned lds = (unsigned)(uintptr_t)(sWbuf + q * 256);
+        // M0 is written here.  It cannot be named as a clobber (the backend reserves M0: "inline asm clobber list contains reserved registers" and
+        // the entry is ignored); the backend never keeps a value of its own live in M0 across an inline asm -- it writes M0 immediately in front of each
+        // instruction of its own that reads it -- and nothing else in this kernel uses M0.
+        // Invariants the vmcnt bookkeeping (S::behind) rests on: every wave issues exactly N / 32 of these per chunk and every activation store
+        // of chain_slab unconditionally -- no copy and no store may sit under a lane- or wave-dependent branch.
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lane_ofs), "s"(base), "s"(lds) : "memory");
     }
 }

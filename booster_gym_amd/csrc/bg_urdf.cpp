@@ -373,7 +373,18 @@ extern "C" int bg_model_load_urdf(const char* path, const bg_asset_options* opt,
         }
         // self-collision capsules (create_actor(..., self_collisions), envs/t1.py:128): per leg the shank = the link two above the foot (the capsule
         // inscribed in its z-axis cylinder) and the foot (its box, L >= W >= H along x, y, z: radius W / 2, half length L / 2 - H about the box centre)
-        if (opt->self_collisions && foot[0] >= 0 && foot[1] >= 0) {
+        // An asset WITHOUT that geometry on either leg is loaded with all capsule radii 0 = "no self-collision geometry": bg_env_create then leaves the
+        // leg-against-leg contacts off (include/booster_gym_amd.h).  Geometry that is there but malformed (two cylinders, a rotated primitive, a box
+        // that is not longest along x) stays an error.
+        bool have_caps = opt->self_collisions && foot[0] >= 0 && foot[1] >= 0;
+        for (int leg = 0; leg < 2 && have_caps; leg++) {
+            const int fb = foot[leg], ank = d.parent[fb], shank = ank >= 0 ? d.parent[ank] : -1;
+            bool cyl = false, box = false;
+            if (shank >= 0) for (const Shape& s : body_link[shank]->shapes) cyl = cyl || s.type == 1;
+            for (const Shape& s : body_link[fb]->shapes) box = box || s.type == 0;
+            have_caps = shank >= 0 && cyl && box;
+        }
+        if (have_caps) {
             for (int leg = 0; leg < 2; leg++) {
                 const int fb = foot[leg], ank = d.parent[fb], shank = ank >= 0 ? d.parent[ank] : -1;
                 if (shank < 0) throw std::runtime_error("self-collision capsules: the foot needs a link two above it");

@@ -137,7 +137,13 @@ class FlatModel:
             cyl = [sh for sh in self.shapes if int(sh["body"]) == shank and sh["type"] == "cylinder"]
             box = [sh for sh in self.shapes if int(sh["body"]) == int(fb) and sh["type"] == "box"]
             if len(cyl) != 1 or len(box) != 1:
-                raise ValueError("self-collision capsules need one cylinder on each shank and one box on each foot (URDF <collision>)")
+                # an asset without that geometry: no self-collision (radius 0 = "no capsule" in bg_model_desc; bg_env_create then leaves the
+                # leg-against-leg contacts off), as the C ABI documents -- not an error
+                import warnings
+
+                warnings.warn("self-collision capsules need one cylinder on each shank and one box on each foot (URDF <collision>): none derived, "
+                              "leg-against-leg contacts are off for this asset")
+                return []
             (px, py, pz), (r, length) = (float(v) for v in cyl[0]["pos"]), (float(v) for v in cyl[0]["size"])
             h = max(0.5 * length - r, 0.0)
             caps = [(shank, (px, py, pz - h), (px, py, pz + h), r)]

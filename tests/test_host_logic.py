@@ -656,6 +656,35 @@ def test_c_urdf_loader_matches_the_python_loader(flat_model, tmp_path):
     assert rc == -1 and "nested deeper" in msg
 
 
+def test_asset_without_leg_collision_shapes_loads_with_self_collision_off(flat_model, tmp_path):
+    """An asset whose shanks carry no cylinder (no geometry to derive the leg-against-leg capsules from) is not an error: both loaders return it with
+    all capsule radii 0 = "no self-collision geometry" (include/booster_gym_amd.h: bg_env_create then leaves the leg contacts off); the Python
+    loader says so in a warning.  Malformed geometry that IS there stays an error (the foot box longest along y)."""
+    import re
+
+    from booster_gym_amd.utils.urdf import load_urdf
+
+    p = tmp_path / "t1_synth.urdf"
+    _synthetic_urdf(flat_model, p)
+    text = open(p).read()
+    bare = re.sub(r"\s*<collision>(?:(?!</collision>).)*<cylinder[^>]*/>(?:(?!</collision>).)*</collision>", "", text, flags=re.S)
+    assert bare.count("<cylinder") == 0 and bare.count("<box") == text.count("<box")
+    pb = tmp_path / "no_cylinders.urdf"; pb.write_text(bare)
+    rc, d, names, found = _load_urdf_c(pb)
+    assert rc == 0, d
+    assert all(d.self_capsule_r[leg][k] == 0.0 for leg in range(2) for k in range(2))
+    py = load_urdf(str(pb), collapse_fixed_joints=True)
+    with pytest.warns(UserWarning, match="leg-against-leg contacts are off"):
+        assert py.self_collision_capsules([py.find_body("left_foot_link"), py.find_body("right_foot_link")]) == []
+    wide = text.replace('<box size="0.223 0.1 0.03"/>', '<box size="0.1 0.223 0.03"/>')
+    assert wide != text
+    pw = tmp_path / "wide_foot.urdf"; pw.write_text(wide)
+    rc, msg, _, _ = _load_urdf_c(pw)
+    assert rc == -1 and "longest along x" in msg
+    with pytest.raises(ValueError, match="longest along x"):
+        load_urdf(str(pw)).self_collision_capsules([6, 12])
+
+
 def test_c_urdf_loader_on_the_reference_asset(flat_model):
     """The real T1 URDF (only where the reference tree is present: this container, not the GPU box): both loaders against the packaged flat model."""
     path = "/root/reference/resources/T1/T1_locomotion.urdf"
