@@ -657,6 +657,45 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
     V3 sr = v3(0.f, 0.f, 0.f);
     float sb = 0.f;
     bool any = false;
+    if (decltype(w.st)::ZSPEC && tr.type == 0) {
+        // Flat ground (wave-uniform; the throughput-bound ABA kernel only, like the z-axis link specialisation): the normal is the world's z axis for
+        // every corner, so nb is ONE vector (the third row of Rfoot), a corner's penetration needs its height only (one dot product instead of the
+        // world position), and the rank-1 terms that carry nb factor out of the sum over the corners: M += (sum alpha) nb nb^T, H += (sum alpha m) nb^T.
+        const V3 nb = v3(w.Rfoot.e[2][0], w.Rfoot.e[2][1], w.Rfoot.e[2][2]);
+        float sa = 0.f;
+        V3 sam = v3(0.f, 0.f, 0.f);
+        for (int k = 0; k < 4; k++) {
+            const V3 r = lp.corner[k];
+            const float pen = -(pfoot.e[2] + dot(nb, r));
+            const V3 vb = vfoot.l + cross(vfoot.a, r);
+            const float vn = dot(vb, nb);
+            const float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
+            const float d_eff = lp.dn * ramp;
+            const float fn0 = lp.kn * pen - d_eff * vn;
+            if (pen > 0.f && fn0 > 0.f) {
+                any = true;
+                const V3 vt = vb - vn * nb;
+                const float c_t = fminf(ph.friction_visc, lp.mu * fn0 * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
+                const V3 fb = fn0 * nb - c_t * vt;
+                const float beta = ph.dt * c_t, alpha = ph.dt * (d_eff + ph.dt * lp.kn) - beta;
+                f0.l = f0.l + fb;
+                f0.a = f0.a + cross(r, fb);
+                const V3 m = cross(r, nb), am = alpha * m, br = beta * r;
+                sa += alpha;
+                sam = sam + am;
+                BA.e[0] += am.e[0] * m.e[0]; BA.e[1] += am.e[1] * m.e[1]; BA.e[2] += am.e[2] * m.e[2];
+                BA.e[3] += am.e[0] * m.e[1]; BA.e[4] += am.e[0] * m.e[2]; BA.e[5] += am.e[1] * m.e[2];
+                P.e[0] += br.e[0] * r.e[0]; P.e[1] += br.e[1] * r.e[1]; P.e[2] += br.e[2] * r.e[2];
+                P.e[3] += br.e[0] * r.e[1]; P.e[4] += br.e[0] * r.e[2]; P.e[5] += br.e[1] * r.e[2];
+                sr = sr + br;
+                sb += beta;
+            }
+        }
+        const V3 an = sa * nb;
+        BM.e[0] = an.e[0] * nb.e[0]; BM.e[1] = an.e[1] * nb.e[1]; BM.e[2] = an.e[2] * nb.e[2];
+        BM.e[3] = an.e[0] * nb.e[1]; BM.e[4] = an.e[0] * nb.e[2]; BM.e[5] = an.e[1] * nb.e[2];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) BH.e[i][j] = sam.e[i] * nb.e[j];
+    } else
     for (int k = 0; k < 4; k++) {
         const V3 r = lp.corner[k];
         const V3 xw = pfoot + mul(w.Rfoot, r);

@@ -9,7 +9,8 @@ OUT=$R/gpurun_out/prof_${TAG}_aba
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 CMD="python3 $R/tools/aba_only.py 1048576 0.1"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD > $OUT.trace.log 2>&1
+# the trace run launches 1200 times: the kernel's sustained rate (the clock is a transient for the first ~160 launches, tools/aba_series.py)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD 1200 > $OUT.trace.log 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT.pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT.pmc2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT.pmc3.log 2>&1
