@@ -177,59 +177,84 @@ constexpr int AROWS = 16;
 constexpr int ALD = 260;  // LDS row stride (floats)
 __device__ __forceinline__ float elu(float x) { return x > 0.f ? x : expm1f(x); }
 
-// K % 16 == 0, weight rows 16-byte aligned.  Computes out[:, n0 .. n0+15] for NT neuron tiles starting at tile `first`, stride 4 waves.
-template <int K, int OUT, bool ACT>
-__device__ __forceinline__ void mfma_layer(const float* __restrict__ W, const float* __restrict__ bias, const float* in /*LDS [16][ALD]*/,
-                                           float* out /*LDS [16][ALD]*/, int wave, int lane) {
-    constexpr int TILES = (OUT + 15) / 16, G = K / 16;
-    const int r = lane & 15, kg = lane >> 4;
-    for (int tile = wave; tile < TILES; tile += 4) {
-        const int n = tile * 16 + r;
-        const bool nv = n < OUT;
-        const float* wrow = W + (size_t)(nv ? n : 0) * K + 4 * kg;
-        float4 bfrag[G];
+// A layer = its weight fetch (straight from L2 into registers, nothing of it depends on the activations) and its MFMAs.  The two are separate calls so that
+// the kernel can issue layer L + 1's fetch BEFORE it computes layer L: with fetch and MFMAs back to back per tile (the first form of this kernel) a
+// workgroup spent ~1 us of exposed L2 latency per tile, 9 tiles per wave, in a launch of 15 us that the rollout waits for 24 times per iteration.
+// K % 16 == 0, weight rows 16-byte aligned; tiles of 16 neurons, tile = wave + 4 j.
+template <int K, int OUT>
+struct LayerW {
+    static constexpr int TILES = (OUT + 15) / 16, NT = (TILES + 3) / 4, G = K / 16;
+    float4 b[NT][G];
+    float bias[NT];
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, const float* __restrict__ bv, int wave, int lane) {
+        const int r = lane & 15, kg = lane >> 4;
 #pragma unroll
-        for (int t = 0; t < G; t++) {
-            bfrag[t] = *reinterpret_cast<const float4*>(wrow + 16 * t);
-            if (!nv) bfrag[t] = make_float4(0.f, 0.f, 0.f, 0.f);
-        }
-        const float bv = nv ? bias[n] : 0.f;
-        f32x4 acc = {bv, bv, bv, bv};
+        for (int j = 0; j < NT; j++) {
+            const int n = (wave + 4 * j) * 16 + r;
+            const bool nv = wave + 4 * j < TILES && n < OUT;
+            const float* wrow = W + (size_t)(nv ? n : 0) * K + 4 * kg;
 #pragma unroll
-        for (int t = 0; t < G; t++) {
-            const float4 a = *reinterpret_cast<const float4*>(in + r * ALD + 16 * t + 4 * kg);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bfrag[t].x, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bfrag[t].y, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bfrag[t].z, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bfrag[t].w, acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const float v = ACT ? elu(acc[q]) : acc[q];
-            out[(kg * 4 + q) * ALD + tile * 16 + r] = v;
+            for (int t = 0; t < G; t++) {
+                b[j][t] = *reinterpret_cast<const float4*>(wrow + 16 * t);
+                if (!nv) b[j][t] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+            bias[j] = nv ? bv[n] : 0.f;
         }
     }
-}
+    template <bool ACT>
+    __device__ __forceinline__ void run(const float* in /*LDS [16][ALD]*/, float* out /*LDS [16][ALD]*/, int wave, int lane) const {
+        const int r = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int tile = wave + 4 * j;
+            if (tile >= TILES) break;
+            f32x4 acc = {bias[j], bias[j], bias[j], bias[j]};
+#pragma unroll
+            for (int t = 0; t < G; t++) {
+                const float4 a = *reinterpret_cast<const float4*>(in + r * ALD + 16 * t + 4 * kg);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, b[j][t].x, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, b[j][t].y, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, b[j][t].z, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, b[j][t].w, acc, 0, 0, 0);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const float v = ACT ? elu(acc[q]) : acc[q];
+                out[(kg * 4 + q) * ALD + tile * 16 + r] = v;
+            }
+        }
+    }
+};
 
 // first layer: K = 47 (rows not 16-byte aligned, K not a multiple of 4): scalar operand loads, k padded to 48 with zeros
 template <int K, int OUT>
-__device__ __forceinline__ void mfma_layer_first(const float* __restrict__ W, const float* __restrict__ bias, const float* in, float* out, int wave,
-                                                 int lane) {
-    constexpr int TILES = OUT / 16, STEPS = (K + 3) / 4;
-    const int r = lane & 15, kg = lane >> 4;
-    for (int tile = wave; tile < TILES; tile += 4) {
-        const int n = tile * 16 + r;
-        float bfrag[STEPS];
+struct FirstLayerW {
+    static constexpr int TILES = OUT / 16, NT = TILES / 4, STEPS = (K + 3) / 4;
+    float b[NT][STEPS];
+    float bias[NT];
+    __device__ __forceinline__ void fetch(const float* __restrict__ W, const float* __restrict__ bv, int wave, int lane) {
+        const int r = lane & 15, kg = lane >> 4;
 #pragma unroll
-        for (int s2 = 0; s2 < STEPS; s2++) { const int k = 4 * s2 + kg; bfrag[s2] = k < K ? W[(size_t)n * K + k] : 0.f; }
-        const float bv = bias[n];
-        f32x4 acc = {bv, bv, bv, bv};
+        for (int j = 0; j < NT; j++) {
+            const int n = (wave + 4 * j) * 16 + r;
 #pragma unroll
-        for (int s2 = 0; s2 < STEPS; s2++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(in[r * ALD + 4 * s2 + kg], bfrag[s2], acc, 0, 0, 0);
-#pragma unroll
-        for (int q = 0; q < 4; q++) out[(kg * 4 + q) * ALD + tile * 16 + r] = elu(acc[q]);
+            for (int s2 = 0; s2 < STEPS; s2++) { const int k = 4 * s2 + kg; b[j][s2] = k < K ? W[(size_t)n * K + k] : 0.f; }
+            bias[j] = bv[n];
+        }
     }
-}
+    __device__ __forceinline__ void run(const float* in, float* out, int wave, int lane) const {
+        const int r = lane & 15, kg = lane >> 4;
+#pragma unroll
+        for (int j = 0; j < NT; j++) {
+            const int tile = wave + 4 * j;
+            f32x4 acc = {bias[j], bias[j], bias[j], bias[j]};
+#pragma unroll
+            for (int s2 = 0; s2 < STEPS; s2++) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(in[r * ALD + 4 * s2 + kg], b[j][s2], acc, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; q++) out[(kg * 4 + q) * ALD + tile * 16 + r] = elu(acc[q]);
+        }
+    }
+};
 
 __global__ __launch_bounds__(256) void actor_sample_kernel(int N, const float* __restrict__ obs, const float* __restrict__ w0,
                                                            const float* __restrict__ b0, const float* __restrict__ w1,
@@ -240,18 +265,27 @@ __global__ __launch_bounds__(256) void actor_sample_kernel(int N, const float* _
     __shared__ __attribute__((aligned(16))) float bufA[AROWS * ALD];
     __shared__ __attribute__((aligned(16))) float bufB[AROWS * ALD];
     const int r0 = blockIdx.x * AROWS, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    FirstLayerW<BG_NUM_OBS, 256> l0;
+    l0.fetch(w0, b0, wave, lane);
+    LayerW<256, 128> l1;
+    l1.fetch(w1, b1, wave, lane);
     for (int k = threadIdx.x; k < AROWS * 48; k += blockDim.x) {  // obs tile, k padded 47 -> 48 with zeros
         const int r = k / 48, c = k % 48;
         bufA[r * ALD + c] = (r0 + r < N && c < BG_NUM_OBS) ? obs[(size_t)(r0 + r) * BG_NUM_OBS + c] : 0.f;
     }
     __syncthreads();
-    mfma_layer_first<BG_NUM_OBS, 256>(w0, b0, bufA, bufB, wave, lane);
+    // same arithmetic and order as one fetch + MFMA pass per layer; only WHEN the weights are fetched differs: a layer ahead
+    l0.run(bufA, bufB, wave, lane);
+    LayerW<128, 128> l2;
+    l2.fetch(w2, b2, wave, lane);
     __syncthreads();
-    mfma_layer<256, 128, true>(w1, b1, bufB, bufA, wave, lane);
+    l1.template run<true>(bufB, bufA, wave, lane);
+    LayerW<128, BG_NUM_DOFS> l3;
+    l3.fetch(w3, b3, wave, lane);
     __syncthreads();
-    mfma_layer<128, 128, true>(w2, b2, bufA, bufB, wave, lane);
+    l2.template run<true>(bufA, bufB, wave, lane);
     __syncthreads();
-    mfma_layer<128, BG_NUM_DOFS, false>(w3, b3, bufB, bufA, wave, lane);
+    l3.template run<false>(bufB, bufA, wave, lane);
     __syncthreads();
     // sample: one thread per (row, group of 4 actions)
     if (threadIdx.x < AROWS * 3) {
