@@ -18,7 +18,7 @@ for n in (4096, 16384, 65536, 262144, 1048576):
     qacc = torch.empty(n, 18, device=dev)
     lib = _lib.load()
     call = lambda: _lib.check(lib.bg_env_forward_dynamics(env._env, _lib.ptr(root), _lib.ptr(q), _lib.ptr(qd), _lib.ptr(tau), None, _lib.ptr(qacc), _lib.current_stream_ptr()))
-    for _ in range(5): call()
+    for _ in range(max(5, min(400, int(80e3 / max(1.0, n * 2e-4))))): call()  # ~80 ms of untimed launches: past the clock transient (tools/aba_series.py)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     K = 50

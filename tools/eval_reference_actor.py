@@ -15,7 +15,8 @@ Reported per scenario (terrain x asset.self_collisions [x contact overrides]):
                             second of each episode; `filtered_*` is what the tracking rewards see (t1.py:610-620); `tracking_rmse_still` for cmd = 0
   reward_terms              mean of each scaled reward term per env step (extras["rew_terms"], t1.py:566-570) and of the total
 
-    python tools/eval_reference_actor.py [num_envs=4096] [steps=1600] [--sweep] -> gpurun_out/reference_actor_eval.json
+    python tools/eval_reference_actor.py [num_envs=4096] [steps=1600] [--sweep] [--checkpoint logs/.../model.pth] -> gpurun_out/reference_actor_eval.json
+(--checkpoint: the same protocol for an actor trained by THIS build -> gpurun_out/own_actor_eval.json: the yardstick for the reference actor's numbers)
 """
 import json
 import os
@@ -31,9 +32,17 @@ from booster_gym_amd.envs import T1
 from booster_gym_amd.utils.config import load_cfg
 
 
+ACTOR_CHECKPOINT = None  # --checkpoint <.pth of this build's Runner>: evaluate that actor instead (how a policy TRAINED HERE fares under the same protocol)
+
+
 def load_actor(dev):
-    W = np.load(os.path.join(ROOT, "tests", "golden", "t1_actor.npz"))
-    layers = [(torch.tensor(W[f"{i}.weight"], device=dev), torch.tensor(W[f"{i}.bias"], device=dev)) for i in (0, 2, 4, 6)]
+    if ACTOR_CHECKPOINT:
+        sd = torch.load(ACTOR_CHECKPOINT, map_location=dev, weights_only=True)["model"]
+        W = {k[len("actor."):]: v.float() for k, v in sd.items() if k.startswith("actor.")}
+        layers = [(W[f"{i}.weight"].to(dev), W[f"{i}.bias"].to(dev)) for i in (0, 2, 4, 6)]
+    else:
+        W = np.load(os.path.join(ROOT, "tests", "golden", "t1_actor.npz"))
+        layers = [(torch.tensor(W[f"{i}.weight"], device=dev), torch.tensor(W[f"{i}.bias"], device=dev)) for i in (0, 2, 4, 6)]
 
     def actor(x):
         for k, (w, b) in enumerate(layers):
@@ -109,10 +118,17 @@ def evaluate(n, steps, overrides, seed=42):
 
 
 def main():
+    global ACTOR_CHECKPOINT
+    if "--checkpoint" in sys.argv:
+        k = sys.argv.index("--checkpoint")
+        ACTOR_CHECKPOINT = sys.argv[k + 1]
+        del sys.argv[k : k + 2]
     args = [a for a in sys.argv[1:] if not a.startswith("--")]
     n = int(args[0]) if len(args) > 0 else 4096
     steps = int(args[1]) if len(args) > 1 else 1600  # one full episode (1,500 steps) and its time-out
-    res = {"what": __doc__.split("\n\n")[0], "actor": "tests/golden/t1_actor.npz (weights of the reference's deploy/models/T1.pt)", "config": "envs/T1.yaml as shipped",
+    res = {"what": __doc__.split("\n\n")[0],
+           "actor": f"{ACTOR_CHECKPOINT} (an actor trained by this build)" if ACTOR_CHECKPOINT else "tests/golden/t1_actor.npz (weights of the reference's deploy/models/T1.pt)",
+           "config": "envs/T1.yaml as shipped",
            "scenarios": {}}
     for terrain in ("plane", "trimesh"):
         for sc in (0, 1):
@@ -137,9 +153,10 @@ def main():
                 print(name, v, sweep[f"{name}={v:g}"]["fall_rate_first_episode"], flush=True)
         res["contact_parameter_sweep_plane"] = sweep
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "reference_actor_eval.json"), "w") as f:
+    name = "own_actor_eval.json" if ACTOR_CHECKPOINT else "reference_actor_eval.json"
+    with open(os.path.join(ROOT, "gpurun_out", name), "w") as f:
         json.dump(res, f, indent=1)
-    print("written gpurun_out/reference_actor_eval.json")
+    print("written gpurun_out/" + name)
 
 
 if __name__ == "__main__":
