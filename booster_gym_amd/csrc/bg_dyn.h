@@ -107,7 +107,13 @@ typedef float lds_f32;
 #endif
 // LDS scratch of the item-parallel leg-against-leg narrow phase (SELF_LDS, self_narrow_phase_lds): poses, segments and pair results of up to 7 envs per pass
 constexpr int SELF_PASS_ENVS = 7, SELF_LDS_FLOATS = (36 * 2 + 13 * 4 + 9 * 4) * SELF_PASS_ENVS;
+#ifndef BG_ENV_PLANE_SPEC
+#define BG_ENV_PLANE_SPEC 1
+#endif
 struct RegStore {
+    // the plane-specialised sole contact (foot_contact) also in the fused env step: 104.95 -> 103.1 us per env step on flat ground, no change on the
+    // height field (tools/ab_sim.py, three alternating pairs on one box) -- unlike the z-axis specialisation below, this branch replaces a loop body
+    static constexpr bool PLANE_SPEC = BG_ENV_PLANE_SPEC;
     // the z-axis specialisation of the sweeps (Phys::zmask) is off here: this store serves the fused env step, one wave per SIMD and latency-bound,
     // where the extra (wave-uniform) branches split the blocks the scheduler overlaps work in: 107.7 -> 109.3 us per env step with it on (measured)
     static constexpr bool ZSPEC = false;
@@ -127,6 +133,7 @@ struct RegStore {
 // below within the 20 KB a workgroup may use when eight of them share a CU.
 struct LdsLinkStore : RegStore {
     static constexpr bool ZSPEC = true;  // the ABA kernel: throughput-bound (two waves per SIMD), fewer issued instructions pay directly
+    static constexpr bool PLANE_SPEC = true;
     static constexpr int PER_LINK = 10, SLOTS = PER_LINK * LEG_LINKS, STRIDE = 64;
     static constexpr int POS_FLOATS = 2 * LEG_LINKS * 4;  // [leg][link][x y z pad]
     static constexpr int FLOATS = SLOTS * STRIDE + POS_FLOATS + SELF_LDS_FLOATS;
@@ -657,7 +664,7 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
     V3 sr = v3(0.f, 0.f, 0.f);
     float sb = 0.f;
     bool any = false;
-    if (decltype(w.st)::ZSPEC && tr.type == 0) {
+    if (decltype(w.st)::PLANE_SPEC && tr.type == 0) {
         // Flat ground (wave-uniform; the throughput-bound ABA kernel only, like the z-axis link specialisation): the normal is the world's z axis for
         // every corner, so nb is ONE vector (the third row of Rfoot), a corner's penetration needs its height only (one dot product instead of the
         // world position), and the rank-1 terms that carry nb factor out of the sum over the corners: M += (sum alpha) nb nb^T, H += (sum alpha m) nb^T.
