@@ -298,13 +298,18 @@ def test_forward_passes_run_during_the_rollout_change_no_bit():
     from booster_gym_amd.utils.config import load_cfg
     from booster_gym_amd.utils.runner import Runner
 
-    for over in ({"terrain.type": "plane"}, {"terrain.type": "trimesh", "commands.curriculum": True}):
+    # (the last two: a horizon that the group size does not divide, and a group larger than the horizon -- every row still gets its pass exactly once)
+    for over, group in (({"terrain.type": "plane"}, None), ({"terrain.type": "trimesh", "commands.curriculum": True}, None),
+                        ({"terrain.type": "plane", "runner.horizon_length": 5, "env.num_envs": 128}, 2),
+                        ({"terrain.type": "plane", "runner.horizon_length": 5, "env.num_envs": 128}, 8)):
         res = []
         for ahead in (True, False):
             cfg = load_cfg("T1", dict({"env.num_envs": 256, "runner.mini_epochs": 3, "basic.seed": 7}, **over))
             r = Runner(cfg=cfg)
             assert r._rollout_forward, "the default path must be the overlapped one at this shape"
             r._rollout_forward = ahead
+            if group is not None:
+                r._rollout_group = group
             obs, infos = r.env.reset()
             r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
             for _ in range(2):
