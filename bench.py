@@ -162,7 +162,7 @@ def aba_roofline(n=1 << 20, launches=50):
                       "(profiles/r04_aba_series.txt); round 3's kernels sustain 263-266 us in this regime",
             "launches_4_to_33_from_idle_us": cold[0],
             "kernels_per_launch_rocprof": "profiles/r04_b_aba_kernel_stats.csv: forward_dynamics_kernel over 1,200 launches (the first ~160 in the clock transient); "
-                                          "PMC (60 launches): profiles/r04_b_aba_pmc.json; round 3: a second, gathering kernel of 79 us for the envs whose legs are close",
+                                          "PMC passes (12 launches each): profiles/r04_b_aba_pmc.json; round 3: a second, gathering kernel of 79 us for the envs whose legs are close",
             "survey_8d_state": {"avg_launch_us": us2, "achieved": gbs2, "frac": gbs2 / HBM_PEAK_GBS, "launches_4_to_33_from_idle_us": cold[1],
                                 "state": "joints ~ U(limits), trunk at 0.72 m within 0.3 rad of upright, torques ~ U(+-effort), qd ~ N(0, 1)"},
             "note": "VALU-issue bound (SQ counters in the PMC file: the SIMDs issue VALU 100 % of the wave cycles of forward_dynamics_kernel at 4 cycles per "
