@@ -415,8 +415,14 @@ __global__ __launch_bounds__(256) void critic_head_forward_kernel(int rows, cons
 // phase is critic_head_forward_kernel's (half a wave per row, same sums: bit-identical values), the values go to LDS and to values_all, threads
 // 0..15 then run gae_kernel's scan on registers (its loads were issued at the top of the kernel).  Moments of the advantages: one float64 triple per
 // workgroup in `partial`; the last workgroup to finish (ticket) adds them up in a fixed order and WRITES sums (no zero fill, no float atomics).
-constexpr int VG_ENVS = 16;
-template <int TMAX>
+// Envs per workgroup: 16 where the launch also evaluates the output layer (25 x 16 rows of activations per workgroup); 64 for the scan alone, which is what
+// the training loop runs (values from the chained forward kernel's value head): a quarter of the workgroups, tickets and fences beside the actor's
+// forward chain -- update 21.12 against 21.26 ms on one box, three of three alternating pairs (tools/ab_env.sh)
+#ifndef BG_GAE_SCAN_ENVS
+#define BG_GAE_SCAN_ENVS 64
+#endif
+constexpr int VG_ENVS_VALUES = 16, VG_ENVS_SCAN = BG_GAE_SCAN_ENVS;
+template <int TMAX, int VG_ENVS>
 __global__ __launch_bounds__(256) void critic_values_gae_kernel(int T, int N, const float* __restrict__ h, const float* __restrict__ w,
                                                                 const float* __restrict__ b, float* __restrict__ rewards,
                                                                 const uint8_t* __restrict__ dones, const uint8_t* __restrict__ touts, float gamma,
@@ -487,13 +493,13 @@ __global__ __launch_bounds__(256) void critic_values_gae_kernel(int T, int N, co
                 next_v = v;
             }
     }
-    if (threadIdx.x < 64) {  // the scanning threads all sit in wave 0
 #pragma unroll
-        for (int k = 0; k < 3; k++) {
-            const double s = wave_sum_d(acc[k]);
-            if (threadIdx.x == 0) partial[(size_t)blockIdx.x * 3 + k] = s;
-        }
+    for (int k = 0; k < 3; k++) {  // (the scanning threads are the first VG_ENVS of the workgroup; the others carry zeros)
+        const double s = wave_sum_d(acc[k]);
+        if ((threadIdx.x & 63) == 0) sd[k * 4 + (threadIdx.x >> 6)] = s;
     }
+    __syncthreads();
+    if (threadIdx.x < 3) partial[(size_t)blockIdx.x * 3 + threadIdx.x] = sd[threadIdx.x * 4] + sd[threadIdx.x * 4 + 1] + sd[threadIdx.x * 4 + 2] + sd[threadIdx.x * 4 + 3];
     __syncthreads();
     if (threadIdx.x == 0) {
         __threadfence();
@@ -536,9 +542,11 @@ extern "C" int bg_critic_values_gae(int32_t T, int32_t N, const float* h, const 
         return bg_set_error(-1, "bg_critic_values_gae: bad argument");
     if (h && (!aligned16(h) || !aligned16(w))) return bg_set_error(-1, "bg_critic_values_gae: h and w must be 16-byte aligned");
     if (T > 32) return bg_set_error(-4, "bg_critic_values_gae: horizon above 32 (use bg_critic_head_forward + bg_gae)");
-    const int grid = (N + VG_ENVS - 1) / VG_ENVS;
-    hipLaunchKernelGGL(critic_values_gae_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, T, N, h, w, b, rewards, dones, time_outs, gamma, lam,
-                       values_all, advantages, returns, scratch, reinterpret_cast<unsigned*>(scratch + (size_t)grid * 3), sums);
+    unsigned* ticket = reinterpret_cast<unsigned*>(scratch + (size_t)((N + 15) / 16) * 3);  // the scratch's last element, whichever form runs
+    if (h) hipLaunchKernelGGL((critic_values_gae_kernel<32, VG_ENVS_VALUES>), dim3((N + VG_ENVS_VALUES - 1) / VG_ENVS_VALUES), dim3(256), 0, (hipStream_t)stream, T, N, h, w,
+                              b, rewards, dones, time_outs, gamma, lam, values_all, advantages, returns, scratch, ticket, sums);
+    else hipLaunchKernelGGL((critic_values_gae_kernel<32, VG_ENVS_SCAN>), dim3((N + VG_ENVS_SCAN - 1) / VG_ENVS_SCAN), dim3(256), 0, (hipStream_t)stream, T, N, h, w, b,
+                            rewards, dones, time_outs, gamma, lam, values_all, advantages, returns, scratch, ticket, sums);
     HIP_OK(hipGetLastError());
     return 0;
 }

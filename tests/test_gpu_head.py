@@ -201,7 +201,12 @@ def test_critic_values_and_gae_in_one_launch_equal_the_separate_launches(T, N):
     s2 = torch.full((3,), 7.0, dtype=torch.float64, device=dev)
     vin = v0.clone()
     critic_values_gae(None, w, b, r2, dones, touts, 0.995, 0.95, vin, adv2, ret2, s2, scratch)
-    assert torch.equal(vin, v0) and torch.equal(adv2, adv0) and torch.equal(ret2, ret0) and torch.equal(r2, r0) and torch.equal(s2, s_first)
+    # (the scan-only form runs 64 envs per workgroup instead of 16: the moments are added in another fixed order)
+    assert torch.equal(vin, v0) and torch.equal(adv2, adv0) and torch.equal(ret2, ret0) and torch.equal(r2, r0)
+    assert torch.allclose(s2, s_first, rtol=1e-12, atol=1e-9) and float(s2[2]) == T * N and float(scratch[-1]) == 0.0
+    s3 = torch.full((3,), 9.0, dtype=torch.float64, device=dev)
+    critic_values_gae(None, w, b, rew.clone(), dones, touts, 0.995, 0.95, v0.clone(), adv2, ret2, s3, scratch)
+    assert torch.equal(s3, s2)  # deterministic
     if T == 32:
         big = torch.zeros(33, N, device=dev)
         with pytest.raises(RuntimeError, match="horizon"):
