@@ -2,6 +2,7 @@
 interface behave like the reference (same errors, same config semantics), the product's per-lane dynamics/RNG headers compiled
 for the host agree with the oracle, and the data-parallel path is exact under gloo with world_size 2."""
 import ctypes as C
+import json
 import os
 import re
 import subprocess
@@ -98,6 +99,37 @@ def test_abi_argument_errors_without_gpu():
 
 
 # ------------------------------------------------------------------ host mirrors of the reference interface
+def test_policy_io_contract_matches_the_deployed_configuration(flat_model):
+    """The exported actor is consumed by deploy/utils/policy.py:34-73 under deploy/configs/T1.yaml (numbers-only fixture: tests/golden/deploy_contract.json).
+    What a policy trained HERE must agree with for that consumer to work: 47 observations / 12 actions, 500 Hz x decimation 10, action scale and clip,
+    the observation scales, the default pose the actions are offsets from, and the leg joints' proportional gains.  Two differences are the reference's
+    own (its training yaml against its deploy yaml), asserted so that they stay visible: the ankles' derivative gain (1 in training, envs/T1.yaml:93; 3 on
+    the robot) and two torque limits (hip pitch: URDF effort 45, 60 on the robot; hip roll: 30 / 25)."""
+    from booster_gym_amd.utils.config import load_cfg
+
+    dep = json.load(open(os.path.join(ROOT, "tests", "golden", "deploy_contract.json")))
+    cfg = load_cfg("T1", {})
+    assert cfg["env"]["num_observations"] == dep["num_observations"] and cfg["env"]["num_actions"] == dep["num_actions"]
+    assert cfg["sim"]["dt"] == dep["dt"] and cfg["control"]["decimation"] == dep["decimation"] and cfg["control"]["action_scale"] == dep["action_scale"]
+    nz = cfg["normalization"]
+    for k, v in dep["normalization"].items():
+        assert float(nz[k]) == float(v), k
+    lo, hi = cfg["commands"]["gait_frequency"]
+    assert lo <= dep["gait_frequency"] <= hi  # the robot walks at a frequency the policy was trained on
+    names = flat_model.dof_names
+    pick = lambda table, name: [v for k, v in table.items() if k in name][-1]
+    kp = [pick(cfg["control"]["stiffness"], n) for n in names]
+    kd = [pick(cfg["control"]["damping"], n) for n in names]
+    dja = cfg["init_state"]["default_joint_angles"]
+    q0 = [([v for k, v in dja.items() if k != "default" and k in n] or [dja["default"]])[-1] for n in names]
+    assert kp == dep["leg_stiffness"] and q0 == dep["leg_default_qpos"]
+    ankle = ["Ankle" in n for n in names]
+    assert [d for d, a in zip(kd, ankle) if not a] == [d for d, a in zip(dep["leg_damping"], ankle) if not a]
+    assert {d for d, a in zip(kd, ankle) if a} == {1} and {d for d, a in zip(dep["leg_damping"], ankle) if a} == {3}
+    diff = {n: (e, t) for n, e, t in zip(names, flat_model.dof_effort.tolist(), dep["leg_torque_limit"]) if e != t}
+    assert diff == {"Left_Hip_Pitch": (45.0, 60), "Right_Hip_Pitch": (45.0, 60), "Left_Hip_Roll": (30.0, 25), "Right_Hip_Roll": (30.0, 25)}
+
+
 def test_config_surface_is_a_superset_of_the_reference_yaml():
     from booster_gym_amd.utils.config import load_cfg
 
