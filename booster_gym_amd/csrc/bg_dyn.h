@@ -35,12 +35,16 @@ constexpr int LEG_LINKS = 6;
 constexpr int LEG_AXIS[LEG_LINKS] = {2, 1, 3, 2, 2, 1};
 constexpr int SELF_SHANK = 3, SELF_FOOT = 5;  // the leg links that carry a self-collision capsule
 
-struct LinkConst {   // one rigid body, per-env randomisation already applied
-    V3 pos;          // origin in the parent frame
-    float m;         // mass
-    V3 mc;           // mass * centre of mass
-    S3 Io;           // rotational inertia about the body origin
+// The lane code below is generic over the scalar type T (bg_math.h): T = float, one LEG per lane (LinkConst, LegParams, ... are the float
+// instances: the fused env step, the granular simulator calls); T = f2, both legs of an env in the halves of 64-bit register pairs, one ENV
+// per lane (bg_dyn_pk.h: the packed ABA kernel).  What cannot be a branch per half is written as a select (sel / both / any_of).
+template <class T> struct LinkConstT {   // one rigid body, per-env randomisation already applied
+    V3T<T> pos;      // origin in the parent frame
+    T m;             // mass
+    V3T<T> mc;       // mass * centre of mass
+    S3T<T> Io;       // rotational inertia about the body origin
 };
+using LinkConst = LinkConstT<float>;
 
 struct Phys {
     float dt;
@@ -81,14 +85,16 @@ struct ModelDev {  // nominal (un-randomised) model, shared by all envs; filled 
     float cap_c[2][2][3], cap_h[2][2], cap_r[2][2];
 };
 
-struct LegParams {
-    LinkConst lk[LEG_LINKS];
-    float q_lo[LEG_LINKS], q_hi[LEG_LINKS], qd_max[LEG_LINKS];
-    V3 corner[4];
-    float mu, kn, dn;  // combined friction, normal stiffness, normal damping of this foot
+template <class T> struct LegParamsT {
+    LinkConstT<T> lk[LEG_LINKS];
+    T q_lo[LEG_LINKS], q_hi[LEG_LINKS], qd_max[LEG_LINKS];
+    V3 corner[4];  // (the same four sole corners under both feet)
+    T mu, kn, dn;  // combined friction, normal stiffness, normal damping of this foot
 };
+using LegParams = LegParamsT<float>;
 
-struct LegState { float q[LEG_LINKS], qd[LEG_LINKS]; };
+template <class T> struct LegStateT { T q[LEG_LINKS], qd[LEG_LINKS]; };
+using LegState = LegStateT<float>;
 
 struct BaseState {
     V3 pos;
@@ -110,23 +116,29 @@ constexpr int SELF_PASS_ENVS = 7, SELF_LDS_FLOATS = (36 * 2 + 13 * 4 + 9 * 4) * 
 #ifndef BG_ENV_PLANE_SPEC
 #define BG_ENV_PLANE_SPEC 1
 #endif
-struct RegStore {
+template <class T> struct RegStoreT {
+    using Scalar = T;
     // the plane-specialised sole contact (foot_contact) also in the fused env step: 104.95 -> 103.1 us per env step on flat ground, no change on the
     // height field (tools/ab_sim.py, three alternating pairs on one box) -- unlike the z-axis specialisation below, this branch replaces a loop body
     static constexpr bool PLANE_SPEC = BG_ENV_PLANE_SPEC;
     // the z-axis specialisation of the sweeps (Phys::zmask) is off here: this store serves the fused env step, one wave per SIMD and latency-bound,
     // where the extra (wave-uniform) branches split the blocks the scheduler overlaps work in: 107.7 -> 109.3 us per env step with it on (measured)
     static constexpr bool ZSPEC = false;
-    SV v[LEG_LINKS], cb[LEG_LINKS], U[LEG_LINKS];
-    template <int I> BG_HD void put_v(SV x) { v[I] = x; }
-    template <int I> BG_HD SV get_v() const { return v[I]; }
-    template <int I> BG_HD void put_cb(SV x) { cb[I] = x; }
-    template <int I> BG_HD SV get_cb() const { return cb[I]; }
-    template <int I> BG_HD void put_U(SV x) { U[I] = x; }
-    template <int I> BG_HD SV get_U() const { return U[I]; }
-    template <int I, class LP> BG_HD V3 link_pos(const LP& lp) const { return lp.lk[I].pos; }
-    template <int I, class LP> BG_HD LinkConst link(const LP& lp) const { return lp.lk[I]; }
+    SVT<T> v[LEG_LINKS], cb[LEG_LINKS], U[LEG_LINKS];
+    template <int I> BG_HD void put_v(SVT<T> x) { v[I] = x; }
+    template <int I> BG_HD SVT<T> get_v() const { return v[I]; }
+    template <int I> BG_HD void put_cb(SVT<T> x) { cb[I] = x; }
+    template <int I> BG_HD SVT<T> get_cb() const { return cb[I]; }
+    template <int I> BG_HD void put_U(SVT<T> x) { U[I] = x; }
+    template <int I> BG_HD SVT<T> get_U() const { return U[I]; }
+    template <int I, class LP> BG_HD V3T<T> link_pos(const LP& lp) const { return lp.lk[I].pos; }
+    template <int I, class LP> BG_HD LinkConstT<T> link(const LP& lp) const { return lp.lk[I]; }
+    // joint range and applied torque of link I: plain members here; the packed kernel's store fetches them where the inward sweep asks
+    template <int I, class LP> BG_HD T q_lo(const LP& lp) const { return lp.q_lo[I]; }
+    template <int I, class LP> BG_HD T q_hi(const LP& lp) const { return lp.q_hi[I]; }
+    template <int I> BG_HD T tau_at(const T* tau) const { return tau[I]; }
 };
+using RegStore = RegStoreT<float>;
 // v / cb / U in registers, the per-env link constants (10 floats per link: mass, m c, inertia about the origin; computed once per launch) in LDS.
 // The link ORIGINS are not per-env (nominal model constants, one set per leg): they sit in a 2 x 6 x 4-float table of the workgroup that every
 // lane of a leg reads at the same address (a broadcast read) -- 18 fewer lane-wide slots, which is what pays for the leg-against-leg scratch
@@ -175,57 +187,60 @@ struct LdsLinkStore : RegStore {
 
 template <class Store>
 struct LegWorkT {  // what the inward sweep leaves behind for the outward sweep
-    float c[LEG_LINKS], s[LEG_LINKS];
+    using T = typename Store::Scalar;
+    using Scalar = T;
+    T c[LEG_LINKS], s[LEG_LINKS];
     int zmask;         // Phys::zmask, for the sweeps that do not see Phys
     Store st;
-    float dinv[LEG_LINKS], u[LEG_LINKS];
-    M3 Rfoot;          // foot -> world
-    M3 Rsh; V3 psh;    // shank -> world, shank origin relative to the trunk origin (for the leg-against-leg contacts; dead after them)
+    T dinv[LEG_LINKS], u[LEG_LINKS];
+    M3T<T> Rfoot;             // foot -> world
+    M3T<T> Rsh; V3T<T> psh;   // shank -> world, shank origin relative to the trunk origin (for the leg-against-leg contacts; dead after them)
     // leg-against-leg contacts: wrench on this leg's shank / foot about the link origin in link coordinates, their world-frame forces,
     // the lateral clearance between the two legs (negative = capsules can meet), and "left to the second kernel" (SELF_DEFER)
-    SV self_fx[2];
-    V3 self_shank, self_foot;
+    SVT<T> self_fx[2];
+    V3T<T> self_shank, self_foot;
     float self_gap;
     bool self_deferred;
-    lds_f32* self_sc;  // SELF_LDS: the workgroup's scratch (SELF_LDS_FLOATS) and this lane's index, set by the kernel
+    lds_f32* self_sc;  // SELF_LDS / SELF_PK: the workgroup's scratch and this lane's index, set by the kernel
     int self_lane;
-    SI Bc;             // contact impedance on the foot
-    SV f0c;            // contact wrench at the current state (foot coords)
-    bool contact;
+    SIT<T> Bc;         // contact impedance on the foot
+    SVT<T> f0c;        // contact wrench at the current state (foot coords)
+    bool contact;      // (T = f2: of either foot; the impedance and the wrench of a foot in the air are zero)
 };
 using LegWork = LegWorkT<RegStore>;
 
-struct BaseContribution { SI I; SV p; };  // articulated inertia / bias force seen at the trunk
-BG_HD void bg_pin(V3& v) { for (int a = 0; a < 3; a++) BG_PIN1(v.e[a]); }
-BG_HD void bg_pin(SV& v) { bg_pin(v.a); bg_pin(v.l); }
-BG_HD void bg_pin(M3& m) { for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) BG_PIN1(m.e[a][b]); }
-BG_HD void bg_pin(S3& m) { for (int a = 0; a < 6; a++) BG_PIN1(m.e[a]); }
-BG_HD void bg_pin(SI& i) { bg_pin(i.A); bg_pin(i.H); bg_pin(i.M); }
+template <class T> struct BaseContributionT { SIT<T> I; SVT<T> p; };  // articulated inertia / bias force seen at the trunk
+using BaseContribution = BaseContributionT<float>;
+template <class T> BG_HD void bg_pin(V3T<T>& v) { for (int a = 0; a < 3; a++) BG_PIN1(v.e[a]); }
+template <class T> BG_HD void bg_pin(SVT<T>& v) { bg_pin(v.a); bg_pin(v.l); }
+template <class T> BG_HD void bg_pin(M3T<T>& m) { for (int a = 0; a < 3; a++) for (int b = 0; b < 3; b++) BG_PIN1(m.e[a][b]); }
+template <class T> BG_HD void bg_pin(S3T<T>& m) { for (int a = 0; a < 6; a++) BG_PIN1(m.e[a]); }
+template <class T> BG_HD void bg_pin(SIT<T>& i) { bg_pin(i.A); bg_pin(i.H); bg_pin(i.M); }
 
-BG_HD SI rigid_inertia(const LinkConst& k) {
-    SI I;
+template <class T> BG_HD SIT<T> rigid_inertia(const LinkConstT<T>& k) {
+    SIT<T> I;
     I.A = k.Io;
     I.H = skew(k.mc);
-    I.M = s3_zero();
+    I.M = s3t_zero<T>();
     I.M.e[0] = I.M.e[1] = I.M.e[2] = k.m;
     return I;
 }
-BG_HD SV mul(const SI& I, SV v) {
-    SV f;
+template <class T> BG_HD SVT<T> mul(const SIT<T>& I, SVT<T> v) {
+    SVT<T> f;
     f.a = mul(I.A, v.a) + mul(I.H, v.l);
     f.l = mulT(I.H, v.a) + mul(I.M, v.l);
     return f;
 }
 // rigid-body shortcut of  I v  (H = skew(mc), M = m 1)
-BG_HD SV mul_rigid(const LinkConst& k, SV v) {
-    SV f;
+template <class T> BG_HD SVT<T> mul_rigid(const LinkConstT<T>& k, SVT<T> v) {
+    SVT<T> f;
     f.a = mul(k.Io, v.a) + cross(k.mc, v.l);
     f.l = k.m * v.l - cross(k.mc, v.a);
     return f;
 }
 // v x* f  (spatial force cross product, RBDA eq. 2.32)
-BG_HD SV crf(SV v, SV f) {
-    SV o;
+template <class T> BG_HD SVT<T> crf(SVT<T> v, SVT<T> f) {
+    SVT<T> o;
     o.a = cross(v.a, f.a) + cross(v.l, f.l);
     o.l = cross(v.a, f.l);
     return o;
@@ -249,6 +264,13 @@ BG_HD void terrain_query(const TerrainDev& t, float x, float y, float* h, V3* n)
     float hy = ((1.f - fx) * (h01 - h00) + fx * (h11 - h10)) * t.vscale * t.inv_hscale;
     float inv = bg_rsqrt(hx * hx + hy * hy + 1.0f);
     *n = v3(-hx * inv, -hy * inv, inv);
+}
+BG_HD void terrain_query(const TerrainDev& t, f2 x, f2 y, f2* h, V3T<f2>* n) {  // both feet of a lane, one after the other
+    float h0, h1; V3 n0, n1;
+    terrain_query(t, x[0], y[0], &h0, &n0);
+    terrain_query(t, x[1], y[1], &h1, &n1);
+    *h = mk2(h0, h1);
+    *n = v3t<f2>(mk2(n0.e[0], n1.e[0]), mk2(n0.e[1], n1.e[1]), mk2(n0.e[2], n1.e[2]));
 }
 BG_HD float terrain_height(const TerrainDev& t, float x, float y) {
     float h; V3 n;
@@ -323,21 +345,21 @@ BG_HD void leg_contact_prepass(const Phys& ph, const TerrainDev& tr, const Model
 }
 
 // ---------------------------------------------------------------- outward sweep, link I
-template <int I, class W>
-BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M3 Rpar, V3 ppar, SV* vfoot, V3* pfoot) {
+template <int I, class W, class T = typename W::Scalar>
+BG_HD void leg_outward(const LegParamsT<T>& lp, const LegStateT<T>& ls, W& w, SVT<T> vpar, M3T<T> Rpar, V3T<T> ppar, SVT<T>* vfoot, V3T<T>* pfoot) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
     bg_pin(vpar); bg_pin(Rpar); bg_pin(ppar);
     BG_PHASE("outward_link");
-    float s, c;
+    T s, c;
     bg_sincos(ls.q[I], &s, &c);
     w.c[I] = c; w.s[I] = s;
     // v_i = X v_parent + S qd :  w' = E w ; v' = E (v + w x r)
-    SV v;
+    SVT<T> v;
     v.a = rotT<AX>(c, s, vpar.a);
-    const V3 lpos = w.st.template link_pos<I>(lp);
-    V3 vlin, p;  // linear velocity of the link origin in parent coordinates, link origin relative to the trunk origin
+    const V3T<T> lpos = w.st.template link_pos<I>(lp);
+    V3T<T> vlin, p;  // linear velocity of the link origin in parent coordinates, link origin relative to the trunk origin
     if ((w.zmask >> I) & 1) {  // r = (0, 0, z): wave-uniform branch (Phys::zmask)
-        const V3 rz = v3(0.f, 0.f, lpos.e[2]);
+        const V3T<T> rz = v3t<T>(splat<T>(0.f), splat<T>(0.f), lpos.e[2]);
         vlin = vpar.l + cross(vpar.a, rz);
         p = ppar + mul(Rpar, rz);
     } else {
@@ -346,15 +368,15 @@ BG_HD void leg_outward(const LegParams& lp, const LegState& ls, W& w, SV vpar, M
     }
     v.l = rotT<AX>(c, s, vlin);
     // c_i = v_i x (S qd)   (S = unit angular axis A)
-    V3 sq = v3(0.f, 0.f, 0.f); sq.e[A] = ls.qd[I];
-    SV cb;
+    V3T<T> sq = v3_zero<T>(); sq.e[A] = ls.qd[I];
+    SVT<T> cb;
     cb.a = cross(v.a, sq);
     cb.l = cross(v.l, sq);
     w.st.template put_cb<I>(cb);
     v.a.e[A] += ls.qd[I];
     w.st.template put_v<I>(v);
     // world-aligned pose of the link (for the foot and the self-collision capsules, carried down the chain)
-    M3 R;  // R_world_child = R_world_parent * R(axis,q): rotate the columns J,K
+    M3T<T> R;  // R_world_child = R_world_parent * R(axis,q): rotate the columns J,K
     {
         constexpr int J = Plane<AX>::J, K = Plane<AX>::K;
         R = Rpar;
@@ -648,8 +670,11 @@ BG_HD void self_contacts(const Phys& ph, const ModelDev& M, int leg, W& w, const
     }
 }
 // ---------------------------------------------------------------- foot contact (4 sole corners)
-template <class W>
-BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& lp, W& w, SV vfoot, V3 pfoot, V3* force_w0) {
+// the 0 / 1 factor that removes the half of a two-wide corner evaluation whose foot does not touch; under `if (hit)` a lane-per-leg corner is a hit
+BG_HD float hit_factor(bool) { return 1.0f; }
+BG_HD f2 hit_factor(B2 h) { return mk2(h.x ? 1.0f : 0.0f, h.y ? 1.0f : 0.0f); }
+template <class W, class T = typename W::Scalar>
+BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParamsT<T>& lp, W& w, SVT<T> vfoot, V3T<T> pfoot, V3T<T>* force_w0) {
     bg_pin(vfoot); bg_pin(pfoot); bg_pin(w.Rfoot);
     BG_PHASE("foot_contact");
     // Everything after the terrain query is done in FOOT coordinates (normal and velocities rotated once; the friction law only needs norms
@@ -658,36 +683,41 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
     //     M += alpha nb nb^T + beta 1,   H += alpha m nb^T + beta rx,   A += alpha m m^T + beta (|r|^2 1 - r r^T),   m = r x nb,
     // so a corner costs three rank-1 updates (two of them symmetric) instead of two 3x3 cross-column products; the beta terms are summed
     // over the corners first (sb = sum beta, sr = sum beta r, P = sum beta r r^T) and added once.
-    S3 BM = s3_zero(), BA = s3_zero(), P = s3_zero();
-    M3 BH = m3_zero();
-    SV f0 = sv_zero();
-    V3 sr = v3(0.f, 0.f, 0.f);
-    float sb = 0.f;
+    // T = f2: a corner is evaluated when EITHER foot's corner touches; `on` (0 / 1 per half) removes the other foot's share.
+    S3T<T> BM = s3t_zero<T>(), BA = s3t_zero<T>(), P = s3t_zero<T>();
+    M3T<T> BH = m3t_zero<T>();
+    SVT<T> f0 = svt_zero<T>();
+    V3T<T> sr = v3_zero<T>();
+    T sb = splat<T>(0.f);
+    const T zero = splat<T>(0.f), one = splat<T>(1.0f);
     bool any = false;
     if (decltype(w.st)::PLANE_SPEC && tr.type == 0) {
         // Flat ground (wave-uniform; the throughput-bound ABA kernel only, like the z-axis link specialisation): the normal is the world's z axis for
         // every corner, so nb is ONE vector (the third row of Rfoot), a corner's penetration needs its height only (one dot product instead of the
         // world position), and the rank-1 terms that carry nb factor out of the sum over the corners: M += (sum alpha) nb nb^T, H += (sum alpha m) nb^T.
-        const V3 nb = v3(w.Rfoot.e[2][0], w.Rfoot.e[2][1], w.Rfoot.e[2][2]);
-        float sa = 0.f;
-        V3 sam = v3(0.f, 0.f, 0.f);
+        const V3T<T> nb = v3t<T>(w.Rfoot.e[2][0], w.Rfoot.e[2][1], w.Rfoot.e[2][2]);
+        T sa = zero;
+        V3T<T> sam = v3_zero<T>();
         for (int k = 0; k < 4; k++) {
-            const V3 r = lp.corner[k];
-            const float pen = -(pfoot.e[2] + dot(nb, r));
-            const V3 vb = vfoot.l + cross(vfoot.a, r);
-            const float vn = dot(vb, nb);
-            const float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
-            const float d_eff = lp.dn * ramp;
-            const float fn0 = lp.kn * pen - d_eff * vn;
-            if (pen > 0.f && fn0 > 0.f) {
+            const V3T<T> r = splat_v3<T>(lp.corner[k]);
+            const T pen = -(pfoot.e[2] + dot(nb, r));
+            const V3T<T> vb = vfoot.l + cross(vfoot.a, r);
+            const T vn = dot(vb, nb);
+            const T ramp = sel(lt(pen, splat<T>(ph.contact_ramp)), pen * bg_rcp(ph.contact_ramp), one);
+            const T d_eff = lp.dn * ramp;
+            const T fn0 = lp.kn * pen - d_eff * vn;
+            const auto hit = both(gt(pen, zero), gt(fn0, zero));
+            if (any_of(hit)) {
                 any = true;
-                const V3 vt = vb - vn * nb;
-                const float c_t = fminf(ph.friction_visc, lp.mu * fn0 * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
-                const V3 fb = fn0 * nb - c_t * vt;
-                const float beta = ph.dt * c_t, alpha = ph.dt * (d_eff + ph.dt * lp.kn) - beta;
+                const T on = hit_factor(hit);
+                const V3T<T> vt = vb - vn * nb;
+                const T fn = on * fn0;
+                const T c_t = on * bg_min(splat<T>(ph.friction_visc), lp.mu * fn0 * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
+                const V3T<T> fb = fn * nb - c_t * vt;
+                const T beta = ph.dt * c_t, alpha = on * (ph.dt * (d_eff + ph.dt * lp.kn)) - beta;
                 f0.l = f0.l + fb;
                 f0.a = f0.a + cross(r, fb);
-                const V3 m = cross(r, nb), am = alpha * m, br = beta * r;
+                const V3T<T> m = cross(r, nb), am = alpha * m, br = beta * r;
                 sa += alpha;
                 sam = sam + am;
                 BA.e[0] += am.e[0] * m.e[0]; BA.e[1] += am.e[1] * m.e[1]; BA.e[2] += am.e[2] * m.e[2];
@@ -698,32 +728,35 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
                 sb += beta;
             }
         }
-        const V3 an = sa * nb;
+        const V3T<T> an = sa * nb;
         BM.e[0] = an.e[0] * nb.e[0]; BM.e[1] = an.e[1] * nb.e[1]; BM.e[2] = an.e[2] * nb.e[2];
         BM.e[3] = an.e[0] * nb.e[1]; BM.e[4] = an.e[0] * nb.e[2]; BM.e[5] = an.e[1] * nb.e[2];
         for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) BH.e[i][j] = sam.e[i] * nb.e[j];
     } else
     for (int k = 0; k < 4; k++) {
-        const V3 r = lp.corner[k];
-        const V3 xw = pfoot + mul(w.Rfoot, r);
-        const V3 vb = vfoot.l + cross(vfoot.a, r);
-        float h; V3 n;
+        const V3T<T> r = splat_v3<T>(lp.corner[k]);
+        const V3T<T> xw = pfoot + mul(w.Rfoot, r);
+        const V3T<T> vb = vfoot.l + cross(vfoot.a, r);
+        T h; V3T<T> n;
         terrain_query(tr, xw.e[0], xw.e[1], &h, &n);
-        const V3 nb = mulT(w.Rfoot, n);
-        const float pen = (h - xw.e[2]) * n.e[2];
-        const float vn = dot(vb, nb);
-        const float ramp = pen < ph.contact_ramp ? pen * bg_rcp(ph.contact_ramp) : 1.0f;
-        const float d_eff = lp.dn * ramp;
-        const float fn0 = lp.kn * pen - d_eff * vn;
-        if (pen > 0.f && fn0 > 0.f) {
+        const V3T<T> nb = mulT(w.Rfoot, n);
+        const T pen = (h - xw.e[2]) * n.e[2];
+        const T vn = dot(vb, nb);
+        const T ramp = sel(lt(pen, splat<T>(ph.contact_ramp)), pen * bg_rcp(ph.contact_ramp), one);
+        const T d_eff = lp.dn * ramp;
+        const T fn0 = lp.kn * pen - d_eff * vn;
+        const auto hit = both(gt(pen, zero), gt(fn0, zero));
+        if (any_of(hit)) {
             any = true;
-            const V3 vt = vb - vn * nb;
-            const float c_t = fminf(ph.friction_visc, lp.mu * fn0 * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
-            const V3 fb = fn0 * nb - c_t * vt;
-            const float beta = ph.dt * c_t, alpha = ph.dt * (d_eff + ph.dt * lp.kn) - beta;
+            const T on = hit_factor(hit);
+            const V3T<T> vt = vb - vn * nb;
+            const T fn = on * fn0;
+            const T c_t = on * bg_min(splat<T>(ph.friction_visc), lp.mu * fn0 * bg_rcp(bg_sqrt(dot(vt, vt)) + 1e-6f));
+            const V3T<T> fb = fn * nb - c_t * vt;
+            const T beta = ph.dt * c_t, alpha = on * (ph.dt * (d_eff + ph.dt * lp.kn)) - beta;
             f0.l = f0.l + fb;
             f0.a = f0.a + cross(r, fb);
-            const V3 m = cross(r, nb), an = alpha * nb, am = alpha * m, br = beta * r;
+            const V3T<T> m = cross(r, nb), an = alpha * nb, am = alpha * m, br = beta * r;
             BM.e[0] += an.e[0] * nb.e[0]; BM.e[1] += an.e[1] * nb.e[1]; BM.e[2] += an.e[2] * nb.e[2];
             BM.e[3] += an.e[0] * nb.e[1]; BM.e[4] += an.e[0] * nb.e[2]; BM.e[5] += an.e[1] * nb.e[2];
             BA.e[0] += am.e[0] * m.e[0]; BA.e[1] += am.e[1] * m.e[1]; BA.e[2] += am.e[2] * m.e[2];
@@ -735,77 +768,79 @@ BG_HD void foot_contact(const Phys& ph, const TerrainDev& tr, const LegParams& l
             sb += beta;
         }
     }
-    const float trP = P.e[0] + P.e[1] + P.e[2];
-    SI B;
+    const T trP = P.e[0] + P.e[1] + P.e[2];
+    SIT<T> B;
     B.M = BM; B.M.e[0] += sb; B.M.e[1] += sb; B.M.e[2] += sb;
     B.H = BH + skew(sr);
     B.A.e[0] = BA.e[0] + trP - P.e[0]; B.A.e[1] = BA.e[1] + trP - P.e[1]; B.A.e[2] = BA.e[2] + trP - P.e[2];
     B.A.e[3] = BA.e[3] - P.e[3]; B.A.e[4] = BA.e[4] - P.e[4]; B.A.e[5] = BA.e[5] - P.e[5];
     w.Bc = B; w.f0c = f0; w.contact = any;
-    *force_w0 = v3(0.f, 0.f, 0.f);  // (the force that acts over the step comes out of substep_solve: f0 - B a)
+    *force_w0 = v3_zero<T>();  // (the force that acts over the step comes out of substep_solve: f0 - B a)
 }
 
 // ---------------------------------------------------------------- inward sweep, link I (child -> parent)
-template <int I, class W>
-BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, const float* tau, W& w, SI IA, SV pA,
-                      BaseContribution* out, const SV* fext) {
+template <int I, class W, class T = typename W::Scalar>
+BG_HD void leg_inward(const Phys& ph, const LegParamsT<T>& lp, const LegStateT<T>& ls, const T* tau, W& w, SIT<T> IA, SVT<T> pA,
+                      BaseContributionT<T>* out, const SVT<T>* fext) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
     bg_pin(IA); bg_pin(pA);
     BG_PHASE("inward_link");
     // joint limit spring/damper, implicit in the joint velocity: tau_lim = t0 - bl * qdd
-    float viol = ls.q[I] < lp.q_lo[I] ? ls.q[I] - lp.q_lo[I] : (ls.q[I] > lp.q_hi[I] ? ls.q[I] - lp.q_hi[I] : 0.f);
-    float t0 = 0.f, bl = 0.f;
-    if (viol != 0.f) { t0 = -ph.limit_k * viol - ph.limit_d * ls.qd[I]; bl = ph.dt * (ph.limit_d + ph.dt * ph.limit_k); }
+    const T zero = splat<T>(0.f);
+    const T lo = w.st.template q_lo<I>(lp), hi = w.st.template q_hi<I>(lp);
+    const T viol = sel(lt(ls.q[I], lo), ls.q[I] - lo, sel(gt(ls.q[I], hi), ls.q[I] - hi, zero));
+    const auto outside = nonzero(viol);
+    const T t0 = sel(outside, -ph.limit_k * viol - ph.limit_d * ls.qd[I], zero), bl = sel(outside, splat<T>(ph.dt * (ph.limit_d + ph.dt * ph.limit_k)), zero);
     // U = IA S ; d = S.U + bl ; u = tau - S.pA     (S = the unit angular axis A: U is a column of [A; H^T])
-    const M3 Af = full(IA.A);
-    SV U;
-    U.a = v3(Af.e[0][A], Af.e[1][A], Af.e[2][A]);
-    U.l = v3(IA.H.e[A][0], IA.H.e[A][1], IA.H.e[A][2]);
-    float d = U.a.e[A] + bl;
-    float dinv = bg_rcp(d);
-    float u = tau[I] + t0 - pA.a.e[A];
+    const M3T<T> Af = full(IA.A);
+    SVT<T> U;
+    U.a = v3t<T>(Af.e[0][A], Af.e[1][A], Af.e[2][A]);
+    U.l = v3t<T>(IA.H.e[A][0], IA.H.e[A][1], IA.H.e[A][2]);
+    T d = U.a.e[A] + bl;
+    T dinv = bg_rcp(d);
+    T u = w.st.template tau_at<I>(tau) + t0 - pA.a.e[A];
     w.dinv[I] = dinv; w.u[I] = u;
     // Ia = IA - U U^T / d ;  pa = pA + Ia c + U u / d.   A and M stay SYMMETRIC through the update, the rotation and the shift: only their six
     // unique entries are computed (the compiler cannot see the symmetry of a full 3x3 and computed all nine)
-    const V3 Uad = dinv * U.a, Uld = dinv * U.l;
-    S3 A1, M1;
+    const V3T<T> Uad = dinv * U.a, Uld = dinv * U.l;
+    S3T<T> A1, M1;
     A1.e[0] = IA.A.e[0] - Uad.e[0] * U.a.e[0]; A1.e[1] = IA.A.e[1] - Uad.e[1] * U.a.e[1]; A1.e[2] = IA.A.e[2] - Uad.e[2] * U.a.e[2];
     A1.e[3] = IA.A.e[3] - Uad.e[0] * U.a.e[1]; A1.e[4] = IA.A.e[4] - Uad.e[0] * U.a.e[2]; A1.e[5] = IA.A.e[5] - Uad.e[1] * U.a.e[2];
     M1.e[0] = IA.M.e[0] - Uld.e[0] * U.l.e[0]; M1.e[1] = IA.M.e[1] - Uld.e[1] * U.l.e[1]; M1.e[2] = IA.M.e[2] - Uld.e[2] * U.l.e[2];
     M1.e[3] = IA.M.e[3] - Uld.e[0] * U.l.e[1]; M1.e[4] = IA.M.e[4] - Uld.e[0] * U.l.e[2]; M1.e[5] = IA.M.e[5] - Uld.e[1] * U.l.e[2];
-    M3 H1 = IA.H - outer(Uad, U.l);
-    SV cb = w.st.template get_cb<I>();
-    SV pa;
+    M3T<T> H1 = IA.H - outer(Uad, U.l);
+    SVT<T> cb = w.st.template get_cb<I>();
+    SVT<T> pa;
     pa.a = pA.a + mul(A1, cb.a) + mul(H1, cb.l) + u * Uad;
     pa.l = pA.l + mulT(H1, cb.a) + mul(M1, cb.l) + u * Uld;
     // to parent coordinates: rotate by R(axis,q) then shift the origin by r = pos
-    float c = w.c[I], s = w.s[I];
-    const float c2 = c * c - s * s, s2 = 2.0f * c * s;
+    T c = w.c[I], s = w.s[I];
+    const T c2 = c * c - s * s, s2 = 2.0f * c * s;
     A1 = rot_conj_sym<AX>(c, s, c2, s2, A1); M1 = rot_conj_sym<AX>(c, s, c2, s2, M1);
     H1 = rot_conj<AX>(c, s, H1);
-    const V3 r0 = w.st.template link_pos<I>(lp);
-    const M3 M1f = full(M1);
-    M3 H2, A2;
-    SV pp;
+    const V3T<T> r0 = w.st.template link_pos<I>(lp);
+    const M3T<T> M1f = full(M1);
+    M3T<T> H2, A2;
+    SVT<T> pp;
     pp.l = rot<AX>(c, s, pa.l);
     if ((w.zmask >> I) & 1) {  // r = (0, 0, z): wave-uniform branch (Phys::zmask)
-        const V3 r = v3(0.f, 0.f, r0.e[2]);
+        const V3T<T> r = v3t<T>(zero, zero, r0.e[2]);
         H2 = H1 + cross_cols(r, M1f);
         A2 = full(A1) + cross_cols(r, transpose(H1)) - mul_skew(H2, r);
         pp.a = rot<AX>(c, s, pa.a) + cross(r, pp.l);
     } else {
-        const V3 r = r0;
+        const V3T<T> r = r0;
         H2 = H1 + cross_cols(r, M1f);
         A2 = full(A1) + cross_cols(r, transpose(H1)) - mul_skew(H2, r);
         pp.a = rot<AX>(c, s, pa.a) + cross(r, pp.l);
     }
     if constexpr (I > 0) {
         // parent's own rigid inertia and velocity-dependent bias
-        const LinkConst pk = w.st.template link<I - 1>(lp);
-        SI IP = rigid_inertia(pk);
-        SV vp = w.st.template get_v<I - 1>();
+        const LinkConstT<T> pk = w.st.template link<I - 1>(lp);
+        SIT<T> IP = rigid_inertia(pk);
+        SVT<T> vp = w.st.template get_v<I - 1>();
         w.st.template put_U<I>(U);
-        SV pP = crf(vp, mul_rigid(pk, vp));
+        SVT<T> pP = crf(vp, mul_rigid(pk, vp));
         if (fext) pP = pP - fext[I - 1];
         IP.A = IP.A + upper(A2); IP.H = IP.H + H2; IP.M = IP.M + M1;
         leg_inward<I - 1>(ph, lp, ls, tau, w, IP, pP + pp, out, fext);
@@ -816,43 +851,53 @@ BG_HD void leg_inward(const Phys& ph, const LegParams& lp, const LegState& ls, c
     }
 }
 
+// The second half of a lane's work before the trunk: sole contact, foot inertia and bias, inward sweep (w holds the outward sweep's results and
+// the leg-against-leg wrenches).  Returns this leg's (T = f2: both legs') contribution at the trunk.
+template <class W, class T = typename W::Scalar>
+BG_HD BaseContributionT<T> leg_phase1_inward(const Phys& ph, const TerrainDev& tr, const LegParamsT<T>& lp, const LegStateT<T>& ls, const T* tau, const BaseState& bs,
+                                             W& w, SVT<T> vfoot, V3T<T> pfoot_rel, const SVT<T>* fext_in = nullptr) {
+    const V3T<T> pfoot = splat_v3<T>(bs.pos) + pfoot_rel;
+    V3T<T> unused;
+    SVT<T> fext[LEG_LINKS];  // applied wrenches per link: the caller's, plus the leg-against-leg contacts on the shank and the foot
+    for (int i = 0; i < LEG_LINKS; i++) fext[i] = fext_in ? fext_in[i] : svt_zero<T>();
+    fext[SELF_SHANK] = fext[SELF_SHANK] + w.self_fx[0];
+    fext[SELF_FOOT] = fext[SELF_FOOT] + w.self_fx[1];
+    foot_contact(ph, tr, lp, w, vfoot, pfoot, &unused);
+    bg_pin(w.Bc); bg_pin(w.f0c);
+    BG_PHASE("foot_inertia_bias");
+    const LinkConstT<T> fk = w.st.template link<LEG_LINKS - 1>(lp);
+    SIT<T> IA = rigid_inertia(fk);
+    SVT<T> pA = crf(vfoot, mul_rigid(fk, vfoot));
+    pA = pA - fext[LEG_LINKS - 1];
+    if (w.contact) {
+        // f_ext = f0 - B a_true = (f0 - B ag) - B a'   with a' = a_true - ag  (gravity field in foot coords)
+        SVT<T> ag; ag.a = v3_zero<T>(); ag.l = mulT(w.Rfoot, splat_v3<T>(ph.g));
+        SVT<T> Bag = mul(w.Bc, ag);
+        IA.A = IA.A + w.Bc.A; IA.H = IA.H + w.Bc.H; IA.M = IA.M + w.Bc.M;
+        pA = pA - (w.f0c - Bag);
+    }
+    BaseContributionT<T> out;
+    leg_inward<LEG_LINKS - 1>(ph, lp, ls, tau, w, IA, pA, &out, fext);
+    return out;
+}
+
 // Everything a lane does before the pair exchange: kinematics, contact, inward sweep.
 // gb = gravity in base coordinates.  Returns this leg's contribution at the trunk.
 // fext (optional): applied wrench on each link about its own origin, link coordinates (a = torque, l = force).
-template <int SELF, class W, class X>
-BG_HD BaseContribution leg_phase1(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int leg, const LegParams& lp, const LegState& ls, const float* tau,
-                                  const BaseState& bs, M3 R0, SV v0, W& w, X& x, V3* foot_force_w0, const SV* fext_in = nullptr) {
+template <int SELF, class W, class X, class T = typename W::Scalar>
+BG_HD BaseContributionT<T> leg_phase1(const Phys& ph, const TerrainDev& tr, const ModelDev& M, int leg, const LegParamsT<T>& lp, const LegStateT<T>& ls, const T* tau,
+                                      const BaseState& bs, M3 R0, SV v0, W& w, X& x, V3T<T>* foot_force_w0, const SVT<T>* fext_in = nullptr) {
     w.zmask = decltype(w.st)::ZSPEC ? ph.zmask : 0;
 #ifdef BG_CENSUS_ZMASK   // tools/isa_census.py --t1: count what a T1 launch executes (the wave-uniform branches on zmask resolved at compile time)
     w.zmask = BG_CENSUS_ZMASK;
 #endif
-    SV vfoot;
-    V3 pfoot_rel;  // link origins are carried RELATIVE to the trunk origin: the leg-against-leg distances must not lose digits to the world position
-    leg_outward<0>(lp, ls, w, v0, R0, v3(0.f, 0.f, 0.f), &vfoot, &pfoot_rel);
-    const V3 pfoot = bs.pos + pfoot_rel;
+    SVT<T> vfoot;
+    V3T<T> pfoot_rel;  // link origins are carried RELATIVE to the trunk origin: the leg-against-leg distances must not lose digits to the world position
+    leg_outward<0>(lp, ls, w, splat_sv<T>(v0), splat_m3<T>(R0), v3_zero<T>(), &vfoot, &pfoot_rel);
     BG_PHASE("self_clearance");
     self_contacts<SELF>(ph, M, leg, w, R0, pfoot_rel, vfoot, x);
-    SV fext[LEG_LINKS];  // applied wrenches per link: the caller's, plus the leg-against-leg contacts on the shank and the foot
-    for (int i = 0; i < LEG_LINKS; i++) fext[i] = fext_in ? fext_in[i] : sv_zero();
-    fext[SELF_SHANK] = fext[SELF_SHANK] + w.self_fx[0];
-    fext[SELF_FOOT] = fext[SELF_FOOT] + w.self_fx[1];
-    foot_contact(ph, tr, lp, w, vfoot, pfoot, foot_force_w0);
-    bg_pin(w.Bc); bg_pin(w.f0c);
-    BG_PHASE("foot_inertia_bias");
-    const LinkConst fk = w.st.template link<LEG_LINKS - 1>(lp);
-    SI IA = rigid_inertia(fk);
-    SV pA = crf(vfoot, mul_rigid(fk, vfoot));
-    pA = pA - fext[LEG_LINKS - 1];
-    if (w.contact) {
-        // f_ext = f0 - B a_true = (f0 - B ag) - B a'   with a' = a_true - ag  (gravity field in foot coords)
-        SV ag; ag.a = v3(0.f, 0.f, 0.f); ag.l = mulT(w.Rfoot, ph.g);
-        SV Bag = mul(w.Bc, ag);
-        IA.A = IA.A + w.Bc.A; IA.H = IA.H + w.Bc.H; IA.M = IA.M + w.Bc.M;
-        pA = pA - (w.f0c - Bag);
-    }
-    BaseContribution out;
-    leg_inward<LEG_LINKS - 1>(ph, lp, ls, tau, w, IA, pA, &out, fext);
-    return out;
+    *foot_force_w0 = v3_zero<T>();  // (the force that acts over the step comes out of substep_solve: f0 - B a)
+    return leg_phase1_inward(ph, tr, lp, ls, tau, bs, w, vfoot, pfoot_rel, fext_in);
 }
 
 // Trunk: solve  IA0 a0' = -pA0  by block elimination on the 3x3 blocks.
@@ -869,21 +914,21 @@ BG_HD SV base_solve(const SI& I, SV p) {
 }
 
 // ---------------------------------------------------------------- outward acceleration sweep + joint integration
-template <int I, class W>
-BG_HD void leg_accel(const Phys& ph, const LegParams& lp, LegState& ls, const W& w, SV apar, float* qdd, SV* afoot) {
+template <int I, class W, class T = typename W::Scalar>
+BG_HD void leg_accel(const Phys& ph, const LegParamsT<T>& lp, LegStateT<T>& ls, const W& w, SVT<T> apar, T* qdd, SVT<T>* afoot) {
     constexpr int AX = LEG_AXIS[I], A = AX - 1;
     bg_pin(apar);
     BG_PHASE("accel_link");
-    float c = w.c[I], s = w.s[I];
-    SV a;
+    T c = w.c[I], s = w.s[I];
+    SVT<T> a;
     a.a = rotT<AX>(c, s, apar.a);
-    const V3 lpos = w.st.template link_pos<I>(lp);
-    V3 alin;
-    if ((w.zmask >> I) & 1) alin = apar.l + cross(apar.a, v3(0.f, 0.f, lpos.e[2]));  // r = (0, 0, z): wave-uniform branch (Phys::zmask)
+    const V3T<T> lpos = w.st.template link_pos<I>(lp);
+    V3T<T> alin;
+    if ((w.zmask >> I) & 1) alin = apar.l + cross(apar.a, v3t<T>(splat<T>(0.f), splat<T>(0.f), lpos.e[2]));  // r = (0, 0, z): wave-uniform branch (Phys::zmask)
     else alin = apar.l + cross(apar.a, lpos);
     a.l = rotT<AX>(c, s, alin);
     a = a + w.st.template get_cb<I>();
-    float qa = (w.u[I] - dot(w.st.template get_U<I>(), a)) * w.dinv[I];
+    T qa = (w.u[I] - dot(w.st.template get_U<I>(), a)) * w.dinv[I];
     a.a.e[A] += qa;
     qdd[I] = qa;
     if constexpr (I + 1 < LEG_LINKS) leg_accel<I + 1>(ph, lp, ls, w, a, qdd, afoot);
@@ -997,20 +1042,24 @@ BG_HD void leg_body_states(const LegParams& lp, const LegState& ls, SV vpar, M3 
 
 // nominal body + per-env randomisation (mass scale, com offset; inertia scales with the mass as
 // Isaac Gym's recomputeInertia=True does, reference t1.py:129-131) -> constants about the body origin
-BG_HD LinkConst make_link(const ModelDev& m, int b, float mass_scale, V3 com_off) {
-    LinkConst k;
-    k.pos = v3(m.pos[b][0], m.pos[b][1], m.pos[b][2]);
-    k.m = m.mass[b] * mass_scale;
-    V3 c = v3(m.com[b][0], m.com[b][1], m.com[b][2]) + com_off;
+template <class T>
+BG_HD LinkConstT<T> make_link_t(V3T<T> pos, T mass, V3T<T> com, const T* inertia /*[6] about the centre of mass*/, T mass_scale, V3T<T> com_off) {
+    LinkConstT<T> k;
+    k.pos = pos;
+    k.m = mass * mass_scale;
+    V3T<T> c = com + com_off;
     k.mc = k.m * c;
-    float cc = dot(c, c);
-    k.Io.e[0] = m.inertia[b][0] * mass_scale + k.m * (cc - c.e[0] * c.e[0]);
-    k.Io.e[1] = m.inertia[b][1] * mass_scale + k.m * (cc - c.e[1] * c.e[1]);
-    k.Io.e[2] = m.inertia[b][2] * mass_scale + k.m * (cc - c.e[2] * c.e[2]);
-    k.Io.e[3] = m.inertia[b][3] * mass_scale - k.m * c.e[0] * c.e[1];
-    k.Io.e[4] = m.inertia[b][4] * mass_scale - k.m * c.e[0] * c.e[2];
-    k.Io.e[5] = m.inertia[b][5] * mass_scale - k.m * c.e[1] * c.e[2];
+    T cc = dot(c, c);
+    k.Io.e[0] = inertia[0] * mass_scale + k.m * (cc - c.e[0] * c.e[0]);
+    k.Io.e[1] = inertia[1] * mass_scale + k.m * (cc - c.e[1] * c.e[1]);
+    k.Io.e[2] = inertia[2] * mass_scale + k.m * (cc - c.e[2] * c.e[2]);
+    k.Io.e[3] = inertia[3] * mass_scale - k.m * c.e[0] * c.e[1];
+    k.Io.e[4] = inertia[4] * mass_scale - k.m * c.e[0] * c.e[2];
+    k.Io.e[5] = inertia[5] * mass_scale - k.m * c.e[1] * c.e[2];
     return k;
+}
+BG_HD LinkConst make_link(const ModelDev& m, int b, float mass_scale, V3 com_off) {
+    return make_link_t<float>(v3(m.pos[b][0], m.pos[b][1], m.pos[b][2]), m.mass[b], v3(m.com[b][0], m.com[b][1], m.com[b][2]), m.inertia[b], mass_scale, com_off);
 }
 
 struct ContactCfg { float k, d, terrain_mu, terrain_restitution; };
@@ -1092,6 +1141,17 @@ BG_HD BaseContribution substep_pre(const Phys& ph, const TerrainDev& tr, const M
         return out;
     }
 }
+// net contact force on the foot in the world frame: terrain (the force that acts over the step: f0 - B a_true) + the other leg
+template <class W, class T = typename W::Scalar>
+BG_HD V3T<T> foot_force_over_step(const Phys& ph, const W& w, SVT<T> afoot) {
+    V3T<T> fw = v3_zero<T>();
+    if (w.contact) {
+        SVT<T> at = afoot; at.l = at.l + mulT(w.Rfoot, splat_v3<T>(ph.g));
+        V3T<T> fb = w.f0c.l - (mulT(w.Bc.H, at.a) + mul(w.Bc.M, at.l));
+        fw = mul(w.Rfoot, fb);
+    }
+    return fw + w.self_foot;
+}
 // `both` = this leg's contribution + the partner leg's.  Returns accelerations; does not integrate.
 template <class Ctx>
 BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& lp, LegState& ls, const Ctx& cx, const BaseContribution& both,
@@ -1105,13 +1165,7 @@ BG_HD void substep_solve(const Phys& ph, const LinkConst& bk, const LegParams& l
     bg_pin(afoot); bg_pin(a0p);
     BG_PHASE("rates_and_foot_force");
     base_world_rates(cx.R0, cx.v0, a0p, ph.g, lin_w, ang_w);
-    V3 fw = v3(0.f, 0.f, 0.f);
-    if (cx.w.contact) {  // force that acts over the step: f0 - B a_true
-        SV at = afoot; at.l = at.l + mulT(cx.w.Rfoot, ph.g);
-        V3 fb = cx.w.f0c.l - (mulT(cx.w.Bc.H, at.a) + mul(cx.w.Bc.M, at.l));
-        fw = mul(cx.w.Rfoot, fb);
-    }
-    *foot_force_w = fw + cx.w.self_foot;  // net contact force on the foot: terrain (over the step) + the other leg
+    *foot_force_w = foot_force_over_step(ph, cx.w, afoot);
 }
 BG_HD void substep_integrate(const Phys& ph, const LegParams& lp, LegState& ls, BaseState& bs, const float* qdd, V3 lin_w, V3 ang_w) {
     integrate_leg(ph, lp, ls, qdd);
