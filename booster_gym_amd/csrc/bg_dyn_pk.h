@@ -38,41 +38,15 @@ inline PairModel make_pair_model(const ModelDev& m) {
     return p;
 }
 
-// The inputs of one env, one 4-byte slot each.  The kernel keeps them in LDS, lane-contiguous (slot k of lane l at in[64 k + l]), filled by
-// asynchronous global -> LDS copies one block of envs ahead (bg_sim.hip: forward_dynamics_pk_kernel), and the lane code fetches a value WHERE it
-// uses it: the 76 "late" slots (torques, applied wrench, per-env link parameters, foot materials) never occupy registers during the outward sweep.
-// The host harness reads the same slots from a plain array (one env, stride 1).
-struct PkSlots { enum { ROOT = 0, Q = 13, QD = 25, EARLY_END = 37, TAU = 37, WRENCH = 49, MS = 55, CO = 68, FM = 107, COUNT = 113 }; };
-// STRIDE = 64: the kernel's LDS buffer.  Slot k of lane l at in[64 k + l], except the three 12-float rows (q, qd, tau), which arrive as three
-// 16-byte copies per lane: row element 4 g + c of lane l at in[64 (slot0 + 4 g) + 4 l + c] (read back with 16-byte LDS reads, conflict-free).
-// STRIDE = 1 (host harness): a plain array of the 113 slots of one env.
-template <int STRIDE>
+// The inputs of one env, one 4-byte slot each (constant slot indices: every entry is a register on the GPU; the host harness fills the same array)
+struct PkSlots { enum { ROOT = 0, Q = 13, QD = 25, TAU = 37, WRENCH = 49, MS = 55, CO = 68, FM = 107, COUNT = 113 }; };
 struct PkInputs {
-#if defined(__HIP_DEVICE_COMPILE__)
-    const volatile lds_f32* base;  // volatile: a plain load would be hoisted to the top of the kernel and the value would sit in registers after all
-#else
-    const float* base;
-#endif
-    int lane;
+    float v[PkSlots::COUNT];
     bool has_wrench;
-    BG_HD float get(int slot) const { return base[slot * STRIDE + lane]; }
-    BG_HD f2 pair(int slot_l, int slot_r) const { return mk2(get(slot_l), get(slot_r)); }
+    BG_HD float get(int slot) const { return v[slot]; }
+    BG_HD f2 pair(int slot_l, int slot_r) const { return mk2(v[slot_l], v[slot_r]); }
     // a 12-float row as (left, right) pairs: element i of the left leg with element 6 + i of the right
-    BG_HD void row(int slot0, f2* out) const {
-        float r[12];
-        if (STRIDE == 1) { for (int j = 0; j < 12; j++) r[j] = base[slot0 + j]; }
-        else {
-#if defined(__HIP_DEVICE_COMPILE__)
-            typedef float f4 __attribute__((ext_vector_type(4)));
-            typedef __attribute__((address_space(3))) f4 lds_f4;
-            for (int g = 0; g < 3; g++) {
-                const f4 v = *(const volatile lds_f4*)((lds_f32*)base + (slot0 + 4 * g) * 64 + 4 * lane);
-                r[4 * g] = v[0]; r[4 * g + 1] = v[1]; r[4 * g + 2] = v[2]; r[4 * g + 3] = v[3];
-            }
-#endif
-        }
-        for (int i = 0; i < LEG_LINKS; i++) out[i] = mk2(r[i], r[LEG_LINKS + i]);
-    }
+    BG_HD void row(int slot0, f2* out) const { for (int i = 0; i < LEG_LINKS; i++) out[i] = mk2(v[slot0 + i], v[slot0 + LEG_LINKS + i]); }
     BG_HD f2 mass_scale(int i) const { return pair(PkSlots::MS + 1 + i, PkSlots::MS + 1 + LEG_LINKS + i); }
     BG_HD V3T<f2> com_off(int i) const {
         const int l = PkSlots::CO + 3 * (1 + i), r = PkSlots::CO + 3 * (1 + LEG_LINKS + i);
@@ -82,12 +56,12 @@ struct PkInputs {
 
 // Sweep work space of the packed kernel: v / cb / U in registers (two per value); link constants cooked from the RAW per-env parameters (mass
 // scale + centre-of-mass offset per link, 4 values) where the inward sweep uses them, each exactly once; joint ranges and link origins straight
-// from the PairModel (scalar loads).
-template <class In>
-struct PkStoreT : RegStoreT<f2> {
+// from the PairModel (scalar loads).  (Round 5 also measured U and cb handed over through LDS as 64-bit lane-contiguous values -- 115 fewer VALU
+// instructions per wave, 1 % slower -- and the inputs copied into LDS a block ahead by a persistent grid -- 20 % slower: HISTORY.md.)
+struct PkStore : RegStoreT<f2> {
     static constexpr bool ZSPEC = true, PLANE_SPEC = true;  // throughput-bound like round 4's ABA kernel: fewer issued instructions pay directly
     const PairModel* pm;
-    In in;
+    PkInputs in;
     template <int I, class LP> BG_HD V3T<f2> link_pos(const LP&) const { return v3t<f2>(pm->pos[I][0], pm->pos[I][1], pm->pos[I][2]); }
     template <int I, class LP> BG_HD LinkConstT<f2> link(const LP& lp) const {
         return make_link_t<f2>(link_pos<I>(lp), pm->mass[I], v3t<f2>(pm->com[I][0], pm->com[I][1], pm->com[I][2]), pm->inertia[I], in.mass_scale(I), in.com_off(I));
@@ -95,6 +69,7 @@ struct PkStoreT : RegStoreT<f2> {
     template <int I, class LP> BG_HD f2 q_lo(const LP&) const { return pm->q_lo[I]; }
     template <int I, class LP> BG_HD f2 q_hi(const LP&) const { return pm->q_hi[I]; }
 };
+struct PkCtx { M3 R0; SV v0; LegWorkT<PkStore> w; };
 
 // ---------------------------------------------------------------- leg against leg, one env per lane
 constexpr int SELF_PK = 3;  // (continues the SELF_* modes of bg_dyn.h)
@@ -300,13 +275,9 @@ BG_HD void pk_foot_params(const ContactCfg& cc, f2 mu_f, f2 compl_f, f2 rest_f, 
     lp.kn = cc.k * bg_rcp(compl_f);
     lp.dn = cc.d * (1.0f - 0.5f * (rest_f + cc.terrain_restitution));
 }
-template <class In> struct PkCtxT { M3 R0; SV v0; LegWorkT<PkStoreT<In>> w; };
-// cx.w.st.pm / .in and cx.w.self_sc / .self_lane are set by the caller.  late(): called once, before the first late slot is read (the kernel waits
-// there for the copies of the late slots).  qdd[i] = (left, right) joint i; foot_force = world frame, per foot.
-template <class In, class Late>
-BG_HD void pk_forward_env(const Phys& ph, const ContactCfg& cc, const TerrainDev& tr, const ModelDev& M, PkCtxT<In>& cx, Late&& late, f2* qdd, V3* lin_w, V3* ang_w,
-                          V3T<f2>* foot_force) {
-    const In& in = cx.w.st.in;
+// cx.w.st.pm / .in and (GPU) cx.w.self_sc / .self_lane are set by the caller.  qdd[i] = (left, right) joint i; foot_force = world frame, per foot.
+BG_HD void pk_forward_env(const Phys& ph, const ContactCfg& cc, const TerrainDev& tr, const ModelDev& M, PkCtx& cx, f2* qdd, V3* lin_w, V3* ang_w, V3T<f2>* foot_force) {
+    const PkInputs& in = cx.w.st.in;
     BG_PHASE("load_state");
     BaseState bs;
     bs.pos = v3(in.get(PkSlots::ROOT), in.get(PkSlots::ROOT + 1), in.get(PkSlots::ROOT + 2));
@@ -318,8 +289,7 @@ BG_HD void pk_forward_env(const Phys& ph, const ContactCfg& cc, const TerrainDev
     BG_PHASE("base_kinematics");
     cx.R0 = quat_to_mat(bs.quat);
     cx.v0 = base_body_velocity(cx.R0, bs);
-    // outward sweep and leg-against-leg contacts first (early slots only), then the late slots: foot materials, torques, link parameters
-    LegWorkT<PkStoreT<In>>& w = cx.w;
+    LegWorkT<PkStore>& w = cx.w;
     w.zmask = ph.zmask;
 #ifdef BG_CENSUS_ZMASK
     w.zmask = BG_CENSUS_ZMASK;
@@ -332,7 +302,6 @@ BG_HD void pk_forward_env(const Phys& ph, const ContactCfg& cc, const TerrainDev
     BG_PHASE("self_clearance");
     NoSwap x;
     self_contacts<SELF_PK>(ph, M, 0, w, cx.R0, pfoot_rel, vfoot, x);
-    late();
     pk_foot_params(cc, in.pair(PkSlots::FM, PkSlots::FM + 3), in.pair(PkSlots::FM + 1, PkSlots::FM + 4), in.pair(PkSlots::FM + 2, PkSlots::FM + 5), lp);
     f2 tau[LEG_LINKS];
     in.row(PkSlots::TAU, tau);

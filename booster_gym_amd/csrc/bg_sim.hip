@@ -4,7 +4,6 @@
 // the kernel is latency-bound per wave, so each wave gets a whole CU (LDS, scalar unit, I-cache).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
-#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <vector>
@@ -335,115 +334,59 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) void
 }
 // The packed ABA kernel (round 5): one ENV per lane, its two legs in the halves of 64-bit register pairs (bg_dyn_pk.h), 64 envs per one-wave
 // workgroup.  The sweeps issue v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 for both legs at once, the trunk is computed once per env, the legs'
-// contributions meet without a lane exchange.  ~2 x the registers of the lane-per-leg form, so ONE wave per SIMD -- and a lone wave hides no
-// latency by itself.  Hence: a persistent grid (PK_GRID workgroups walk the 64-env blocks) whose waves copy the inputs of their NEXT block into LDS
-// with asynchronous global -> LDS loads (global_load_lds_dword: no register stop, lane-contiguous slots, bg_dyn_pk.h:PkSlots) while they compute the
-// current one, and read every input from LDS where it is used:
-//   early slots (root state, q, qd: read at the top of a block)  -> the copies for block k+1 are issued right after block k has read its own;
-//   late slots (torques, wrench, per-env parameters: read from the sole contact to the trunk solve) -> issued right after block k's trunk solve.
-// The copies are inline asm (known to the compiler they would cost a vmcnt(0) in front of every LDS read); their bookkeeping is explicit:
-//   * top of a block: the early copies are older than the >= 64 vector-memory instructions issued since (late copies + the block's stores), and a
-//     wave has at most 64 in flight, in order -- they have completed (static_assert below);
-//   * before the first late read: s_waitcnt vmcnt(PK_EARLY) -- everything but the early copies issued since.
-// Copy instructions per block: early = root 13 x 4 B + q, qd 3 x 16 B each; late = tau 3 x 16 B + wrench 6 x 4 B + 58 parameter fields x 4 B.
-constexpr int PK_GRID_PER_CU = 4, PK_EARLY = 13 + 3 + 3, PK_LATE = 3 + 6 + 58, PK_STORES = 24;
-static_assert(PK_LATE + PK_STORES >= 64, "the early copies of a block must have left the 64-deep vector-memory queue by the top of that block");
-static_assert(PK_EARLY <= 63, "vmcnt immediate");
-struct PkSrc {   // global sources: array bases (block offsets are added per copy run) and the slab of the 58 per-env parameter fields, n floats apart
-    const float *root, *q, *qd, *tau, *wrench, *params;
-    int n;
-};
-// One run of copies from one array: `count` instructions of W dwords per lane; per instruction the lane offset advances by `vstep` bytes and the LDS
-// destination by 256 W bytes (64 lanes x 4 W).  Everything that changes per instruction changes INSIDE the asm: known to the compiler, 113 addresses
-// per block become 113 loop-carried scalar induction variables of the persistent loop (measured: 750 v_readlane / v_writelane of spilled SGPRs).
-// M0 is written here; it cannot be named as a clobber (reserved), the backend never keeps a value of its own live in M0 across an inline asm
-// (bg_mlp_chain.hip:dma_rows).
-template <int W, int COUNT>
-__device__ __forceinline__ void pk_copy_run(const float* base, unsigned lane_ofs, unsigned vstep, lds_f32* dst) {
-    unsigned v = lane_ofs, l = (unsigned)(uintptr_t)dst;
-#pragma unroll
-    for (int k = 0; k < COUNT; k++) {
-        if (W == 1) asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, %2\n\tv_add_u32 %0, %3, %0\n\ts_addk_i32 %1, 0x100" : "+v"(v), "+s"(l) : "s"(base), "s"(vstep) : "memory", "scc");
-        else asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %2\n\tv_add_u32 %0, %3, %0\n\ts_addk_i32 %1, 0x400" : "+v"(v), "+s"(l) : "s"(base), "s"(vstep) : "memory", "scc");
-    }
-}
-__device__ __forceinline__ void pk_copy_early(const PkSrc& S, int block, int lane, lds_f32* in) {
-    const size_t e0 = (size_t)block * 64;
-    pk_copy_run<1, 13>(S.root + e0 * 13, lane * 52u, 4u, in + PkSlots::ROOT * 64);
-    pk_copy_run<4, 3>(S.q + e0 * 12, lane * 48u, 16u, in + PkSlots::Q * 64);
-    pk_copy_run<4, 3>(S.qd + e0 * 12, lane * 48u, 16u, in + PkSlots::QD * 64);
-}
-__device__ __forceinline__ void pk_copy_late(const PkSrc& S, int block, int lane, lds_f32* in) {
-    const size_t e0 = (size_t)block * 64;
-    pk_copy_run<4, 3>(S.tau + e0 * 12, lane * 48u, 16u, in + PkSlots::TAU * 64);
-    // (no wrench: six copies are issued all the same, from the root rows: the number of copies per block is a constant of the vmcnt bookkeeping)
-    if (S.wrench) pk_copy_run<1, 6>(S.wrench + e0 * 6, lane * 24u, 4u, in + PkSlots::WRENCH * 64);
-    else pk_copy_run<1, 6>(S.root + e0 * 13, lane * 52u, 4u, in + PkSlots::WRENCH * 64);
-    pk_copy_run<1, 58>(S.params + e0, lane * 4u, (unsigned)S.n * 4u, in + PkSlots::MS * 64);
-}
-template <int N> __device__ __forceinline__ void pk_wait_vm() { __builtin_amdgcn_s_waitcnt((N & 15) | ((N >> 4) << 14) | 0x0F70); }  // vmcnt(N) only
-
+// contributions meet without a lane exchange.  ~2 x the registers of the lane-per-leg form, so ONE wave per SIMD.
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) void forward_dynamics_pk_kernel(
     EnvDev E, const PairModel* __restrict__ pm, const float* __restrict__ root, const float* __restrict__ q, const float* __restrict__ qd,
-    const float* __restrict__ tau, const float* __restrict__ wrench, float* __restrict__ qacc, int nblocks) {
-    __shared__ float s_in[PkSlots::COUNT * 64];
+    const float* __restrict__ tau, const float* __restrict__ wrench, float* __restrict__ qacc) {
     __shared__ float s_self[SelfPk::END];
     const int lane = threadIdx.x, n = E.n;
+    int e = blockIdx.x * 64 + lane;
+    const bool valid = e < n;
+    if (!valid) e = n - 1;
+    BG_PHASE("load_inputs");
     Phys ph = make_phys(E.cfg);
     ph.zmask = E.zmask;
     const ContactCfg cc = make_contact_cfg(E.cfg);
-    // the last block may be ragged: its lanes beyond n read env n - 1 (clamped per-lane offsets), compute, and do not store
-    PkSrc S;
-    S.root = root; S.q = q; S.qd = qd; S.tau = tau; S.wrench = wrench; S.params = E.f + (size_t)F_MASS_SCALE * n; S.n = n;
-    lds_f32* in = (lds_f32*)s_in;
-    int b = blockIdx.x;
-    if (b >= nblocks) return;
-    const int tail = n - (nblocks - 1) * 64;  // envs of the last block
-    // per-lane source offsets are in envs of the block; a ragged last block clamps them (wave-uniform test per block)
-    auto lane_in = [&](int block) { return (block == nblocks - 1 && lane >= tail) ? tail - 1 : lane; };
-    pk_copy_early(S, b, lane_in(b), in);
-    pk_copy_late(S, b, lane_in(b), in);
-    for (; b < nblocks; b += gridDim.x) {
-        const int nb = b + gridDim.x;
-        // the model constants are re-loaded (scalar cache) where each block uses them: hoisted out of the persistent loop -- which is what the compiler
-        // does with loads from a loop-invariant pointer -- they are ~250 live scalar registers, spilled to vector lanes and read back with v_readlane
-        const PairModel* pmi = pm;
-        const ModelDev* mdi = E.model;
-        asm volatile("" : "+s"(pmi), "+s"(mdi));
-        PkCtxT<PkInputs<64>> cx;
-        cx.w.st.pm = pmi;
-        cx.w.st.in.base = (decltype(cx.w.st.in.base))in; cx.w.st.in.lane = lane;
-        cx.w.st.in.has_wrench = wrench != nullptr;
-        cx.w.self_sc = (lds_f32*)s_self; cx.w.self_lane = lane;
-        if (b == (int)blockIdx.x) pk_wait_vm<0>();  // the first block of this wave: its copies were issued just now
-        f2 qdd[LEG_LINKS];
-        V3 lin_w, ang_w;
-        V3T<f2> fw;
-        // `late` runs after the outward sweep has read the early slots (their reads have returned: the clearance test used them): now the early
-        // slots may be overwritten -- issue the next block's early copies -- and the late slots of THIS block must have arrived
-        pk_forward_env(ph, cc, E.terrain, *mdi, cx,
-                       [&]() {
-                           __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): every early LDS read of this block has returned
-                           if (nb < nblocks) { pk_copy_early(S, nb, lane_in(nb), in); pk_wait_vm<PK_EARLY>(); }
-                           else pk_wait_vm<0>();
-                       },
-                       qdd, &lin_w, &ang_w, &fw);
-        bg_pin(lin_w); bg_pin(ang_w); bg_pin(fw);
-        BG_PHASE("store");
-        // every late slot has been read (the trunk solve took the last ones): the next block's late copies
-        __builtin_amdgcn_s_waitcnt(0xC07F);
-        if (nb < nblocks) pk_copy_late(S, nb, lane_in(nb), in);
-        const int e = b * 64 + lane;
-        if (e < n) {
-            float* o = qacc + (size_t)e * 18;
+    PkCtx cx;
+    PkInputs& in = cx.w.st.in;
+    {
+        const float* r = root + (size_t)e * 13;
 #pragma unroll
-            for (int a = 0; a < 3; a++) { o[a] = lin_w.e[a]; o[3 + a] = ang_w.e[a]; }
+        for (int k = 0; k < 13; k++) in.v[PkSlots::ROOT + k] = r[k];
+        // [N][12] rows are 48 bytes: three 16-byte loads per array
+        const float4* q4 = (const float4*)(q + (size_t)e * 12);
+        const float4* d4 = (const float4*)(qd + (size_t)e * 12);
+        const float4* t4 = (const float4*)(tau + (size_t)e * 12);
 #pragma unroll
-            for (int i = 0; i < LEG_LINKS; i++) { o[6 + i] = qdd[i][0]; o[12 + i] = qdd[i][1]; }
-#pragma unroll
-            for (int a = 0; a < 3; a++) { E.f[(size_t)(F_CONTACT + a) * n + e] = fw.e[a][0]; E.f[(size_t)(F_CONTACT + 3 + a) * n + e] = fw.e[a][1]; }
+        for (int k = 0; k < 3; k++) {
+            const float4 a = q4[k], b = d4[k], c = t4[k];
+            in.v[PkSlots::Q + 4 * k] = a.x; in.v[PkSlots::Q + 4 * k + 1] = a.y; in.v[PkSlots::Q + 4 * k + 2] = a.z; in.v[PkSlots::Q + 4 * k + 3] = a.w;
+            in.v[PkSlots::QD + 4 * k] = b.x; in.v[PkSlots::QD + 4 * k + 1] = b.y; in.v[PkSlots::QD + 4 * k + 2] = b.z; in.v[PkSlots::QD + 4 * k + 3] = b.w;
+            in.v[PkSlots::TAU + 4 * k] = c.x; in.v[PkSlots::TAU + 4 * k + 1] = c.y; in.v[PkSlots::TAU + 4 * k + 2] = c.z; in.v[PkSlots::TAU + 4 * k + 3] = c.w;
         }
+        in.has_wrench = wrench != nullptr;
+#pragma unroll
+        for (int k = 0; k < 6; k++) in.v[PkSlots::WRENCH + k] = wrench ? wrench[(size_t)e * 6 + k] : 0.f;
+        const float* par = E.f + (size_t)F_MASS_SCALE * n + e;   // the 58 per-env parameter fields, n floats apart
+#pragma unroll
+        for (int k = 0; k < 58; k++) in.v[PkSlots::MS + k] = par[(size_t)k * n];
     }
+    cx.w.st.pm = pm;
+    cx.w.self_sc = (lds_f32*)s_self; cx.w.self_lane = lane;
+    f2 qdd[LEG_LINKS];
+    V3 lin_w, ang_w;
+    V3T<f2> fw;
+    pk_forward_env(ph, cc, E.terrain, *E.model, cx, qdd, &lin_w, &ang_w, &fw);
+    bg_pin(lin_w); bg_pin(ang_w); bg_pin(fw);
+    BG_PHASE("store");
+    if (!valid) return;
+    float* o = qacc + (size_t)e * 18;
+#pragma unroll
+    for (int a = 0; a < 3; a++) { o[a] = lin_w.e[a]; o[3 + a] = ang_w.e[a]; }
+#pragma unroll
+    for (int i = 0; i < LEG_LINKS; i++) { o[6 + i] = qdd[i][0]; o[12 + i] = qdd[i][1]; }
+#pragma unroll
+    for (int a = 0; a < 3; a++) { E.f[(size_t)(F_CONTACT + a) * n + e] = fw.e[a][0]; E.f[(size_t)(F_CONTACT + 3 + a) * n + e] = fw.e[a][1]; }
 }
 // masks of kernel A -> compact list of env indices (count in left_count[0]); one atomic per 256 blocks
 __global__ __launch_bounds__(256) void aba_compact_kernel(const unsigned* __restrict__ left_mask, int nblocks, int* __restrict__ left_list, unsigned* __restrict__ left_count) {
@@ -1054,13 +997,7 @@ extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float
     if (!e || !root || !q || !qd || !tau || !qacc) return fail(-1, "bg_env_forward_dynamics: null argument");
     const int nb = (e->n + ENVS_PER_BLOCK - 1) / ENVS_PER_BLOCK;
     dim3 grid(nb), block(64);
-    static const bool pk = getenv("BG_ABA_PK") ? atoi(getenv("BG_ABA_PK")) != 0 : true;  // (A/B while the packed kernel is being brought up)
-    if (!e->body_two_kernel && pk)
-    {
-        const int nblocks = (e->n + 63) / 64, cap = PK_GRID_PER_CU * e->num_cus;
-        hipLaunchKernelGGL(forward_dynamics_pk_kernel, dim3(nblocks < cap ? nblocks : cap), block, 0, (hipStream_t)stream, env_dev(e), e->pair_dev, root, q, qd, tau, wrench, qacc, nblocks);
-    }
-    else if (!e->body_two_kernel) hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, (unsigned*)nullptr);
+    if (!e->body_two_kernel) hipLaunchKernelGGL(forward_dynamics_kernel<false>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, (unsigned*)nullptr);
     else {
         hipLaunchKernelGGL(forward_dynamics_kernel<true>, grid, block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau, wrench, qacc, e->fd_mask);
         // kernel B: one wave per SIMD, 1024 resident workgroups walk the list
@@ -1068,6 +1005,18 @@ extern "C" int bg_env_forward_dynamics(bg_env* e, const float* root, const float
         hipLaunchKernelGGL(forward_dynamics_body_kernel<true>, dim3(nb < 1024 ? nb : 1024), block, 0, (hipStream_t)stream, env_dev(e), root, q, qd, tau,
                            wrench, qacc, (const int*)e->fd_list, e->fd_count);
     }
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+// The same accelerations from the packed kernel (one env per lane, bg_dyn_pk.h).  43 % fewer VALU instructions per env than the lane-per-leg
+// kernel and 3-5 % SLOWER at 1 M envs (215-218 against 208 us on one box): ~420 registers = one wave per SIMD, and a lone wave keeps the vector
+// ALU busy 55 % of its life (profiles/r05_aba_pk_*.json, HISTORY.md).  Not available with the trunk-low gate (non-foot body contacts).
+extern "C" int bg_env_forward_dynamics_packed(bg_env* e, const float* root, const float* q, const float* qd, const float* tau, const float* wrench,
+                                              float* qacc, void* stream) {
+    if (!e || !root || !q || !qd || !tau || !qacc) return fail(-1, "bg_env_forward_dynamics_packed: null argument");
+    if (e->body_two_kernel) return fail(-4, "bg_env_forward_dynamics_packed: not available when the non-foot body contacts can occur (body_gate_height > terminate_height)");
+    hipLaunchKernelGGL(forward_dynamics_pk_kernel, dim3((e->n + 63) / 64), dim3(64), 0, (hipStream_t)stream, env_dev(e), e->pair_dev, root, q, qd, tau, wrench, qacc);
     HIP_OK(hipGetLastError());
     return 0;
 }

@@ -412,13 +412,15 @@ class T1(BaseTask):
             _lib.check(self._lib.bg_env_set_field(self._env, b"episode_stats", _lib.ptr(z), _lib.current_stream_ptr()), "bg_env_set_field")
         return s
 
-    def forward_dynamics(self, root, dof_pos, dof_vel, tau, base_wrench=None):
-        """d/dt of (root lin vel, root ang vel, dof vel) for the given states: [N,18].  Uses this env's model / randomisation / terrain."""
+    def forward_dynamics(self, root, dof_pos, dof_vel, tau, base_wrench=None, packed=False):
+        """d/dt of (root lin vel, root ang vel, dof vel) for the given states: [N,18].  Uses this env's model / randomisation / terrain.
+        packed: through the kernel with one env per wavefront lane and both legs in 64-bit register pairs (bg_env_forward_dynamics_packed)
+        instead of one leg per lane."""
         qacc = torch.empty(self.num_envs, 18, dtype=torch.float32, device=self.device)
         args = [t.contiguous().float() for t in (root, dof_pos, dof_vel, tau)]
         w = base_wrench.contiguous().float() if base_wrench is not None else None
-        _lib.check(self._lib.bg_env_forward_dynamics(self._env, *[_lib.ptr(t) for t in args], _lib.ptr(w), _lib.ptr(qacc),
-                                                     _lib.current_stream_ptr()), "bg_env_forward_dynamics")
+        name = "bg_env_forward_dynamics_packed" if packed else "bg_env_forward_dynamics"
+        _lib.check(getattr(self._lib, name)(self._env, *[_lib.ptr(t) for t in args], _lib.ptr(w), _lib.ptr(qacc), _lib.current_stream_ptr()), name)
         torch.cuda.current_stream().synchronize()
         return qacc
 

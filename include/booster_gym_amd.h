@@ -202,6 +202,12 @@ int bg_env_set_step_count(bg_env* env, int64_t count);
  * ang vel world, dof vel).  Uses the env's model, per-env parameters and terrain. */
 int bg_env_forward_dynamics(bg_env* env, const float* root, const float* dof_pos, const float* dof_vel, const float* tau,
                             const float* base_wrench, float* qacc, void* stream);
+/* The same call through the PACKED kernel: one env per wavefront lane, its two legs in the halves of 64-bit register pairs (v_pk_fma_f32 ...),
+ * instead of one leg per lane.  Same inputs, same outputs to fp32 rounding; returns -4 when the env was created with the trunk-low gate
+ * (body_gate_height > terminate_height: the non-foot body contacts need the two-kernel launch).  Replaces the same reference line
+ * (envs/t1.py:451 gym.simulate, dynamics only). */
+int bg_env_forward_dynamics_packed(bg_env* env, const float* root, const float* dof_pos, const float* dof_vel, const float* tau,
+                            const float* base_wrench, float* qacc, void* stream);
 
 /* ---- granular simulator calls: the Isaac Gym tensor API of envs/t1.py one call at a time (lower seam).
  * A maintainer who keeps the reference's Python task logic replaces each gym.* call by the entry point named here; the fused

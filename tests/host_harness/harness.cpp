@@ -1,7 +1,7 @@
-// TEST TOOL: compiles the product's per-lane dynamics header (booster_gym_amd/csrc/bg_dyn.h) with g++
+// TEST TOOL: compiles the product's per-lane dynamics headers (booster_gym_amd/csrc/bg_dyn.h, and bg_dyn_pk.h which includes it) with g++
 // so that its arithmetic can be compared with the double-precision oracle on a machine
 // without a GPU.  Not part of the shipped library; never loaded by the product path.
-#include "../../booster_gym_amd/csrc/bg_dyn.h"
+#include "../../booster_gym_amd/csrc/bg_dyn_pk.h"
 #include <string.h>
 using namespace bg;
 
@@ -82,6 +82,30 @@ int hh_forward(const ModelDev* m, const hh_cfg* c, const TerrainDev* tr, const f
         for (int a = 0; a < 3; a++) { root[a] = bs.pos.e[a]; root[7 + a] = bs.vlin.e[a]; root[10 + a] = bs.vang.e[a]; }
         for (int i = 0; i < 4; i++) root[3 + i] = bs.quat[i];
     }
+    return 0;
+}
+
+// The PACKED lane code (bg_dyn_pk.h: one env per lane, both legs in two-wide values -- g++ vector_size here, ext_vector_type on the GPU): one env,
+// same arguments as hh_forward, accelerations and foot forces only.
+int hh_forward_pk(const ModelDev* m, const hh_cfg* c, const TerrainDev* tr, const float* mass_scale, const float* com_off, const float* foot_mat,
+                  const float* root, const float* q, const float* qd, const float* tau, const float* wrench, float* qacc, float* cf /*2x3*/) {
+    Phys ph; ContactCfg cc; setup(c, ph, cc);
+    const PairModel pm = make_pair_model(*m);
+    PkCtx cx;
+    PkInputs& in = cx.w.st.in;
+    for (int k = 0; k < 13; k++) { in.v[PkSlots::ROOT + k] = root[k]; in.v[PkSlots::MS + k] = mass_scale[k]; }
+    for (int k = 0; k < 12; k++) { in.v[PkSlots::Q + k] = q[k]; in.v[PkSlots::QD + k] = qd[k]; in.v[PkSlots::TAU + k] = tau[k]; }
+    for (int k = 0; k < 6; k++) { in.v[PkSlots::WRENCH + k] = wrench[k]; in.v[PkSlots::FM + k] = foot_mat[k]; }
+    for (int k = 0; k < 39; k++) in.v[PkSlots::CO + k] = com_off[k];
+    in.has_wrench = true;
+    cx.w.st.pm = &pm;
+    cx.w.self_sc = nullptr; cx.w.self_lane = 0;
+    f2 qdd[6];
+    V3 lin_w, ang_w;
+    V3T<f2> fw;
+    pk_forward_env(ph, cc, *tr, *m, cx, qdd, &lin_w, &ang_w, &fw);
+    for (int a = 0; a < 3; a++) { qacc[a] = lin_w.e[a]; qacc[3 + a] = ang_w.e[a]; cf[a] = fw.e[a][0]; cf[3 + a] = fw.e[a][1]; }
+    for (int i = 0; i < 6; i++) { qacc[6 + i] = qdd[i][0]; qacc[12 + i] = qdd[i][1]; }
     return 0;
 }
 }

@@ -316,7 +316,8 @@ def test_product_rng_header_matches_oracle_philox(harness):
 
 
 def test_product_dynamics_header_matches_oracle(harness, flat_model):
-    """The per-lane fp32 articulated-body code of the HIP kernel (bg_dyn.h), compiled for the host, against the float64 oracle."""
+    """The per-lane fp32 articulated-body code of the HIP kernels, compiled for the host, against the float64 oracle: one leg per lane (bg_dyn.h)
+    and, the same generic code with two-wide scalars, one env per lane (bg_dyn_pk.h)."""
     from oracle.dyn_ref import DEFAULT_PHYS, DynRef
 
     hh, m = harness["harness"], flat_model
@@ -388,7 +389,7 @@ def test_product_dynamics_header_matches_oracle(harness, flat_model):
         t = Terr()
         if terrain is not None:
             t.type, t.rows, t.cols, t.border_px, t.inv_hscale, t.vscale, t.hf = 1, 60, 60, 30, 10.0, 0.005, hf.ctypes.data
-        worst, ncontact, nbody, crossed = 0.0, 0, 0, contact == "crossed"
+        worst, worst_pk, ncontact, nbody, crossed = 0.0, 0.0, 0, 0, contact == "crossed"
         if crossed:
             contact = False
         for _ in range(150):
@@ -413,11 +414,17 @@ def test_product_dynamics_header_matches_oracle(harness, flat_model):
             qacc, cf = d.forward(arrs[3], arrs[4], arrs[5], arrs[6], base_wrench=arrs[7], mass_scale=arrs[0], com_off=arrs[1].reshape(13, 3), foot_mat=arrs[2])
             tol_s = tol if np.abs(cf).max() == 0 else max(tol, 5e-4)  # any contact (also a chance leg-against-leg one in the airborne case) is stiff
             worst = max(worst, np.abs(qa - qacc).max() / max(1.0, np.abs(qacc).max()) / tol_s)
+            if contact != "low":  # the packed lane code (one env per lane, bg_dyn_pk.h) carries no non-foot body contacts: every other case
+                qp, cfp = np.zeros(18, np.float32), np.zeros(6, np.float32)
+                hh.hh_forward_pk(C.byref(md), C.byref(cfg), C.byref(t), *[p(a) for a in arrs], p(qp), p(cfp))
+                worst_pk = max(worst_pk, np.abs(qp - qacc).max() / max(1.0, np.abs(qacc).max()) / tol_s)
+                assert np.abs(cfp.reshape(2, 3) - cf[[6, 12]]).max() <= 2e-3 * max(1.0, np.abs(cf).max())
             ncontact += int(np.abs(cf).max() > 0)
             body_rows = [0, 1, 2, 3, 4, 5, 7, 8, 9, 10, 11]
             nbody += int(np.abs(cf[body_rows]).max() > 0)
             assert np.abs(bcf[body_rows] - cf[body_rows]).max() <= 2e-3 * max(1.0, np.abs(cf).max())
         assert worst < 1.0, (terrain is not None, contact, crossed, worst)
+        assert worst_pk < 1.0, ("packed", terrain is not None, contact, crossed, worst_pk)
         assert (ncontact > 50) == bool(contact or crossed), ncontact
         assert (nbody > 30) == (contact == "low" or crossed), nbody  # crossed: the shank rows carry leg-against-leg forces
 

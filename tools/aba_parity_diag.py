@@ -15,6 +15,7 @@ m = FlatModel.load(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(
 cfg = load_cfg("T1", {"env.num_envs": n, "terrain.type": "plane"})
 env = T1(cfg)
 ref = DynRef(m, feet_edge_pos=cfg["asset"]["feet_edge_pos"], terrain=None)
+twin = DynRef(m, feet_edge_pos=cfg["asset"]["feet_edge_pos"], terrain=None, real="f32")  # the oracle's own source in single precision
 rng = np.random.default_rng(3)
 if case == "sparse_crossed":
     root, q, qd, tau, w = _states(rng, m, n, False)
@@ -24,15 +25,20 @@ if case == "sparse_crossed":
 else:
     root, q, qd, tau, w = _states(rng, m, n, {"airborne": False, "standing": True}.get(case, case))
 f = lambda a: torch.tensor(a, dtype=torch.float32, device=env.device)
-qacc = env.forward_dynamics(f(root), f(q), f(qd), f(tau), f(w)).cpu().numpy().astype(np.float64)
+packed = os.environ.get("BG_ABA_PK", "1") != "0"
+qacc = env.forward_dynamics(f(root), f(q), f(qd), f(tau), f(w), packed=packed).cpu().numpy().astype(np.float64)
 rows = []
 for e in range(n):
     qa, cfr = ref.forward(root[e].astype(np.float32).astype(np.float64), q[e].astype(np.float32), qd[e].astype(np.float32), tau[e].astype(np.float32),
                           base_wrench=w[e].astype(np.float32), mass_scale=env._mass_scale[e].astype(np.float32), com_off=env._com_off[e].astype(np.float32),
                           foot_mat=env._foot_mat[e].astype(np.float32).reshape(6))
-    rows.append((np.abs(qacc[e] - qa).max() / max(1.0, np.abs(qa).max()), e, float(np.abs(cfr).max()), float(np.abs(qa).max()), int(np.abs(qacc[e] - qa).argmax())))
+    kw = dict(base_wrench=w[e].astype(np.float32), mass_scale=env._mass_scale[e].astype(np.float32), com_off=env._com_off[e].astype(np.float32),
+              foot_mat=env._foot_mat[e].astype(np.float32).reshape(6))
+    qt, _ = twin.forward(root[e].astype(np.float32).astype(np.float64), q[e].astype(np.float32), qd[e].astype(np.float32), tau[e].astype(np.float32), **kw)
+    rows.append((np.abs(qacc[e] - qa).max() / max(1.0, np.abs(qa).max()), e, float(np.abs(cfr).max()), float(np.abs(qa).max()), int(np.abs(qacc[e] - qa).argmax()),
+                 np.abs(qt - qa).max() / max(1.0, np.abs(qa).max())))
 rows.sort(reverse=True)
-print("pk" if os.environ.get("BG_ABA_PK", "1") != "0" else "lane-per-leg", case, n)
+print("packed (env per lane)" if packed else "leg per lane", case, n)
 for r in rows[:8]:
-    print(f"  env {r[1]:4d} rel err {r[0]:.2e} contact {r[2]:9.2f} N  max|qacc| {r[3]:9.1f}  worst component {r[4]}")
+    print(f"  env {r[1]:4d} rel err {r[0]:.2e} (fp32 twin of the oracle: {r[5]:.2e}) contact {r[2]:9.2f} N  max|qacc| {r[3]:9.1f}  worst component {r[4]}")
 print("  median rel err %.2e" % np.median([r[0] for r in rows]))
