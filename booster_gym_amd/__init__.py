@@ -1,9 +1,11 @@
 import os as _os
 
-# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues per process (default 4).  With the process group's own streams beside this build's
-# two (the critic's work runs on a high-priority side stream, utils/runner.py) the default mapping costs the update phase 50 % of its speed:
-# measured on one MI355X with RCCL in a world of one rank, 32-33 ms per update against 21.4 ms without a process group (29.7 ms even with every
-# collective skipped), and 22.4 ms with 8 (or 2) hardware queues, collectives included (tools/host_enqueue_probe2.py).
+# ROCm maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues per process (default 4).  With a process group's streams beside this build's two (the
+# critic's work runs on a high-priority side stream, utils/runner.py) the default mapping costs the whole loop 50-65 % of its speed.  Measured on one
+# MI355X with RCCL in a world of one rank (tools/ab_env.sh): round 3, every exchange through torch.distributed's NCCL backend:
+# 41 ms per iteration at 4 queues, 25.4 ms at 8 or 2; round 5, the per-mini-epoch exchanges through an own communicator on the update's streams
+# (utils/rccl.py): 39.8 ms at 8, 12 or 16 queues (the env step itself runs at 164 us instead of 101), 24.5-24.6 ms at 1, 2 or 3 -- against 23.9-24.0 ms
+# without a process group.  2 is the value that was good in every configuration measured.
 # The variable is read when the HIP runtime starts, so it is set here, when the package is imported, for processes that will join a process
 # group (the launcher's WORLD_SIZE, or BG_DIST_FORCE); a value from the environment wins.  Without a process group it changes nothing (measured).
 HW_QUEUES_SET_TOO_LATE = False  # the setting below was made after this process had already started the HIP runtime (utils/parallel.py warns)
@@ -12,4 +14,4 @@ if int(_os.environ.get("WORLD_SIZE", "1")) > 1 or _os.environ.get("BG_DIST_FORCE
         import torch as _torch
 
         HW_QUEUES_SET_TOO_LATE = bool(_torch.cuda.is_initialized())
-        _os.environ["GPU_MAX_HW_QUEUES"] = "8"
+        _os.environ["GPU_MAX_HW_QUEUES"] = "2"

@@ -196,28 +196,19 @@ __global__ __launch_bounds__(1024) void tail_adam_kernel(OptArgs o, ParamMirrors
 }
 }  // namespace
 
-extern "C" int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, const bg_reduce_problem* reduce, int32_t n_reduce, int32_t n, float* params,
-                              float* grads, float* exp_avg, float* exp_avg_sq, float* lr_device, int32_t step, float beta1, float beta2, float eps,
-                              float max_grad_norm, double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats, double* stats_acc, double* stats_last,
-                              int32_t n_stats, int32_t kl_index, float kl_count, float desired_kl, float lr_min, float lr_max, uint32_t* sync,
-                              double* norm_scratch, const bg_param_mirror* mirrors, int32_t n_mirrors, void* stream) {
-    if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr_device || step <= 0 || !sync || !norm_scratch)
-        return bg_set_error(-1, "bg_update_tail: bad argument");
-    if (grad_logstd && (ls_n <= 0 || ls_n > 1024 || ls_off < 0 || ls_off + ls_n > n)) return bg_set_error(-1, "bg_update_tail: log-std slice outside the buffer");
-    if (stats && (!stats_acc || !stats_last || n_stats <= 0 || kl_index < 0 || kl_index >= n_stats || !(kl_count > 0.f)))
-        return bg_set_error(-1, "bg_update_tail: statistics arguments");
-    if (n_mirrors < 0 || n_mirrors > OPT_MAX_MIRRORS || (n_mirrors > 0 && !mirrors)) return bg_set_error(-1, "bg_update_tail: at most 8 weight mirrors");
+// the work list of tail_sums_kernel from the two descriptor lists (shared by bg_update_tail and bg_update_tail_sums)
+static int tail_sums_fill(const bg_wgrad_problem* wgrad, int32_t n_wgrad, const bg_reduce_problem* reduce, int32_t n_reduce, WgradGroup& wg, ReduceGroup& rg,
+                          int& blocks, int& fin, const char* who) {
     if (n_reduce < 0 || n_reduce > RG_MAX || (n_reduce > 0 && !reduce)) return bg_set_error(-1, "bg_update_tail: at most 8 reductions");
-    WgradGroup wg;
     wg.np = 0;
-    int wgs = 0, fin = 0;
+    int wgs = 0;
+    fin = 0;
     if (n_wgrad > 0) {
-        const int rc = bg_wgrad_group_fill(wgrad, n_wgrad, wg, wgs, fin, "bg_update_tail");
+        const int rc = bg_wgrad_group_fill(wgrad, n_wgrad, wg, wgs, fin, who);
         if (rc) return rc;
     }
-    ReduceGroup rg;
     rg.np = n_reduce;
-    int blocks = 0;
+    blocks = 0;
     for (int k = 0; k < n_reduce; k++) {
         const bg_reduce_problem& q = reduce[k];
         if (!q.partial || q.groups <= 0 || q.record <= 0 || q.n_out <= 0 || q.n_out > q.record || !q.out[0] || q.n[0] <= 0 ||
@@ -230,6 +221,41 @@ extern "C" int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, co
         blocks += (q.n_out + 15) / 16 + q.n_stat;
     }
     for (int k = n_reduce; k < RG_MAX; k++) rg.begin[k] = blocks;
+    if (blocks + fin > TAIL_MAX_ITEMS) return bg_set_error(-4, "bg_update_tail: more than 8192 blocks of sums (norm_scratch holds one slot per block)");
+    return 0;
+}
+// Launch (1) of bg_update_tail alone: the sums.  For the ranks of a multi-GPU job, whose gradient is averaged over the ranks between the sums and the
+// optimiser: bg_update_tail_sums, the all-reduce, bg_optimizer_step (which takes the norm of the AVERAGED gradient itself).
+extern "C" int bg_update_tail_sums(const bg_wgrad_problem* wgrad, int32_t n_wgrad, const bg_reduce_problem* reduce, int32_t n_reduce, double* norm_scratch,
+                                   void* stream) {
+    if (!norm_scratch) return bg_set_error(-1, "bg_update_tail_sums: bad argument");
+    WgradGroup wg;
+    ReduceGroup rg;
+    int blocks = 0, fin = 0;
+    const int rc = tail_sums_fill(wgrad, n_wgrad, reduce, n_reduce, wg, rg, blocks, fin, "bg_update_tail_sums");
+    if (rc) return rc;
+    if (blocks + fin > 0) hipLaunchKernelGGL(tail_sums_kernel, dim3(blocks + fin), dim3(TAIL_THREADS), 0, (hipStream_t)stream, wg, rg, blocks, norm_scratch);
+    if (hipGetLastError() != hipSuccess) return bg_set_error(-2, "bg_update_tail_sums: launch failed");
+    return 0;
+}
+extern "C" int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, const bg_reduce_problem* reduce, int32_t n_reduce, int32_t n, float* params,
+                              float* grads, float* exp_avg, float* exp_avg_sq, float* lr_device, int32_t step, float beta1, float beta2, float eps,
+                              float max_grad_norm, double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats, double* stats_acc, double* stats_last,
+                              int32_t n_stats, int32_t kl_index, float kl_count, float desired_kl, float lr_min, float lr_max, uint32_t* sync,
+                              double* norm_scratch, const bg_param_mirror* mirrors, int32_t n_mirrors, void* stream) {
+    if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr_device || step <= 0 || !sync || !norm_scratch)
+        return bg_set_error(-1, "bg_update_tail: bad argument");
+    if (grad_logstd && (ls_n <= 0 || ls_n > 1024 || ls_off < 0 || ls_off + ls_n > n)) return bg_set_error(-1, "bg_update_tail: log-std slice outside the buffer");
+    if (stats && (!stats_acc || !stats_last || n_stats <= 0 || kl_index < 0 || kl_index >= n_stats || !(kl_count > 0.f)))
+        return bg_set_error(-1, "bg_update_tail: statistics arguments");
+    if (n_mirrors < 0 || n_mirrors > OPT_MAX_MIRRORS || (n_mirrors > 0 && !mirrors)) return bg_set_error(-1, "bg_update_tail: at most 8 weight mirrors");
+    WgradGroup wg;
+    ReduceGroup rg;
+    int blocks = 0, fin = 0;
+    {
+        const int rc = tail_sums_fill(wgrad, n_wgrad, reduce, n_reduce, wg, rg, blocks, fin, "bg_update_tail");
+        if (rc) return rc;
+    }
     ParamMirrors mir;
     mir.n = n_mirrors;
     for (int k = 0; k < n_mirrors; k++) {
@@ -245,7 +271,6 @@ extern "C" int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, co
     o.grad_logstd = grad_logstd; o.ls_off = ls_off; o.ls_n = ls_n;
     o.stats = stats; o.stats_acc = stats_acc; o.stats_last = stats_last; o.n_stats = n_stats; o.kl_index = kl_index; o.kl_count = kl_count;
     o.desired_kl = desired_kl; o.lr_min = lr_min; o.lr_max = lr_max;
-    if (blocks + fin > TAIL_MAX_ITEMS) return bg_set_error(-4, "bg_update_tail: more than 8192 blocks of sums (norm_scratch holds one slot per block)");
     if (blocks + fin > 0) hipLaunchKernelGGL(tail_sums_kernel, dim3(blocks + fin), dim3(TAIL_THREADS), 0, (hipStream_t)stream, wg, rg, blocks, norm_scratch);
     hipLaunchKernelGGL(tail_adam_kernel, dim3(ADAM_GRID), dim3(1024), 0, (hipStream_t)stream, o, mir, (const double*)norm_scratch, blocks + fin, (unsigned*)sync);
     if (hipGetLastError() != hipSuccess) return bg_set_error(-2, "bg_update_tail: launch failed");

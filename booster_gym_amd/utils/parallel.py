@@ -15,6 +15,8 @@ import os
 import torch
 import torch.distributed as dist
 
+from .rccl import NCCL_AVG, NCCL_SUM
+
 
 class DataParallel:
     def __init__(self, backend=None):
@@ -36,22 +38,34 @@ class DataParallel:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29511")
             if self.backend == "nccl":
-                # The process group's streams beside this build's two need more than ROCm's default of 4 hardware queues per process (50 % of the update's
-                # speed).  booster_gym_amd/__init__.py sets GPU_MAX_HW_QUEUES=8 at import for processes that will join a group; the
-                # variable is read when the HIP runtime starts, so say so if that could not have worked.
+                # A process group's streams beside this build's two want another mapping of HIP streams onto hardware queues than ROCm's default of 4 per
+                # process (50-65 % of the loop's speed).  booster_gym_amd/__init__.py sets GPU_MAX_HW_QUEUES=2 at import for processes
+                # that will join a group; the variable is read when the HIP runtime starts, so say so if that could not have worked.
                 import warnings
 
                 import booster_gym_amd
 
                 q = os.environ.get("GPU_MAX_HW_QUEUES")
                 if booster_gym_amd.HW_QUEUES_SET_TOO_LATE:
-                    warnings.warn("GPU_MAX_HW_QUEUES=8 was set after this process had started the HIP runtime and has no effect; import booster_gym_amd (or "
+                    warnings.warn("GPU_MAX_HW_QUEUES=2 was set after this process had started the HIP runtime and has no effect; import booster_gym_amd (or "
                                   "export the variable) before the first CUDA call")
-                elif q is None or (int(q) < 8 and int(q) != 2):
-                    warnings.warn(f"GPU_MAX_HW_QUEUES={q!r}: with RCCL's streams beside the update's two, fewer than 8 hardware queues per process cost up to "
-                                  "50 % of the update phase on MI355X; export GPU_MAX_HW_QUEUES=8 before the process starts")
+                elif q is None or not q.isdigit() or not 1 <= int(q) <= 3:  # (best effort: only runtimes started through torch are noticed)
+                    warnings.warn(f"GPU_MAX_HW_QUEUES={q!r}: with RCCL's streams beside the update's two, anything but 1-3 hardware queues per process cost "
+                                  "40-65 % of the training loop on MI355X (measured); export GPU_MAX_HW_QUEUES=2 before the process starts")
             dist.init_process_group(backend=self.backend, rank=self.rank, world_size=self.world_size)
             self.owns_group = True
+        # the per-mini-epoch exchanges go through an own RCCL communicator, issued on the stream of the kernels around them (utils/rccl.py: the process
+        # group's collectives run on its own stream between two event hand-overs, +54 us per mini-epoch in a world of one); gloo (CPU tests): the group
+        self.comm = None
+        if self.active and self.backend == "nccl":
+            from .rccl import RcclComm
+
+            def exchange_id(raw):
+                box = [raw]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+
+            self.comm = RcclComm(self.rank, self.world_size, self.device_index, exchange_id)
 
     @property
     def active(self):
@@ -70,7 +84,10 @@ class DataParallel:
         """In-place SUM all-reduce (no-op for a single process).  tag: which exchange this is, for bench.py's per-exchange timing."""
         if self.active:
             e1 = self._timed(tag, t)
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if self.comm is not None and t.is_cuda:
+                self.comm.all_reduce_(t, NCCL_SUM)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
             if e1 is not None:
                 e1.record()
         return t
@@ -80,14 +97,33 @@ class DataParallel:
         current stream: the span is the collective plus the wait for the slowest rank to arrive."""
         if self.active:
             e1 = self._timed("bucket", t)
-            if self.backend == "nccl":  # RCCL averages inside the collective: no second launch on the critical path of every mini-epoch
-                dist.all_reduce(t, op=dist.ReduceOp.AVG)
+            if self.comm is not None and t.is_cuda:  # RCCL averages inside the collective: no second launch on the critical path of every mini-epoch
+                self.comm.all_reduce_(t, NCCL_AVG)
             else:                       # gloo has no AVG
                 dist.all_reduce(t, op=dist.ReduceOp.SUM)
                 t.mul_(1.0 / self.world_size)
             if e1 is not None:
                 e1.record()
         return t
+
+    def exchange_tail_(self, bucket, stats, grad_logstd):
+        """The exchanges behind the gradient's last sums as ONE collective launch on the current stream: the flat gradient bucket (mean over ranks), the
+        loss / KL sums (sum) and the log-std gradient (mean) -- exchanges (2) and (3) of SURVEY 8(e).  Timed as "bucket" when bench.py arms the events."""
+        if not self.active:
+            return
+        e1 = self._timed("bucket", bucket)
+        if self.comm is not None and bucket.is_cuda:
+            with self.comm.group() as c:
+                c.all_reduce_(bucket, NCCL_AVG)
+                c.all_reduce_(stats, NCCL_SUM)
+                c.all_reduce_(grad_logstd, NCCL_AVG)
+        else:
+            for t in (bucket, stats, grad_logstd):
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            bucket.mul_(1.0 / self.world_size)
+            grad_logstd.mul_(1.0 / self.world_size)
+        if e1 is not None:
+            e1.record()
 
     def sync_grid(self, cur, last):
         """Command-curriculum grid under data parallelism (reference envs/t1.py:404-413 on one process): every rank has added
@@ -124,5 +160,9 @@ class DataParallel:
                 dist.barrier()
 
     def shutdown(self):
+        if self.comm is not None:
+            torch.cuda.synchronize()
+            self.comm.destroy()
+            self.comm = None
         if self.active and self.owns_group and dist.is_initialized():
             dist.destroy_process_group()

@@ -106,6 +106,16 @@ class FlatAdam:
                                               None if mirrors is None else ctypes.addressof(mirrors), 0 if mirrors is None else len(mirrors),
                                               _lib.current_stream_ptr()), "bg_update_tail")
 
+    def tail_sums(self, wgrad, reductions):
+        """Launch (1) of `step_tail` alone (bg_update_tail_sums): the ranks of a multi-GPU job average the gradient between the sums and `step_fused`."""
+        if not hasattr(self, "_tail_sync"):
+            self._tail_sync = torch.zeros(4, dtype=torch.int32, device=self.flat.device)
+            self._tail_norm = torch.zeros(8192, dtype=torch.float64, device=self.flat.device)
+        warr, wn = wgrad if wgrad is not None else (None, 0)
+        rarr = (_lib.ReduceProblem * len(reductions))(*reductions) if reductions else None
+        _lib.check(_lib.load().bg_update_tail_sums(warr, wn, rarr, len(reductions) if reductions else 0, _lib.ptr(self._tail_norm), _lib.current_stream_ptr()),
+                   "bg_update_tail_sums")
+
     def adapt_lr(self, kl_sum, count, desired_kl, lr_min=1e-5, lr_max=1e-2):
         _lib.check(_lib.load().bg_adapt_lr(_lib.ptr(kl_sum), float(count), desired_kl, lr_min, lr_max, _lib.ptr(self.lr), _lib.current_stream_ptr()),
                    "bg_adapt_lr")
@@ -484,8 +494,11 @@ class Runner:
                 # the sums of the tail as one launch behind the main weight-gradient kernel + a lean optimiser launch (single process, see __init__)
                 # (its norm is assembled from the sums' own pieces: every gradient element must come out of that launch -- all hidden-layer weight
                 # gradients from the grouped kernel, everything else from the deferred reductions)
-                one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and not self.dp.active and len(fins) + 2 <= 8
-                            and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr)))
+                # (that is: every hidden layer's backward went through the partial kernel, whose finish carries the bias gradient of the layer below --
+                # a layer that fell to the library path wrote its bias gradient outside both lists and the norm would miss it)
+                one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and len(fins) + 2 <= 8
+                            and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr))
+                            and len(fins) == sum(len(tr.layers) - 2 for tr in (self._critic_tr, self._actor_tr)))
                 main.wait_stream(side)
                 if one_tail:
                     pass  # the deferred reductions run inside bg_update_tail
@@ -506,7 +519,13 @@ class Runner:
                 wg_partial = self._wgrad_group.run((self._critic_tr, self._actor_tr), finish=not one_tail)
                 if defer and (self.dp.active or not self._defer_serial):
                     main.wait_stream(side)
-                self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
+                if one_tail and self.dp.active:
+                    # ranks: the sums, then ONE collective launch on this stream (gradient bucket: mean; loss / KL sums: sum; log-std gradient: mean -- exchanges
+                    # (2) and (3) of SURVEY 8(e)), then the optimiser launch, which takes the norm of the averaged gradient
+                    self.optimizer.tail_sums(wg_partial, [fin_c, fin_a] + fins)
+                    self.dp.exchange_tail_(self.optimizer.grad, self._stats, self._grad_logstd)
+                elif not one_tail:
+                    self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
                 if fused_tail:
                     # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch
                     # ... and the copies of the weights that the layer kernels read (zero-padded first layers, transposed hidden layers): written by the
@@ -514,7 +533,7 @@ class Runner:
                     if mirrors is None:
                         ms = self._critic_tr.mirror_descriptors(self.optimizer.flat) + self._actor_tr.mirror_descriptors(self.optimizer.flat)
                         mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 8 else None
-                    if one_tail:
+                    if one_tail and not self.dp.active:
                         self.optimizer.step_tail(wg_partial, [fin_c, fin_a] + fins, self._stats, self._stats_acc, self._stats_last, 4, B, alg["desired_kl"],
                                                  grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
                     else:

@@ -423,6 +423,10 @@ int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, const bg_redu
                    double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats, double* stats_acc, double* stats_last, int32_t n_stats, int32_t kl_index,
                    float kl_count, float desired_kl, float lr_min, float lr_max, uint32_t* sync, double* norm_scratch, const bg_param_mirror* mirrors,
                    int32_t n_mirrors, void* stream);
+/* Launch (1) of bg_update_tail alone, for the ranks of a multi-GPU job: the gradient's last sums, THEN the all-reduce over the ranks, THEN
+ * bg_optimizer_step, which takes the norm of the averaged gradient itself (the reference clips what `loss.backward()` left on its one process,
+ * runner.py:162-165; under data parallelism that is the mean over the ranks).  norm_scratch: float64 [8192] (written, not used by the caller). */
+int bg_update_tail_sums(const bg_wgrad_problem* wgrad, int32_t n_wgrad, const bg_reduce_problem* reduce, int32_t n_reduce, double* norm_scratch, void* stream);
 /* bg_actor_head mode 1 / bg_critic_head_backward / bg_mlp_layer_backward without their finishing launch: same arguments, plus the descriptor
  * of the reduction that produces grad_W, grad_b, grad_b_hidden, grad_logstd, stats / bias_grad_below when handed to bg_reduce_group. */
 int bg_actor_head_partial(int32_t B, const float* h, const float* W, const float* bias, const float* logstd, const float* actions,

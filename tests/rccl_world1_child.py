@@ -13,6 +13,16 @@ from booster_gym_amd.utils.parallel import DataParallel
 from booster_gym_amd.utils.runner import Runner
 
 out = {}
+if os.environ.get("BG_DIST_FORCE", "0") != "1":
+    # the same seeded iteration WITHOUT a process group (single-process two-launch tail): the yardstick for the collective path's arithmetic
+    r = Runner(cfg=load_cfg("T1", {"env.num_envs": 64, "terrain.type": "plane", "runner.mini_epochs": 2, "commands.curriculum": True}))
+    assert not r.dp.active
+    obs, infos = r.env.reset()
+    r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+    stats = r.iteration()
+    torch.cuda.synchronize()
+    print("RCCL_WORLD1 " + json.dumps({"params": r.optimizer.flat.double().cpu().tolist()[::97], "stats": stats.cpu().tolist(), "lr": float(r.optimizer.lr)}), flush=True)
+    sys.exit(0)
 dp = DataParallel()
 assert dp.active and dp.world_size == 1 and dp.backend == "nccl" and dist.is_initialized() and dist.get_backend() == "nccl"
 dev = torch.device(f"cuda:{dp.device_index}")
@@ -28,6 +38,12 @@ with torch.cuda.stream(side):                  # collectives issued on the side 
 main.wait_stream(side)
 dep = g32 * 2.0 + a64.sum().float()            # a dependent kernel on the main stream
 torch.cuda.synchronize()
+assert dp.comm is not None, "the per-mini-epoch exchanges must go through the own communicator (utils/rccl.py)"
+s64, l64 = torch.arange(5, dtype=torch.float64, device=dev) + 0.5, torch.arange(12, dtype=torch.float64, device=dev) - 3.0
+dp.exchange_tail_(g32, s64, l64)               # bucket (mean) + loss sums (sum) + log-std gradient (mean): one grouped launch on the current stream
+torch.cuda.synchronize()
+out["group_exact"] = bool(torch.equal(g32, g0) and torch.equal(s64, torch.arange(5, dtype=torch.float64, device=dev) + 0.5)
+                          and torch.equal(l64, torch.arange(12, dtype=torch.float64, device=dev) - 3.0))
 out["sum_fp64_exact"] = bool(torch.equal(a64, torch.arange(5, dtype=torch.float64, device=dev) + 0.25))
 out["avg_fp32_exact"] = bool(torch.equal(g32, g0))
 out["dependent_ok"] = bool(torch.allclose(dep, g0 * 2.0 + float(a64.sum())))
@@ -46,6 +62,7 @@ r._sync_curriculum()
 torch.cuda.synchronize()
 out["iteration_finite"] = bool(torch.isfinite(stats).all() and torch.isfinite(r.optimizer.flat).all())
 out["parameters_moved"] = bool((r.optimizer.flat - p0).abs().max() > 0)
+out["params"], out["stats"], out["lr"] = r.optimizer.flat.double().cpu().tolist()[::97], stats.cpu().tolist(), float(r.optimizer.lr)
 dp.barrier()
 dp.shutdown()
 out["shutdown"] = not dist.is_initialized()
