@@ -62,7 +62,7 @@ class ParamMirror(C.Structure):
 
 class MlpChain(C.Structure):
     """bg_mlp_chain: the forward chain of one network for bg_mlp_chain_forward_group (include/booster_gym_amd.h)."""
-    _fields_ = [("M", C.c_int32), ("K0", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("N3", C.c_int32), ("pad", C.c_int32)] + \
+    _fields_ = [("M", C.c_int32), ("K0", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("N3", C.c_int32), ("workgroups", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("X", "W1", "b1", "W2", "b2", "W3", "b3", "Y1", "Y2", "Y3", "v_w", "v_b", "v_out")]
 
 

@@ -229,9 +229,17 @@ __global__ __launch_bounds__(256) void mlp_chain_fwd_kernel(ChainGroup grp) {
             if (j < grp.n && (int)blockIdx.x >= grp.begin[j]) k = j;
     }
     const bg_mlp_chain& a = grp.net[k];
-    const int slab = blockIdx.x - grp.begin[k];
-    if (TAG == 2 || (TAG == 0 && a.N2 == 256)) chain_slab<64, 256, 256, 128>(a, slab, sW, sB);
-    else chain_slab<64, 256, 128, 128>(a, slab, sW, sB);
+    // One slab per workgroup, or (bg_mlp_chain::workgroups > 0) that many workgroups walking the network's slabs: the update's two networks, launched side
+    // by side on two streams, then SHARE the chip by CUs instead of by slabs (a workgroup fills a CU: 128 KB of LDS).  Equal-sized slabs of unequal cost
+    // (critic 65 us, actor 41 us) dispatched as CUs fall free run in lockstep rounds and leave the last 32 slabs to run alone: 370 us for the pair against
+    // 325 us of work per CU; 160 workgroups x 5 critic slabs beside 96 x 8 actor slabs is 323 / 328 us (utils/runner.py plans the split).
+    const int nslabs = (a.M + 127) / 128, stride = grp.begin[k + 1] - grp.begin[k];
+    for (int slab = blockIdx.x - grp.begin[k]; slab < nslabs; slab += stride) {
+        if (TAG == 2 || (TAG == 0 && a.N2 == 256)) chain_slab<64, 256, 256, 128>(a, slab, sW, sB);
+        else chain_slab<64, 256, 128, 128>(a, slab, sW, sB);
+        // every wave has read the last chunk (and the biases) before anybody's copies of the next slab land in the buffers
+        asm volatile("s_barrier" ::: "memory");
+    }
 }
 
 static int chain_check(const bg_mlp_chain& q) {
@@ -255,7 +263,9 @@ extern "C" int bg_mlp_chain_forward_group(const bg_mlp_chain* nets, int32_t coun
         if (rc) return rc;
         grp.begin[k] = blocks;
         grp.net[k] = nets[k];
-        blocks += (nets[k].M + 127) / 128;
+        const int slabs = (nets[k].M + 127) / 128;
+        if (nets[k].workgroups < 0) return bg_set_error(-1, "bg_mlp_chain_forward_group: workgroups < 0");
+        blocks += nets[k].workgroups > 0 && nets[k].workgroups < slabs ? nets[k].workgroups : slabs;
     }
     grp.begin[count] = blocks;
     if (count > 1) hipLaunchKernelGGL(mlp_chain_fwd_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
@@ -267,7 +277,7 @@ extern "C" int bg_mlp_chain_forward_group(const bg_mlp_chain* nets, int32_t coun
 extern "C" int bg_mlp_chain_forward(int32_t M, int32_t K0, int32_t N1, int32_t N2, int32_t N3, const float* X, const float* W1, const float* b1,
                                     const float* W2, const float* b2, const float* W3, const float* b3, float* Y1, float* Y2, float* Y3, void* stream) {
     bg_mlp_chain q;
-    q.M = M; q.K0 = K0; q.N1 = N1; q.N2 = N2; q.N3 = N3; q.pad = 0;
+    q.M = M; q.K0 = K0; q.N1 = N1; q.N2 = N2; q.N3 = N3; q.workgroups = 0;
     q.X = X; q.W1 = W1; q.b1 = b1; q.W2 = W2; q.b2 = b2; q.W3 = W3; q.b3 = b3; q.Y1 = Y1; q.Y2 = Y2; q.Y3 = Y3;
     q.v_w = nullptr; q.v_b = nullptr; q.v_out = nullptr;
     return bg_mlp_chain_forward_group(&q, 1, stream);

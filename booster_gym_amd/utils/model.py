@@ -148,7 +148,8 @@ class MLPTrainer:
         vw, vb, vo = self.value_head if self.value_head is not None else (None, None, None)
         if vo is not None and (vo.numel() < self.x.shape[0] or vw.numel() != ls[2].weight.shape[0]):
             raise ValueError("value_head: weight [width of the last hidden layer], bias [1], output [rows]")
-        return _lib.MlpChain(self.x.shape[0], self._kin, ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0], 0, p(self.x), p(self.w0pad),
+        return _lib.MlpChain(self.x.shape[0], self._kin, ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0], int(self.chain_workgroups), p(self.x),
+                             p(self.w0pad),
                              p(ls[0].bias), p(ls[1].weight), p(ls[1].bias), p(ls[2].weight), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]), p(self.acts[2]),
                              p(vw), p(vb), p(vo))
 
@@ -178,6 +179,7 @@ class MLPTrainer:
             raise ValueError("chain_rows_descriptor: row0 and nrows must be multiples of 128 inside the prepared batch")
         d = self._chain_descriptor()
         d.M = nrows
+        d.workgroups = 0  # (a few slabs during the rollout: one workgroup each)
         d.X = d.X + 4 * row0 * self._kin
         ls = self.layers
         d.Y1, d.Y2, d.Y3 = (y + 4 * row0 * l.weight.shape[0] for y, l in zip((d.Y1, d.Y2, d.Y3), ls[:3]))
@@ -197,6 +199,8 @@ class MLPTrainer:
         self.x = None
         self._B = self._rows = self._kin = None
         self.timed_layer, self.timed_events = None, []
+        # workgroups of the full-batch chained forward launch (0: one per slab); the runner sets it when two networks' launches share the chip
+        self.chain_workgroups = 0
         # (weight [N3], bias [1], out [rows]): a scalar output layer evaluated by the chained forward kernel itself (the critic's values); None: not
         self.value_head = None
 

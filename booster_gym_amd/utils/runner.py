@@ -229,6 +229,9 @@ class Runner:
         # critic output layer + GAE in one launch (bg_critic_values_gae: horizons up to 32 steps); otherwise bg_critic_head_forward, a fill and bg_gae
         self._fused_gae = self.cfg["runner"]["horizon_length"] <= 32
         self._chain_values = True  # ... with the values from the chained forward kernel's value head (False: from the stored activations)
+        # the two networks' chained forward launches of a mini-epoch share the chip by CUs (each a persistent grid over its slabs, _plan_chain_split);
+        # False: one workgroup per slab, dispatched as CUs fall free
+        self._split_chain_cus = os.environ.get("BG_SPLIT_CHAIN_CUS", "1") == "1"
         self._gae_scratch = torch.zeros(3 * ((self.env.num_envs + 15) // 16) + 1, dtype=torch.float64, device=self.device)
 
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value (utils/model.py); a model of
@@ -420,6 +423,7 @@ class Runner:
         self._stats.zero_()
         self._grad_logstd.zero_()
         mirrors = None
+        self._plan_chain_split(critic_all.shape[0], B)
         # Two HIP streams: the actor and the critic are independent networks, so the HBM-bound elementwise kernels of one overlap
         # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
         main = torch.cuda.current_stream()
@@ -553,6 +557,23 @@ class Runner:
                     self._stats.zero_()
                     self._grad_logstd.zero_()
         return self._stats_acc
+
+    def _plan_chain_split(self, rows_c, rows_a):
+        """The two networks' chained forward launches of a mini-epoch run side by side on two streams, one workgroup per CU (128 KB of LDS).  Left to the
+        dispatcher, equal-sized slabs of unequal cost run in lockstep rounds and the last 32 slabs run alone (370 us for 325 us of work per CU); here each
+        launch gets a share of the CUs and walks its slabs (bg_mlp_chain::workgroups): the split that minimises the longer of the two, slab cost ~ flops."""
+        ct, at = self._critic_tr, self._actor_tr
+        ct.chain_workgroups = at.chain_workgroups = 0
+        if not (self._split_chain_cus and ct._chainable() and at._chainable()):
+            return
+        cus = torch.cuda.get_device_properties(self.device).multi_processor_count
+        sc, sa = (rows_c + 127) // 128, (rows_a + 127) // 128
+        if sc + sa <= cus:
+            return
+        cost = lambda tr: sum(l.weight.shape[0] * (tr._kin if i == 0 else l.weight.shape[1]) for i, l in enumerate(tr.layers[:3]))
+        fc, fa = cost(ct), cost(at)
+        best = min(range(1, cus), key=lambda a: (max(-(-sc // a) * fc, -(-sa // (cus - a)) * fa), abs(a - cus * sc * fc / (sc * fc + sa * fa))))
+        ct.chain_workgroups, at.chain_workgroups = best, cus - best
 
     def _exchange_sums(self):
         """Exchange (3), on the current (side) stream: the loss / KL sums and the log-std gradient of all ranks in one float64 all-reduce; the gradient

@@ -298,7 +298,9 @@ int bg_mlp_layer_forward(int32_t M, int32_t K, int32_t N, const float* X, const 
  * ceil(M / 128) * 128 rows (rows >= M of the last slab are written with unspecified values).  Bit-identical to three bg_mlp_layer_forward
  * launches.  -4: unsupported widths. */
 typedef struct bg_mlp_chain {
-    int32_t M, K0, N1, N2, N3, pad;
+    int32_t M, K0, N1, N2, N3;
+    int32_t workgroups;  /* 0: one workgroup per 128-row slab; > 0: that many workgroups walk the slabs (each fills a CU: two launches side by side then
+                          * share the chip by CUs -- see bg_mlp_chain.hip).  Same outputs either way. */
     const float *X, *W1, *b1, *W2, *b2, *W3, *b3;
     float *Y1, *Y2, *Y3;
     /* optional scalar output layer on Y3 (the critic's value head, utils/model.py:21): v_out[row] = v_w . Y3[row] + v_b[0], taken from the registers that

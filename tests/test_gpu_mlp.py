@@ -235,14 +235,19 @@ def _chain_check(M, x, Ws, bs, ys):
         hin = z
 
 
-@pytest.mark.parametrize("M,dims", [(98304, (64, 256, 128, 128)), (102400, (64, 256, 256, 128)), (1000, (64, 256, 256, 128)), (77, (64, 256, 128, 128))])
-def test_mlp_chain_forward_matches_torch_fp64(M, dims):
+@pytest.mark.parametrize("M,dims,wgs", [(98304, (64, 256, 128, 128), 0), (102400, (64, 256, 256, 128), 0), (1000, (64, 256, 256, 128), 0), (77, (64, 256, 128, 128), 0),
+                                        # bg_mlp_chain::workgroups > 0: that many workgroups walk the slabs (the update's split of the CUs between the two
+                                        # networks' launches: 160 x 5 critic slabs, 96 x 8 actor slabs); a count that does not divide the slabs; more
+                                        # workgroups than slabs (= one per slab)
+                                        (98304, (64, 256, 128, 128), 96), (102400, (64, 256, 256, 128), 160), (1000, (64, 256, 256, 128), 3), (77, (64, 256, 128, 128), 5)])
+def test_mlp_chain_forward_matches_torch_fp64(M, dims, wgs):
     """bg_mlp_chain_forward_group (three Linear+ELU layers of a network in one launch, activations in registers between them) at the training
     shapes (M = 98,304 / 102,400) and on ragged batches: every stored activation against torch fp64 and the per-layer kernels."""
     import ctypes
     from booster_gym_amd import _lib
 
     d, x, Ws, bs, ys = _chain_case(M, dims, seed=M + dims[2])
+    d.workgroups = wgs
     _lib.check(_lib.load().bg_mlp_chain_forward_group(ctypes.addressof(d), 1, _lib.current_stream_ptr()))
     _chain_check(M, x, Ws, bs, ys)
 

@@ -332,6 +332,7 @@ SWITCHES = {
     "hidden_layers_one_launch_each": ({}, {"CHAIN": False}),                     # bg_mlp_layer_forward x 3 per network
     "hidden_layers_as_library_gemms": ({}, {"FUSED": False}),                    # torch.addmm + elu_, torch.mm + bg_elu_backward_colsum, bmm weight gradients
     "weight_gradients_as_library_gemms": ({}, {"FUSED_WGRAD": False}),           # split-K bmm + sum
+    "chain_one_workgroup_per_slab": ({"_split_chain_cus": False}, {}),            # the two forward launches share the chip by slabs instead of by CUs
     "rollout_forward_off": ({"_rollout_forward": False}, {}),
     "rollout_forward_one_step_per_group": ({"_rollout_group": 1}, {}),
     "rollout_forward_five_steps_per_group": ({"_rollout_group": 5}, {}),
@@ -380,7 +381,7 @@ def test_update_through_every_switch_matches_the_default(switch, default_update)
     rate.  The rollout-forward variants run the same kernels on the same numbers: identical bits, also after a second iteration."""
     start, (p0, a0, s0), (q0, b0, act0) = default_update
     _, (p1, a1, s1), (q1, b1, act1) = _update_under(switch)
-    if switch.startswith("rollout_forward"):
+    if switch.startswith("rollout_forward") or switch == "chain_one_workgroup_per_slab":
         assert torch.equal(p1, p0) and torch.equal(a1, a0) and torch.equal(q1, q0) and torch.equal(b1, b0) and torch.equal(act1, act0)
         return
     _assert_same_adam_steps(switch, p1, p0, start)
