@@ -85,6 +85,13 @@ def build(force=False, f32=False):
     name = "libdynref32.so" if f32 else "libdynref.so"
     so = os.path.join(_HERE, name)
     src = os.path.join(_HERE, "dyn_ref.c")
+    if os.environ.get("BG_SANITIZE", "0") == "1":  # tests/test_sanitizers.py: the same source under the address / undefined-behaviour sanitizers
+        import tempfile
+
+        so = os.path.join(tempfile.mkdtemp(prefix="bg_san_"), name)
+        subprocess.check_call(["gcc", "-O1", "-g", "-fPIC", "-fopenmp", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+                              + (["-DREF_F32", "-fsingle-precision-constant"] if f32 else []) + ["-shared", "-o", so, src, "-lm"])
+        return so
     if force or not os.path.isfile(so) or (os.path.isfile(src) and os.path.getmtime(src) > os.path.getmtime(so)):
         subprocess.check_call(["make", "-C", _HERE, "-s", name])
     return so

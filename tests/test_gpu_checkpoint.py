@@ -89,3 +89,44 @@ def test_train_entry_writes_the_reference_log_layout(tmp_path, monkeypatch):
               "reward", "episode/survival", "episode/feet_swing"):
         assert t in tags, t
     assert "episode/feet_vel_z" not in tags  # dropped reward terms are not logged
+
+
+def test_actor_kernels_and_export_reproduce_the_reference_deploy_codes_actions(tmp_path):
+    """tests/golden/deploy_policy.npz: observations and network outputs of the reference's own deploy-side class (deploy/utils/policy.py:34-73) with its
+    trained actor (weights as numbers: tests/golden/t1_actor.npz).  With those weights loaded, (1) the rollout's fused MFMA actor kernel (bg_actor_sample:
+    the mean it samples around), (2) the update's chained forward + output layer and (3) the TorchScript that export_model.py writes -- the file that
+    class loads on the robot -- give the reference's actions on the reference's observations."""
+    import subprocess
+    import sys
+
+    from booster_gym_amd.utils.model import ActorCritic
+
+    here = os.path.dirname(os.path.abspath(__file__))
+    d = np.load(os.path.join(here, "golden", "deploy_policy.npz"))
+    w = np.load(os.path.join(here, "golden", "t1_actor.npz"))
+    obs = torch.tensor(d["obs"].reshape(-1, 47), device="cuda:0")
+    raw = torch.tensor(d["raw_actions"].reshape(-1, 12), device="cuda:0")
+    model = ActorCritic(12, 47, 14).to("cuda:0")
+    model.actor.load_state_dict({k: torch.tensor(w[k]) for k in w.files})
+    # (1) rollout inference kernel
+    mu, act = torch.empty_like(raw), torch.empty_like(raw)
+    model.sample_actions(obs, act, seed=1, counter=0, mu_out=mu)
+    assert torch.allclose(mu, raw, rtol=0, atol=1e-5), (mu - raw).abs().max().item()
+    # (2) the training-side forward (hand-written MFMA layers + library output layer)
+    with torch.no_grad():
+        assert torch.allclose(model.actor(obs), raw, rtol=0, atol=1e-5)
+    # (3) checkpoint -> export_model.py -> TorchScript file, loaded the way deploy/utils/policy.py:9 loads it
+    ck = tmp_path / "logs" / "run" / "nn"
+    ck.mkdir(parents=True)
+    torch.save({"model": {k: v.cpu() for k, v in model.state_dict().items()}}, str(ck / "model_1.pth"))
+    root = os.path.dirname(here)
+    p = subprocess.run([sys.executable, os.path.join(root, "export_model.py"), "--task=T1", "--checkpoint", str(ck / "model_1.pth")], cwd=str(tmp_path),
+                       env=dict(os.environ, PYTHONPATH=root), capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stdout[-1000:] + p.stderr[-2000:]
+    scripted = torch.jit.load(str(tmp_path / "deploy" / "models" / "T1.pt"))
+    scripted.eval()
+    with torch.no_grad():
+        out = scripted(obs.cpu())
+    assert torch.allclose(out, raw.cpu(), rtol=0, atol=1e-5), (out - raw.cpu()).abs().max().item()
+    clip = torch.clamp(out, -1.0, 1.0)
+    assert torch.allclose(clip, torch.tensor(d["actions"].reshape(-1, 12)), rtol=0, atol=1e-5)

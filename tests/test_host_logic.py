@@ -291,6 +291,51 @@ def test_model_state_dict_keys_match_the_reference_layout():
         assert tuple(W[f"{i}.weight"].shape) == tuple(m.actor[i].weight.shape)
 
 
+def test_observation_layout_equals_what_the_reference_deploy_code_builds(flat_model):
+    """tests/golden/deploy_policy.npz holds what the reference's OWN deploy-side class computes (deploy/utils/policy.py:34-73 run on 96 seeded robot states
+    with its yaml and its trained TorchScript actor; tests/golden/make_policy_fixture.py).  The training-side observation of this build -- the oracle's
+    compute_observations, which the HIP env step is held to entry by entry in tests/test_gpu_env.py -- must BE that vector on the same state: layout,
+    scales, default pose, the gait-gated phase entries, the previous (clipped) actions; then the clip and the joint targets the class derives."""
+    import oracle.task_ref as tr
+    from booster_gym_amd.utils.config import load_cfg
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", "deploy_policy.npz"))
+    cfg = load_cfg("T1", {})
+    names = flat_model.dof_names
+    dja = cfg["init_state"]["default_joint_angles"]
+    default = np.array([([v for k, v in dja.items() if k != "default" and k in n] or [dja["default"]])[-1] for n in names], dtype=np.float64)
+    assert np.array_equal(default.astype(np.float32), d["default_qpos"][11:])  # robot joints 11..22 = the 12 policy DoFs (policy.py:60)
+    nz = cfg["normalization"]
+    norm = dict(gravity=nz["gravity"], lin_vel=nz["lin_vel"], ang_vel=nz["ang_vel"], dof_pos=nz["dof_pos"], dof_vel=nz["dof_vel"], push_force=0.1, push_torque=0.5)
+    E, T = d["obs"].shape[:2]
+    prev = np.concatenate([np.zeros((E, 1, 12), np.float32), d["actions"][:, :-1]], axis=1)  # obs[35:47] = the actions of the call before (policy.py:62)
+    flat = lambda a: a.reshape(E * T, *a.shape[2:]).astype(np.float64)
+    K = E * T
+    s = dict(projected_gravity=flat(d["projected_gravity"]), base_ang_vel=flat(d["base_ang_vel"]), commands=flat(d["smoothed_commands"]),
+             gait_frequency=flat(d["gait_frequency"]), gait_process=flat(d["gait_process"]), dof_pos=flat(d["dof_pos"])[:, 11:], dof_vel=flat(d["dof_vel"])[:, 11:],
+             actions=flat(prev), root_states=np.zeros((K, 13)), base_mass_scaled=np.zeros((K, 4)), base_lin_vel=np.zeros((K, 3)), push_force=np.zeros((K, 3)),
+             push_torque=np.zeros((K, 3)))
+    obs, _ = tr.compute_observations(s, norm, default, None, noisy=None)
+    ref = flat(d["obs"])
+    closed = s["gait_frequency"] == 0
+    assert 10 <= closed.sum() < K  # both states of the gait gate are in the fixture
+    # the deploy code also multiplies the commands by the gate (policy.py:49-57); the env does not need to: its standing envs carry commands of exactly
+    # zero (t1.py:381-386), and here the gate closes below |smoothed command| = 1e-5
+    assert np.abs(obs[closed, 6:9]).max() < 1e-5 and np.all(ref[closed, 6:11] == 0)
+    cols = np.r_[0:6, 9:47]
+    assert np.allclose(obs[:, cols], ref[:, cols], rtol=0, atol=2e-6), np.abs(obs[:, cols] - ref[:, cols]).max()
+    assert np.allclose(obs[~closed, 6:9], ref[~closed, 6:9], rtol=0, atol=1e-7)
+    # what the class does with the network's output: clip to +-clip_actions, targets = default pose + action_scale * actions on the 12 leg joints
+    clip = float(nz["clip_actions"])
+    assert np.abs(d["raw_actions"]).max() > clip  # (the clip is exercised)
+    assert np.array_equal(np.clip(d["raw_actions"], -clip, clip), d["actions"])
+    tgt = np.tile(d["default_qpos"], (E, T, 1)); tgt[..., 11:] += np.float32(cfg["control"]["action_scale"]) * d["actions"]
+    assert np.array_equal(tgt, d["dof_targets"])
+    # the smoothing of policy.py:39-40: the commands move towards their set point by at most dt * decimation per call
+    step = np.abs(np.diff(d["smoothed_commands"], axis=1)).max()
+    assert step <= float(d["policy_interval"]) * (1 + 1e-6) and abs(float(d["policy_interval"]) - cfg["sim"]["dt"] * cfg["control"]["decimation"]) < 1e-12
+
+
 # ------------------------------------------------------------------ product headers compiled for the host vs the oracle
 @pytest.fixture(scope="module")
 def harness(tmp_path_factory):
@@ -298,9 +343,44 @@ def harness(tmp_path_factory):
     libs = {}
     for name in ("harness", "rng_harness"):
         so = str(d / f"lib{name}.so")
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-o", so, os.path.join(HERE, "host_harness", f"{name}.cpp")])
+        subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared"] + (SAN_FLAGS if SANITIZE else ["-O2"]) + ["-o", so, os.path.join(HERE, "host_harness", f"{name}.cpp")])
         libs[name] = C.CDLL(so)
     return libs
+
+
+# BG_SANITIZE=1 (set by tests/test_sanitizers.py, which re-runs the host-code tests of this file in a child process under LD_PRELOAD=libasan): every
+# piece of native host code these tests touch is built with the address and undefined-behaviour sanitizers -- the harnesses above, the oracle's C
+# source (oracle/dyn_ref.py honours the same variable) and the URDF loader + model object of the product as a stand-alone library (below)
+SANITIZE = os.environ.get("BG_SANITIZE", "0") == "1"
+SAN_FLAGS = ["-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-fno-sanitize-recover=undefined"]
+_san_urdf_lib = None
+
+
+def _urdf_lib():
+    """The library that exports bg_model_load_urdf: the product's, or (BG_SANITIZE) csrc/bg_urdf.cpp + csrc/bg_model.cpp built by g++ with sanitizers."""
+    global _san_urdf_lib
+    from booster_gym_amd import _lib
+
+    if not SANITIZE:
+        return _lib.load()
+    if _san_urdf_lib is None:
+        import tempfile
+
+        so = os.path.join(tempfile.mkdtemp(prefix="bg_san_"), "libbgurdf_san.so")
+        src = os.path.join(ROOT, "booster_gym_amd", "csrc")
+        subprocess.check_call(["g++", "-std=c++17", "-fPIC", "-shared"] + SAN_FLAGS + ["-o", so, os.path.join(src, "bg_urdf.cpp"), os.path.join(src, "bg_model.cpp")])
+        l = C.CDLL(so)
+        l.bg_last_error.restype = C.c_char_p
+        l.bg_model_body_name.restype = C.c_char_p
+        l.bg_model_dof_name.restype = C.c_char_p
+        l.bg_model_body_name.argtypes = [C.c_void_p, C.c_int32]
+        l.bg_model_dof_name.argtypes = [C.c_void_p, C.c_int32]
+        l.bg_model_find_body.argtypes = [C.c_void_p, C.c_char_p]
+        l.bg_model_load_urdf.argtypes = [C.c_char_p, C.c_void_p, C.c_void_p]
+        l.bg_model_get.argtypes = [C.c_void_p, C.c_void_p]
+        l.bg_model_destroy.argtypes = [C.c_void_p]
+        _san_urdf_lib = l
+    return _san_urdf_lib
 
 
 def test_product_rng_header_matches_oracle_philox(harness):
@@ -603,7 +683,7 @@ def _load_urdf_c(path, collapse=1, feet=("left_foot_link", "right_foot_link"), b
 
     from booster_gym_amd import _lib
 
-    lib = _lib.load()
+    lib = _urdf_lib()
     opt = _lib.AssetOptions()
     opt.collapse_fixed_joints, opt.body_contacts, opt.self_collisions = collapse, body_contacts, self_collisions
     opt.foot_names[0], opt.foot_names[1] = feet[0].encode(), feet[1].encode()
@@ -616,7 +696,7 @@ def _load_urdf_c(path, collapse=1, feet=("left_foot_link", "right_foot_link"), b
     if rc != 0:
         return rc, lib.bg_last_error().decode(), None, None
     d = _lib.ModelDesc()
-    _lib.check(lib.bg_model_get(h, C.byref(d)))
+    assert lib.bg_model_get(h, C.byref(d)) == 0
     names = ([lib.bg_model_body_name(h, i).decode() for i in range(d.num_bodies)], [lib.bg_model_dof_name(h, j).decode() for j in range(d.num_dofs)])
     found = (lib.bg_model_find_body(h, b"Trunk"), lib.bg_model_find_body(h, b"right_foot_link"), lib.bg_model_find_body(h, b"nope"))
     assert lib.bg_model_body_name(h, 99) is None
