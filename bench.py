@@ -58,7 +58,7 @@ ABA_BYTES = 4 * (13 + 12 + 12 + 12 + 6 + 18 + 6 + 58)  # forward_dynamics_kernel
 from booster_gym_amd import _lib  # noqa: E402  (raw ABI calls for the kernel-level timings)
 
 
-PMC_TAG = "r04"
+PMC_TAG = "r05"
 PMC_SOURCE = (f"profiles/{PMC_TAG}_bench_pmc.json / profiles/{PMC_TAG}_env_pmc.json: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes of "
               "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra` and `tools/prof_env.py 4096 plane` (tools/profile.sh); "
               "hbm_bytes = 2 x FETCH_SIZE + WRITE_SIZE for the 16-byte-per-lane MFMA layer kernels (the guide's gfx950 correction), FETCH_SIZE + WRITE_SIZE otherwise")
@@ -75,10 +75,26 @@ def pmc_traffic(kernel_prefix, which="bench"):
         return None
 
 
+ABA_PMC_FILE = f"profiles/{PMC_TAG}_aba_pmc.json"            # tools/profile_aba.sh <tag>: the one file both the numbers and their citation come from
+ABA_STATS_FILE = f"profiles/{PMC_TAG}_aba_kernel_stats.csv"
+ABA_BYTES_SURVEY_8D = 500  # SURVEY section 8(d)'s figure for the same kernel: it counts 13 + 39 inertial parameters where this build reads 58 (+ foot materials) and writes the 6 foot-force floats
+
+
+def pmc_ratio(kernel_prefix, num, den, which="env"):
+    """Ratio of two counters of a kernel in the committed PMC summary (e.g. SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES = the share of its waves' cycles in which
+    the vector ALU is busy); None if the profile is absent."""
+    try:
+        ks = json.load(open(os.path.join(ROOT, "profiles", f"{PMC_TAG}_{which}_pmc.json")))["kernels"]
+        k = next(v for name, v in ks.items() if name.startswith(kernel_prefix))
+        return float(k[num]["mean"]) / float(k[den]["mean"])  # (both in quad-cycles)
+    except (OSError, StopIteration, KeyError, ValueError, ZeroDivisionError):
+        return None
+
+
 def _aba_pmc():
     """Per-launch HBM bytes and VALU instructions per wave of the ABA launch's kernels from this round's rocprofv3 passes (tools/profile_aba.sh)."""
     try:
-        ks = json.load(open(os.path.join(ROOT, "profiles", "r04_a_aba_pmc.json")))["kernels"]
+        ks = {k: v for k, v in json.load(open(os.path.join(ROOT, ABA_PMC_FILE)))["kernels"].items() if "pk_kernel" not in k}
         return {k.split("<")[0]: {"hbm_bytes": v.get("hbm_bytes"), "valu_per_wave": v.get("valu_per_wave")} for k, v in ks.items()}
     except (OSError, KeyError, ValueError):
         return None
@@ -103,10 +119,10 @@ def aba_roofline(n=1 << 20, launches=50):
 
     cold = []
 
-    def measure(root, q, qd, tau):
+    def measure(root, q, qd, tau, entry="bg_env_forward_dynamics"):
         root, q, qd, tau = (t.to(dev).contiguous() for t in (root, q, qd, tau))
-        call = lambda: _lib.check(lib.bg_env_forward_dynamics(env._env, _lib.ptr(root), _lib.ptr(q), _lib.ptr(qd), _lib.ptr(tau), None, _lib.ptr(qacc),
-                                                              _lib.current_stream_ptr()), "bg_env_forward_dynamics")
+        fn = getattr(lib, entry)
+        call = lambda: _lib.check(fn(env._env, _lib.ptr(root), _lib.ptr(q), _lib.ptr(qd), _lib.ptr(tau), None, _lib.ptr(qacc), _lib.current_stream_ptr()), entry)
         # The part's clock under this kernel is a transient for the first ~40 ms of back-to-back launches (tools/aba_series.py, profiles/r04_aba_series.txt:
         # 226 us for launches 1-4 from idle, up to 270 around launch 12, then a steady decline to 205-206 us from launch ~160 on, where it stays).
         # The roofline figure is the sustained rate: 200 untimed launches, then the median of three series.
@@ -138,6 +154,7 @@ def aba_roofline(n=1 << 20, launches=50):
     qd = torch.randn(n, 12, generator=g)
     tau = (torch.rand(n, 12, generator=g) * 2 - 1) * 20
     us = measure(root, q, qd, tau)
+    us_pk = measure(root, q, qd, tau, entry="bg_env_forward_dynamics_packed")
     # SURVEY 8(d) K1 inputs
     lo, hi, eff = (torch.tensor(a, dtype=torch.float32) for a in (m.dof_lower, m.dof_upper, m.dof_effort))
     root2 = torch.zeros(n, 13); root2[:, 2] = 0.72
@@ -146,28 +163,43 @@ def aba_roofline(n=1 << 20, launches=50):
     root2[:, 3:6] = ax * torch.sin(ang / 2)[:, None]; root2[:, 6] = torch.cos(ang / 2)
     q2 = lo + (hi - lo) * torch.rand(n, 12, generator=g)
     tau2 = (torch.rand(n, 12, generator=g) * 2 - 1) * eff
-    us2 = measure(root2, q2, torch.randn(n, 12, generator=g), tau2)
+    qd2 = torch.randn(n, 12, generator=g)
+    us2 = measure(root2, q2, qd2, tau2)
+    us2_pk = measure(root2, q2, qd2, tau2, entry="bg_env_forward_dynamics_packed")
     gbs, gbs2 = n * ABA_BYTES / us / 1e3, n * ABA_BYTES / us2 / 1e3
+    valu_busy = pmc_ratio("forward_dynamics_kernel", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", which="aba")
+    valu_busy_pk = pmc_ratio("forward_dynamics_pk_kernel", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", which="aba")
     pmc = _aba_pmc()
     traffic = sum(v["hbm_bytes"] for v in pmc.values() if v.get("hbm_bytes")) if pmc else None
     return {"kernel": "bg_env_forward_dynamics = forward_dynamics_kernel (hand-written HIP, ONE launch: an ABA substep with sole contact, joint limits and the "
                       "leg-against-leg narrow phase item-parallel through LDS; per-step joint accelerations)",
             "bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": traffic,
-            "traffic_source": "profiles/r04_b_aba_pmc.json (tools/profile_aba.sh: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in separate passes "
+            "traffic_source": f"{ABA_PMC_FILE} (tools/profile_aba.sh {PMC_TAG}: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE | SQ_* in separate passes "
                               "of tools/aba_only.py, the same launch); FETCH_SIZE + WRITE_SIZE as reported: dword-per-lane accesses, whose width the guide "
-                              "calls uncalibrated on gfx950, and inputs that stay in the 256 MB Infinity Cache between launches -- indicative only",
+                              "calls uncalibrated on gfx950 -- indicative only",
+            "traffic_note": "inputs partly Infinity-Cache-resident: identical back-to-back launches keep about half of the 575 MB of inputs in the 256 MB cache, so "
+                            "`traffic` is below the algorithmic bytes and `frac` is an algorithmic-bytes rate against the HBM roof, not measured HBM traffic",
+            "bytes_per_env": {"this_build": ABA_BYTES, "survey_8d": ABA_BYTES_SURVEY_8D},
+            "frac_with_survey_8d_bytes": n * ABA_BYTES_SURVEY_8D / us / 1e3 / HBM_PEAK_GBS,
             "avg_launch_us": us, "num_envs": n, "algorithmic_bytes_per_launch": n * ABA_BYTES, "state": "standing_noise_0.1",
             "timing": "sustained rate: 200 untimed launches, then the median of three series of 50 (HIP events on the launch stream).  launches_4_to_33_from_idle_us is "
                       "the figure rounds 1-3 reported as avg_launch_us (round 3: 305 us): the clock under this kernel is a transient for the first ~40 ms "
-                      "(profiles/r04_aba_series.txt); round 3's kernels sustain 263-266 us in this regime",
+                      "(profiles/r04_aba_series.txt)",
             "launches_4_to_33_from_idle_us": cold[0],
-            "kernels_per_launch_rocprof": "profiles/r04_b_aba_kernel_stats.csv: forward_dynamics_kernel over 1,200 launches (the first ~160 in the clock transient); "
-                                          "PMC passes (12 launches each): profiles/r04_b_aba_pmc.json; round 3: a second, gathering kernel of 79 us for the envs whose legs are close",
-            "survey_8d_state": {"avg_launch_us": us2, "achieved": gbs2, "frac": gbs2 / HBM_PEAK_GBS, "launches_4_to_33_from_idle_us": cold[1],
+            "kernels_per_launch_rocprof": f"{ABA_STATS_FILE}: forward_dynamics_kernel over 1,200 launches (the first ~160 in the clock transient); "
+                                          f"PMC passes (12 launches each): {ABA_PMC_FILE}",
+            "survey_8d_state": {"avg_launch_us": us2, "achieved": gbs2, "frac": gbs2 / HBM_PEAK_GBS,
+                                "frac_with_survey_8d_bytes": n * ABA_BYTES_SURVEY_8D / us2 / 1e3 / HBM_PEAK_GBS, "launches_4_to_33_from_idle_us": cold[2],
                                 "state": "joints ~ U(limits), trunk at 0.72 m within 0.3 rad of upright, torques ~ U(+-effort), qd ~ N(0, 1)"},
-            "note": "VALU-issue bound (SQ counters in the PMC file: the SIMDs issue VALU 100 % of the wave cycles of forward_dynamics_kernel at 4 cycles per "
-                    "instruction, at the ~2.15 GHz the part sustains under this load); itemised instruction budget: tools/isa_census.py, "
-                    "profiles/r04_aba_isa_census_plane_t1.json, DESIGN.md section 6"}
+            "packed_form": {"kernel": "bg_env_forward_dynamics_packed = forward_dynamics_pk_kernel: one env per lane, both legs in 64-bit register pairs "
+                                      "(v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32), ~420 registers, one wave per SIMD",
+                            "avg_launch_us": us_pk, "frac": n * ABA_BYTES / us_pk / 1e3 / HBM_PEAK_GBS, "survey_8d_state_avg_launch_us": us2_pk,
+                            "valu_busy_share_of_wave_cycles": valu_busy_pk,
+                            "note": "43 % fewer VALU instructions per env than the lane-per-leg kernel and no faster: a lone wave per SIMD keeps the vector ALU "
+                                    "busy about half of its life (HISTORY.md, round 5); not the default"},
+            "valu_busy_share_of_wave_cycles": valu_busy, "waves_per_simd": 2,
+            "note": "vector-ALU bound: two waves share a SIMD and each has the vector ALU busy in valu_busy_share_of_wave_cycles of its cycles (SQ_ACTIVE_INST_VALU / "
+                    "SQ_WAVE_CYCLES of forward_dynamics_kernel in the PMC file), i.e. the SIMD's ALU is busy twice that share; itemised instruction budget: tools/isa_census.py, profiles/r04_aba_isa_census_plane_t1.json, DESIGN.md section 6"}
 
 
 def cpu_baseline(n_envs=4096):
@@ -188,6 +220,14 @@ def cpu_baseline(n_envs=4096):
     out = run(n_envs)
     one = run(max(1024, n_envs // 4), threads=1)
     out["single_thread"] = {k: one[k] for k in ("value", "unit", "cores", "num_envs", "phase_s", "sample")}
+    # `cores` = what this process may really use (affinity mask and cgroup CPU quota: oracle/cpu_baseline.py).  When the host shows more cores than that,
+    # the same workload once more with one thread per VISIBLE core, so that the line carries SURVEY 8(d)'s "OMP_NUM_THREADS = nproc" figure beside it
+    if out.get("host_cores_visible", 0) > out["cores"]:
+        try:
+            allc = run(n_envs, threads=out["host_cores_visible"])
+            out["all_visible_cores"] = {k: allc[k] for k in ("value", "unit", "cores", "num_envs", "phase_s")}
+        except Exception as ex:
+            out["all_visible_cores"] = {"error": repr(ex)}
     return out
 
 
@@ -400,6 +440,28 @@ def main():
         # HBM traffic per launch comes from PMC counters, which rocprofv3 collects in separate passes of the same command (tools/profile.sh
         # -> profiles/<PMC_TAG>_*_pmc.json, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes); the JSON line names the file it cites
         traffic = pmc_traffic("env_step_kernel", which="env") if N == 4096 else None
+        env_valu_busy = pmc_ratio("env_step_kernel", "SQ_ACTIVE_INST_VALU", "SQ_WAVE_CYCLES", which="env") if N == 4096 else None
+        # backward-data chains (dX = G W of the hidden layers, ELU' and bias-gradient sums in the epilogues): the critic's on the side stream, the actor's
+        # on the main stream; priced like the forward pair, over the span from the first start to the last end of each mini-epoch's two chains
+        bwc = [e for e in runner._critic_tr.timed_events if e[5] == "backward"]
+        bwa = [e for e in runner._actor_tr.timed_events if e[5] == "backward"]
+        backward = None
+        if bwc and len(bwc) == len(bwa):
+            bspans = []
+            for (c0, c1, *_), (a0, a1, *_) in zip(bwc, bwa):
+                first = a0 if a0.elapsed_time(c0) >= 0 else c0
+                last = c1 if a1.elapsed_time(c1) >= 0 else a1
+                bspans.append(first.elapsed_time(last))
+            bus = sum(bspans) / len(bspans) * 1e3
+            bfl = bwc[0][3] + bwa[0][3]
+            backward = {"kernel": "mlp_fwd_kernel<256,2,2> / <128,2,2> / <128,2,1>: the backward-data GEMMs of both networks' hidden layers (dX = G W with ELU' and the "
+                                  "bias-gradient column sums in the epilogue), two chains of two launches on two streams",
+                        "bound": "mfma", "achieved": bfl / (bus * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": bfl / (bus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+                        "avg_launch_us": bus, "algorithmic_flops_per_launch": bfl,
+                        "per_chain_in_the_loop_us": {"critic": sum(a.elapsed_time(b) for a, b, *_ in bwc) / len(bwc) * 1e3,
+                                                     "actor": sum(a.elapsed_time(b) for a, b, *_ in bwa) / len(bwa) * 1e3},
+                        "note": "flops of both chains / time from the first start to the last end of the pair, HIP events on the two launch streams inside the timed "
+                                "loop; the head kernels (loss + output layers) run at the front of the same span"}
         out = {
             "metric": "env-steps/sec (whole node), PPO rollout+update, T1 4096 envs/GPU",
             "value": world * N * T * args.steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -417,7 +479,9 @@ def main():
             "roofline_env_step": {"kernel": "env_step_kernel (hand-written HIP: 10 ABA substeps + task logic, one launch per env-step)", "bound": "hbm",
                                   "achieved": sim_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": sim_gbs / HBM_PEAK_GBS, "traffic": traffic,
                                   "traffic_source": PMC_SOURCE, "avg_launch_us": step_ms * 1e3, "algorithmic_bytes_per_launch": env_bytes,
-                                  "note": "issue-latency-bound at 128 waves: SQ counters in profiles/ show VALU busy 73% of wave cycles at 4 cycles/instruction"},
+                                  "valu_busy_share_of_wave_cycles": env_valu_busy,
+                                  "note": f"issue-latency-bound at 128 waves, one per SIMD on half of the CUs: SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES in profiles/{PMC_TAG}_env_pmc.json "
+                                          "(valu_busy_share_of_wave_cycles)"},
             "roofline_update": {"bound": "mfma", "achieved": flops / (upd_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
                                 "frac": flops / (upd_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF,
                                 "note": "all actor+critic GEMM flops of the update phase / update-phase wall time (which also holds GAE, loss, ELU, Adam)"},
@@ -425,6 +489,8 @@ def main():
         }
         if wgrad is not None:
             out["roofline_wgrad"] = wgrad
+        if backward is not None:
+            out["roofline_backward"] = backward
         if world == 1 and not args.no_extra:
             try:
                 # Opt-in form of the layer kernels, measured beside the headline and NOT part of `value`: BG_GEMM_SPLIT (bg_mlp_split.hip) runs the

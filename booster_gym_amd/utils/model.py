@@ -339,7 +339,16 @@ class MLPTrainer:
         layer's weight / bias gradients have already been written by the fused head kernel.  finishes (a list): the fused backward layers run
         without their column-sum finish and append its descriptor (_lib.ReduceProblem) instead; the caller runs them later with
         utils.reduce_group (the bias gradients are not needed before the optimiser step)."""
+        timed = self.timed_layer is not None
+        if timed:  # bench.py: HIP events on the launch stream around this network's backward-data chain
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
         self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g, finishes)
+        if timed:
+            e1.record()
+            # dX = G W of every hidden layer but the first (whose input gradient nobody needs): 2 B C_out C_in each
+            fl = 2.0 * self._B * sum(l.weight.shape[0] * l.weight.shape[1] for l in self.layers[1:-1])
+            self.timed_events.append((e0, e1, self._B, fl, None, "backward"))
 
     # The backward chain computes only dL/dz; the weight gradients of all layers run afterwards, when both networks' chains are done and nothing
     # else competes for the GPU: the grouped launch (GroupedWeightGrad.run); shapes outside its range run as library GEMMs there.

@@ -17,15 +17,32 @@ import time
 
 
 def _cpu_share():
-    """Threads this process may really use: the affinity mask, capped at 16 (the GPU box gives 16 cores per GPU)."""
+    """Threads this process may really use: the affinity mask, cut down to the cgroup's CPU quota where there is one (cgroup v2 cpu.max, v1
+    cpu.cfs_quota_us / cpu.cfs_period_us).  Returns (threads, where the number comes from)."""
     try:
-        n = len(os.sched_getaffinity(0))
+        n, src = len(os.sched_getaffinity(0)), "affinity mask"
     except AttributeError:
-        n = os.cpu_count() or 1
-    return max(1, min(n, 16))
+        n, src = os.cpu_count() or 1, "os.cpu_count"
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except (OSError, ValueError):
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n, src = max(1, int(quota + 0.5)), f"cgroup CPU quota ({quota:.1f} cores) below the affinity mask"
+    return max(1, n), src
 
 
-_THREADS = int(os.environ.get("BG_CPU_THREADS", _cpu_share()))
+_SHARE, _SHARE_SOURCE = _cpu_share()
+_THREADS = int(os.environ.get("BG_CPU_THREADS", _SHARE))
 os.environ["OMP_NUM_THREADS"] = str(_THREADS)  # before numpy / torch / the oracle's libgomp start their pools
 os.environ.setdefault("OMP_WAIT_POLICY", "PASSIVE")
 
@@ -108,7 +125,7 @@ def main(n=4096, horizon=24, mini_epochs=20):
     t_upd = time.perf_counter() - t0
     total = t_roll + t_upd
     print(json.dumps({"value": n * horizon / total, "unit": "env-steps/s", "cores": cores, "kind": "port", "cpu_model": _cpu_model(),
-                      "host_cores_visible": os.cpu_count(), "num_envs": n,
+                      "host_cores_visible": os.cpu_count(), "cores_source": "BG_CPU_THREADS" if "BG_CPU_THREADS" in os.environ else _SHARE_SOURCE, "num_envs": n,
                       "phase_s": {"rollout": t_roll, "rollout_physics_only": t_phys, "update": t_upd},
                       "sample": f"{n} envs x {horizon} env-steps, task logic included (observations, rewards, termination, resets, resampling, noise: "
                                 f"oracle/task_ref.py) around fp32 physics (oracle/dyn_ref.c as libdynref32.so, OpenMP over envs) + torch-CPU actor, then "

@@ -14,6 +14,12 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $CMD 1200 
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD > $OUT.pmc1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD > $OUT.pmc2.log 2>&1
 rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD > $OUT.pmc3.log 2>&1
+# ... and the packed form of the same launch (bg_env_forward_dynamics_packed: forward_dynamics_pk_kernel) into the same summary
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_pk -- $CMD 1200 1 > $OUT.trace_pk.log 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- $CMD 12 1 > $OUT.pmc4.log 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- $CMD 12 1 > $OUT.pmc5.log 2>&1
+rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq -- $CMD 12 1 > $OUT.pmc6.log 2>&1
+cp $(ls -t $OUT/trace_pk/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_aba_packed_kernel_stats.csv
 cp $(ls -t $OUT/trace/*/*kernel_stats.csv | head -1) $R/gpurun_out/${TAG}_aba_kernel_stats.csv
 python3 - "$OUT" "$R/gpurun_out/${TAG}_aba_pmc.json" <<'PY'
 import collections, csv, glob, json, os, sys
