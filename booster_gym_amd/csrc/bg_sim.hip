@@ -63,11 +63,11 @@ struct DppSwap {
     }
 };
 
-#ifndef BG_ENV_SELF_MODE
-#define BG_ENV_SELF_MODE SELF_INLINE
-#endif
 struct LdsSink {
-    static constexpr int SELF = BG_ENV_SELF_MODE;
+    // the fused env step runs the leg-against-leg narrow phase lane per leg (SELF_INLINE).  The item-parallel LDS form of the ABA kernel needs the whole
+    // wave converged at its call site (a ballot, and worker lanes acting for other envs); the env-step kernels call the lane code under lane-divergent
+    // branches (trunk-low gate), and it was slower here anyway (108.3 against 104.7 us, HISTORY.md round 4): not selectable
+    static constexpr int SELF = SELF_INLINE;
     float* obs; float* priv; int el;
     lds_f32* self_sc; int lane;
     // sweep work space of the fused step: everything in registers.  (Staging the link constants in LDS as forward_dynamics_kernel does

@@ -165,6 +165,7 @@ class Runner:
         self.learning_rate = self.cfg["algorithm"]["learning_rate"]
         self.model = ActorCritic(self.env.num_actions, self.env.num_obs, self.env.num_privileged_obs).to(self.device)
         self.dp.broadcast_parameters(self.model)  # identical initial weights on every rank
+        self.invalidate()
         self.optimizer = FlatAdam(self.model.parameters(), lr=self.learning_rate)
         self._load()
         # Resume semantics of the reference (runner.py:31-34,174-180): the restored param_group lr serves the FIRST optimiser step only; the
@@ -299,6 +300,7 @@ class Runner:
         print("Loading model from {}".format(ck))
         model_dict = torch.load(ck, map_location=self.device, weights_only=True)
         self.model.load_state_dict(model_dict["model"], strict=False)
+        self.invalidate()
         try:
             self.env.curriculum_prob = model_dict["curriculum"]
         except Exception as e:
@@ -307,6 +309,17 @@ class Runner:
             self.optimizer.load_state_dict(model_dict["optimizer"])
         except Exception as e:
             print(f"Failed to load optimizer: {e}")
+
+    def invalidate(self):
+        """Call after changing the model's parameters or the rollout buffers by any means other than this runner's own rollout() / update() (a
+        checkpoint or test that loads weights, a tool that edits buffer["obses"] / buffer["actions"]).  The contract between the two phases:
+        rollout() may leave the first mini-epoch's forward passes (activations, values, old mu, old log-probabilities of every row) in the trainers'
+        buffers and the weight copies that the layer kernels read current, and update() then trusts both without looking; this forgets them, so the
+        next update() recomputes everything from the parameters and the buffers as they are."""
+        self._fwd_ready = False
+        for tr in (getattr(self, "_actor_tr", None), getattr(self, "_critic_tr", None)):
+            if tr is not None:
+                tr.mirror_fresh = False
 
     def checkpoint_dict(self):
         return {"model": self.model.state_dict(), "optimizer": self.optimizer.state_dict(), "curriculum": self.env.curriculum_prob}
@@ -388,7 +401,11 @@ class Runner:
                 self._logp_done = T
 
     def update(self):
-        """runner.py:123-189: old log-probs, then mini_epochs full-batch optimiser steps."""
+        """runner.py:123-189: old log-probs, then mini_epochs full-batch optimiser steps.
+
+        Contract with rollout(): when rollout() has run the first mini-epoch's forward passes (`_fwd_ready`), this method starts from them and from the
+        weight copies the last optimiser launch wrote -- parameters and rollout buffers must not have been changed in between except through
+        `invalidate()` (which `_load` and the initial broadcast call)."""
         cfg, buf = self.cfg, self.buffer
         T, N = cfg["runner"]["horizon_length"], self.env.num_envs
         B, A = T * N, self.env.num_actions

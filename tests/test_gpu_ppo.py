@@ -250,7 +250,7 @@ def _assert_same_adam_steps(name, p, q, start):
     assert off <= 0.005 and d.max().item() <= 2.0 * moved + 2e-6, (name, off, d.max().item(), moved)
 
 
-@pytest.mark.parametrize("n,E,T", [(128, 3, 24), (4096, 20, 24), (128, 2, 40), (100, 2, 24)])
+@pytest.mark.parametrize("n,E,T", [(128, 3, 24), (256, 5, 24), (4096, 20, 24), (128, 2, 40), (100, 2, 24)])
 def test_full_update_matches_reference_loop(n, E, T):
     """Runner.update() (fused kernels, flat Adam, device-side LR) vs oracle/ppo_ref.ppo_update_reference (the reference loop op by op)
     from the same weights on the same rollout data: parameters after E mini-epochs agree, and so do the logged losses and the LR.
@@ -281,7 +281,7 @@ def test_full_update_matches_reference_loop(n, E, T):
     for (k, p), (k2, q) in zip(r.model.named_parameters(), ref_model.named_parameters()):
         assert k == k2
         _assert_same_adam_steps(k, p, q, p_start[k])
-        if E <= 3:
+        if E <= 5:  # (element-wise closeness holds for a handful of optimiser steps; beyond that the bound above on steps gone astray is the statement)
             assert torch.allclose(p, q, rtol=1e-3, atol=2e-6), (k, (p - q).abs().max().item())
     assert torch.allclose(b["rewards"], rewards_ref, atol=1e-5)  # in-place time-out overwrite, repeated every mini-epoch
     for k in ("value_loss", "actor_loss", "bound_loss", "entropy", "kl_mean"):
