@@ -107,6 +107,37 @@ def test_command_curriculum_matches_reference():
     assert np.allclose([np.abs(lv[:, 0]).mean(), np.abs(lv[:, 1]).mean(), np.abs(lv[:, 0]).max(), np.abs(lv[:, 1]).max()], d["curr_level_stats"], atol=1e-5)
 
 
+def test_recalled_isaacgym_quaternion_helpers_agree_with_scipy():
+    """The task-logic fixtures are generated through a stand-in `isaacgym.torch_utils` whose helpers are restated from recall
+    (tests/golden/_stub/isaacgym/torch_utils.py); the oracle carries its own copies.  A wrong recall would make oracle and fixture agree with each other
+    on wrong numbers, so both are held here to an implementation neither of them was written from -- scipy.spatial.transform.Rotation, xyzw quaternions:
+    quat_rotate / quat_rotate_inverse = R v / R^T v, get_euler_xyz = the roll-pitch-yaw angles of R = Rz(yaw) Ry(pitch) Rx(roll) folded into [0, 2 pi)
+    (the convention the reference's own uses need: t1.py:541-547 wraps them back to [-pi, pi), play_mujoco.py:282-297 pins quat_rotate_inverse),
+    quat_from_euler_xyz = its inverse."""
+    import importlib.util
+
+    from scipy.spatial.transform import Rotation
+
+    spec = importlib.util.spec_from_file_location("stub_torch_utils", os.path.join(HERE, "golden", "_stub", "isaacgym", "torch_utils.py"))
+    stub = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(stub)
+    rng = np.random.default_rng(7)
+    q = rng.normal(size=(500, 4)); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    v = rng.normal(size=(500, 3))
+    R = Rotation.from_quat(q)  # scipy: scalar-last (x, y, z, w), like Isaac Gym
+    tq, tv = torch.tensor(q), torch.tensor(v)
+    assert np.allclose(stub.quat_rotate(tq, tv).numpy(), R.apply(v), atol=1e-12) and np.allclose(tr.quat_rotate(q, v), R.apply(v), atol=1e-12)
+    assert np.allclose(stub.quat_rotate_inverse(tq, tv).numpy(), R.inv().apply(v), atol=1e-12) and np.allclose(tr.quat_rotate_inverse(q, v), R.inv().apply(v), atol=1e-12)
+    rpy = R.as_euler("xyz")  # extrinsic x-y-z = Rz(yaw) Ry(pitch) Rx(roll)
+    keep = np.abs(np.abs(rpy[:, 1]) - np.pi / 2) > 1e-3  # (away from the gimbal lock, where the split between roll and yaw is a convention)
+    wrap = lambda a: (a + np.pi) % (2 * np.pi) - np.pi
+    for got in (np.stack([a.numpy() for a in stub.get_euler_xyz(tq)], axis=1), np.stack(tr.get_euler_xyz(q), axis=1)):
+        assert got.min() >= 0 and got.max() < 2 * np.pi + 1e-12
+        assert np.abs(wrap(got[keep] - rpy[keep])).max() < 1e-9
+    back = stub.quat_from_euler_xyz(torch.tensor(rpy[:, 0]), torch.tensor(rpy[:, 1]), torch.tensor(rpy[:, 2])).numpy()
+    assert np.allclose(np.abs(np.sum(back * q, axis=1)), 1.0, atol=1e-9)  # the same rotation (q and -q are)
+
+
 def test_philox_known_answer():
     # Random123 known-answer vectors for philox4x32-10
     o = tr.philox4x32_10(0, 0, np.uint32(0), np.uint32(0), np.uint32(0), np.uint32(0))
