@@ -65,7 +65,24 @@ class DataParallel:
                 dist.broadcast_object_list(box, src=0)
                 return box[0]
 
-            self.comm = RcclComm(self.rank, self.world_size, self.device_index, exchange_id)
+            comm, err = None, None
+            try:
+                comm = RcclComm(self.rank, self.world_size, self.device_index, exchange_id)
+            except Exception as ex:  # (library without the C entry points, a failed bootstrap, ...)
+                err = ex
+            # every rank takes the same path: the own communicator only if it came up EVERYWHERE, otherwise the process group's collectives (still RCCL,
+            # on the group's stream) -- loudly
+            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=f"cuda:{self.device_index}")
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+            if int(ok.item()) == 1:
+                self.comm = comm
+            else:
+                import warnings
+
+                warnings.warn(f"own RCCL communicator unavailable on at least one rank ({err!r} here): the per-mini-epoch exchanges go through torch.distributed's "
+                              "NCCL backend (+0.5 ms per iteration of stream hand-overs, DESIGN.md section 8)")
+                if comm is not None:
+                    comm.destroy()
 
     @property
     def active(self):
