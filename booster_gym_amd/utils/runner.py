@@ -25,6 +25,8 @@ import os
 import random
 import time
 
+import types
+
 import numpy as np
 import torch
 
@@ -406,6 +408,19 @@ class Runner:
         Contract with rollout(): when rollout() has run the first mini-epoch's forward passes (`_fwd_ready`), this method starts from them and from the
         weight copies the last optimiser launch wrote -- parameters and rollout buffers must not have been changed in between except through
         `invalidate()` (which `_load` and the initial broadcast call)."""
+        u = self._update_begin()
+        with torch.no_grad():
+            for epoch in range(self.cfg["runner"]["mini_epochs"]):
+                # this mini-epoch's hidden activations and values may be the rollout's: same kernels, same weights
+                have_fwd = u.ahead and epoch == 0
+                self._epoch_critic_forward_and_gae(u, have_fwd)
+                self._epoch_losses_and_backward(u, have_fwd)
+                self._epoch_gradients_and_step(u)
+        return self._stats_acc
+
+    def _update_begin(self):
+        """What update() does once per call: inputs of both networks, old mu / log-std / log-probabilities (runner.py:123-129) unless rollout() left them,
+        zeroed accumulators, the CU split of the forward launches.  Returns the namespace the three phases of a mini-epoch share."""
         cfg, buf = self.cfg, self.buffer
         T, N = cfg["runner"]["horizon_length"], self.env.num_envs
         B, A = T * N, self.env.num_actions
@@ -439,141 +454,159 @@ class Runner:
         self._stats_acc.zero_()
         self._stats.zero_()
         self._grad_logstd.zero_()
-        mirrors = None
         self._plan_chain_split(critic_all.shape[0], B)
         # Two HIP streams: the actor and the critic are independent networks, so the HBM-bound elementwise kernels of one overlap
         # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
         main = torch.cuda.current_stream()
         side = self._side_stream
-        with torch.no_grad():
-            for epoch in range(cfg["runner"]["mini_epochs"]):
-                have_fwd = ahead and epoch == 0  # this mini-epoch's hidden activations and values are the rollout's: same kernels, same weights
-                # parameters updated by the previous optimiser step; the loss accumulators (_stats, _grad_logstd) were zeroed by it (before the loop
-                # for the first mini-epoch): both heads add into them
-                # the chained forward kernel also evaluates the value head, from the registers that hold the last activations: the launch between the
-                # critic's forward and the actor's loss then has 400 KB to read instead of 52 MB
-                chain_values = fused_head and self._fused_gae and self._chain_values and self._critic_tr.chainable_for(critic_all, B)
-                self._critic_tr.value_head = (c_out.weight.reshape(-1), c_out.bias, self._values_all) if chain_values else None
+        return types.SimpleNamespace(cfg=cfg, buf=buf, T=T, N=N, B=B, A=A, alg=alg, act_flat=act_flat, ahead=ahead, obs_flat=obs_flat, critic_all=critic_all,
+                                     fused_head=fused_head, logstd_flat=logstd_flat, a_out=a_out, c_out=c_out, old_mu=old_mu, old_logstd=old_logstd, main=main, side=side,
+                                     mirrors=None)
+
+    def _epoch_critic_forward_and_gae(self, u, have_fwd):
+        """Side stream: the critic's forward pass (unless the rollout ran it), values, time-out bootstrap, GAE, returns, advantage moments and their
+        exchange (runner.py:132-145).  Leaves hc / values / gae_done in u."""
+        cfg, buf, T, N, B, alg, critic_all, fused_head, c_out, main, side = u.cfg, u.buf, u.T, u.N, u.B, u.alg, u.critic_all, u.fused_head, u.c_out, u.main, u.side
+        # parameters updated by the previous optimiser step; the loss accumulators (_stats, _grad_logstd) were zeroed by it (before the loop
+        # for the first mini-epoch): both heads add into them
+        # the chained forward kernel also evaluates the value head, from the registers that hold the last activations: the launch between the
+        # critic's forward and the actor's loss then has 400 KB to read instead of 52 MB
+        chain_values = fused_head and self._fused_gae and self._chain_values and self._critic_tr.chainable_for(critic_all, B)
+        self._critic_tr.value_head = (c_out.weight.reshape(-1), c_out.bias, self._values_all) if chain_values else None
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            if fused_head:
+                if have_fwd:
+                    hc = self._critic_tr.acts[2]
+                else:
+                    hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
+                if self._fused_gae:
+                    # output layer + timeout bootstrap + GAE + returns + advantage moments in ONE launch in front of the actor's loss
+                    v_all = critic_values_gae(None if chain_values else hc, c_out.weight, c_out.bias, buf["rewards"], buf["dones"], buf["time_outs"],
+                                              alg["gamma"], alg["lam"], self._values_all, self._adv, self._ret, self._adv_sums, self._gae_scratch)
+                else:
+                    v_all = critic_head_forward(hc, c_out.weight, c_out.bias, self._values_all)
+            else:
+                v_all = self._critic_tr.forward(critic_all, train_rows=B).squeeze(-1)
+            values, last_values = v_all[:B], v_all[B:]
+            if not (fused_head and self._fused_gae):
+                gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
+                    advantages=self._adv, returns=self._ret, sums=self._adv_sums)
+            self.dp.sum_(self._adv_sums, tag="moments")  # exchange (1), on the side stream: hidden under the actor forward
+            gae_done = side.record_event()
+        u.hc, u.values, u.gae_done = (hc if fused_head else None), values, gae_done
+
+    def _epoch_losses_and_backward(self, u, have_fwd):
+        """The actor's forward pass (main stream), both output layers fused with the loss, both backward-data chains on their streams
+        (runner.py:147-163).  Leaves defer / fins / fin_c / fin_a in u."""
+        buf, B, alg, act_flat, obs_flat, fused_head, logstd_flat, a_out, c_out, old_mu, old_logstd, main, side = u.buf, u.B, u.alg, u.act_flat, u.obs_flat, u.fused_head, u.logstd_flat, u.a_out, u.c_out, u.old_mu, u.old_logstd, u.main, u.side
+        hc, values, gae_done = u.hc, u.values, u.gae_done
+        fins = fin_c = fin_a = None
+        if fused_head:
+            # Output layers fused with the loss (bg_head.hip): per network ONE pass over the [B][128] hidden activations gives the
+            # output, the loss terms, dL/dz of the hidden layer and the output layer's gradients.  Both heads add into _stats.
+            # defer (the default, see __init__): the small fixed-order reductions behind the head kernels and behind every backward layer
+            # (output-layer and bias gradients, loss statistics: nothing a chain needs) run as ONE launch on the side stream beside the
+            # weight-gradient launch (bg_reduce_group) instead of inside the chains.
+            defer = self._defer_finish and not MLPTrainer.SPLIT
+            fins = [] if defer else None
+            fin_c, fin_a = (_lib.ReduceProblem(), _lib.ReduceProblem()) if defer else (None, None)
+            ha = self._actor_tr.acts[2] if have_fwd else self._actor_tr.forward_hidden(obs_flat)
+            with torch.cuda.stream(side):
+                critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,
+                                     c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c, finish=fin_c)
+                self._critic_tr.backward_hidden(finishes=fins)
+            main.wait_event(gae_done)  # advantages and their moments
+            actor_head_loss_backward(ha, a_out.weight, a_out.bias, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp,
+                                     self._adv.view(B), self._adv_sums, 0.2, alg["bound_coef"], alg["entropy_coef"],
+                                     self._actor_tr.hidden_grad, a_out.weight.grad, a_out.bias.grad, self._actor_tr.layers[-2].bias.grad,
+                                     self._grad_logstd, self._stats, self._head_scratch_a, finish=fin_a)
+            if self.dp.active and not defer:
                 side.wait_stream(main)
                 with torch.cuda.stream(side):
-                    if fused_head:
-                        if have_fwd:
-                            hc = self._critic_tr.acts[2]
-                        else:
-                            hc = self._critic_tr.forward_hidden(critic_all, train_rows=B)
-                        if self._fused_gae:
-                            # output layer + timeout bootstrap + GAE + returns + advantage moments in ONE launch in front of the actor's loss
-                            v_all = critic_values_gae(None if chain_values else hc, c_out.weight, c_out.bias, buf["rewards"], buf["dones"], buf["time_outs"],
-                                                      alg["gamma"], alg["lam"], self._values_all, self._adv, self._ret, self._adv_sums, self._gae_scratch)
-                        else:
-                            v_all = critic_head_forward(hc, c_out.weight, c_out.bias, self._values_all)
-                    else:
-                        v_all = self._critic_tr.forward(critic_all, train_rows=B).squeeze(-1)
-                    values, last_values = v_all[:B], v_all[B:]
-                    if not (fused_head and self._fused_gae):
-                        gae(buf["rewards"], buf["dones"], buf["time_outs"], values.view(T, N), last_values, alg["gamma"], alg["lam"],
-                            advantages=self._adv, returns=self._ret, sums=self._adv_sums)
-                    self.dp.sum_(self._adv_sums, tag="moments")  # exchange (1), on the side stream: hidden under the actor forward
-                    gae_done = side.record_event()
-                if fused_head:
-                    # Output layers fused with the loss (bg_head.hip): per network ONE pass over the [B][128] hidden activations gives the
-                    # output, the loss terms, dL/dz of the hidden layer and the output layer's gradients.  Both heads add into _stats.
-                    # defer (the default, see __init__): the small fixed-order reductions behind the head kernels and behind every backward layer
-                    # (output-layer and bias gradients, loss statistics: nothing a chain needs) run as ONE launch on the side stream beside the
-                    # weight-gradient launch (bg_reduce_group) instead of inside the chains.
-                    defer = self._defer_finish and not MLPTrainer.SPLIT
-                    fins = [] if defer else None
-                    fin_c, fin_a = (_lib.ReduceProblem(), _lib.ReduceProblem()) if defer else (None, None)
-                    ha = self._actor_tr.acts[2] if have_fwd else self._actor_tr.forward_hidden(obs_flat)
-                    with torch.cuda.stream(side):
-                        critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), self._critic_tr.hidden_grad, c_out.weight.grad,
-                                             c_out.bias.grad, self._critic_tr.layers[-2].bias.grad, self._stats, self._head_scratch_c, finish=fin_c)
-                        self._critic_tr.backward_hidden(finishes=fins)
-                    main.wait_event(gae_done)  # advantages and their moments
-                    actor_head_loss_backward(ha, a_out.weight, a_out.bias, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp,
-                                             self._adv.view(B), self._adv_sums, 0.2, alg["bound_coef"], alg["entropy_coef"],
-                                             self._actor_tr.hidden_grad, a_out.weight.grad, a_out.bias.grad, self._actor_tr.layers[-2].bias.grad,
-                                             self._grad_logstd, self._stats, self._head_scratch_a, finish=fin_a)
-                    if self.dp.active and not defer:
-                        side.wait_stream(main)
-                        with torch.cuda.stream(side):
-                            self._exchange_sums()  # exchange (3): loss / KL sums, hidden under the backward passes
-                    self._actor_tr.backward_hidden(finishes=fins)
-                else:
-                    defer = False
-                    mu = self._actor_tr.forward(obs_flat)
-                    main.wait_stream(side)
-                    ppo_loss_fused(mu, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
-                                   values, self._ret.view(B), 0.2, alg["bound_coef"], alg["entropy_coef"], self._grad_mu, self._grad_val,
-                                   self._grad_logstd, self._stats)
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        self._exchange_sums()  # exchange (3): loss / KL sums, hidden under the backward passes
-                        self._critic_tr.backward(self._grad_val.view(B, 1))
-                    self._actor_tr.backward(self._grad_mu)
-                fused_tail = self._fused_opt and not self._lr_restart
-                # the sums of the tail as one launch behind the main weight-gradient kernel + a lean optimiser launch (single process, see __init__)
-                # (its norm is assembled from the sums' own pieces: every gradient element must come out of that launch -- all hidden-layer weight
-                # gradients from the grouped kernel, everything else from the deferred reductions)
-                # (that is: every hidden layer's backward went through the partial kernel, whose finish carries the bias gradient of the layer below --
-                # a layer that fell to the library path wrote its bias gradient outside both lists and the norm would miss it)
-                one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and len(fins) + 2 <= 8
-                            and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr))
-                            and len(fins) == sum(len(tr.layers) - 2 for tr in (self._critic_tr, self._actor_tr)))
-                main.wait_stream(side)
-                if one_tail:
-                    pass  # the deferred reductions run inside bg_update_tail
-                elif defer and self._defer_serial:  # the deferred reductions as one launch in FRONT of the weight gradients (the default)
-                    reduce_group([fin_c, fin_a] + fins)
-                    if self.dp.active:
-                        side.wait_stream(main)
-                        with torch.cuda.stream(side):
-                            self._exchange_sums()  # exchange (3), beside the weight gradients
-                elif defer:  # BG_DEFER_FINISH=2: ... (+ what depends on them) on the side stream, beside the weight gradients on the main stream
-                    side.wait_stream(main)
-                    with torch.cuda.stream(side):
-                        reduce_group([fin_c, fin_a] + fins)
-                        if self.dp.active:
-                            self._exchange_sums()  # exchange (3)
-                # all weight gradients after both backward chains, alone on the GPU: one launch pair for the six hidden layers (shapes outside the
-                # kernel's range, or MLPTrainer.FUSED_WGRAD = False: library GEMMs, layer by layer)
-                wg_partial = self._wgrad_group.run((self._critic_tr, self._actor_tr), finish=not one_tail)
-                if defer and (self.dp.active or not self._defer_serial):
-                    main.wait_stream(side)
-                if one_tail and self.dp.active:
-                    # ranks: the sums, then ONE collective launch on this stream (gradient bucket: mean; loss / KL sums: sum; log-std gradient: mean -- exchanges
-                    # (2) and (3) of SURVEY 8(e)), then the optimiser launch, which takes the norm of the averaged gradient
-                    self.optimizer.tail_sums(wg_partial, [fin_c, fin_a] + fins)
-                    self.dp.exchange_tail_(self.optimizer.grad, self._stats, self._grad_logstd)
-                elif not one_tail:
-                    self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
-                if fused_tail:
-                    # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch
-                    # ... and the copies of the weights that the layer kernels read (zero-padded first layers, transposed hidden layers): written by the
-                    # same launch instead of six strided torch copies inside the chains of the next mini-epoch
-                    if mirrors is None:
-                        ms = self._critic_tr.mirror_descriptors(self.optimizer.flat) + self._actor_tr.mirror_descriptors(self.optimizer.flat)
-                        mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 8 else None
-                    if one_tail and not self.dp.active:
-                        self.optimizer.step_tail(wg_partial, [fin_c, fin_a] + fins, self._stats, self._stats_acc, self._stats_last, 4, B, alg["desired_kl"],
-                                                 grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
-                    else:
-                        self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
-                                                  grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
-                    self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = mirrors is not None
-                else:
-                    self._logstd_grad_view.copy_(self._grad_logstd)  # (behind the bucket's all-reduce, which carries a stale value in this slot)
-                    self.optimizer.step()
-                    self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = False  # this launch does not write the weight copies: the next pass copies them
-                    if self._lr_restart:  # first step after a checkpoint load: see __init__
-                        self.optimizer.lr.fill_(float(cfg["algorithm"]["learning_rate"]))
-                        self._lr_restart = False
-                    self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
-                    self._stats_acc += self._stats
-                    self._stats_last.copy_(self._stats)
-                    self._stats.zero_()
-                    self._grad_logstd.zero_()
-        return self._stats_acc
+                    self._exchange_sums()  # exchange (3): loss / KL sums, hidden under the backward passes
+            self._actor_tr.backward_hidden(finishes=fins)
+        else:
+            defer = False
+            mu = self._actor_tr.forward(obs_flat)
+            main.wait_stream(side)
+            ppo_loss_fused(mu, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums,
+                           values, self._ret.view(B), 0.2, alg["bound_coef"], alg["entropy_coef"], self._grad_mu, self._grad_val,
+                           self._grad_logstd, self._stats)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                self._exchange_sums()  # exchange (3): loss / KL sums, hidden under the backward passes
+                self._critic_tr.backward(self._grad_val.view(B, 1))
+            self._actor_tr.backward(self._grad_mu)
+        u.defer, u.fins, u.fin_c, u.fin_a = defer, fins, fin_c, fin_a
+
+    def _epoch_gradients_and_step(self, u):
+        """Deferred reductions, all weight gradients, the exchange of the gradient over the ranks, clip + Adam + KL rule (runner.py:162-180)."""
+        cfg, B, alg, main, side = u.cfg, u.B, u.alg, u.main, u.side
+        defer, fins, fin_c, fin_a, mirrors = u.defer, u.fins, u.fin_c, u.fin_a, u.mirrors
+        fused_tail = self._fused_opt and not self._lr_restart
+        # the sums of the tail as one launch behind the main weight-gradient kernel + a lean optimiser launch (single process, see __init__)
+        # (its norm is assembled from the sums' own pieces: every gradient element must come out of that launch -- all hidden-layer weight
+        # gradients from the grouped kernel, everything else from the deferred reductions)
+        # (that is: every hidden layer's backward went through the partial kernel, whose finish carries the bias gradient of the layer below --
+        # a layer that fell to the library path wrote its bias gradient outside both lists and the norm would miss it)
+        one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and len(fins) + 2 <= 8
+                    and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr))
+                    and len(fins) == sum(len(tr.layers) - 2 for tr in (self._critic_tr, self._actor_tr)))
+        main.wait_stream(side)
+        if one_tail:
+            pass  # the deferred reductions run inside bg_update_tail
+        elif defer and self._defer_serial:  # the deferred reductions as one launch in FRONT of the weight gradients (the default)
+            reduce_group([fin_c, fin_a] + fins)
+            if self.dp.active:
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._exchange_sums()  # exchange (3), beside the weight gradients
+        elif defer:  # BG_DEFER_FINISH=2: ... (+ what depends on them) on the side stream, beside the weight gradients on the main stream
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                reduce_group([fin_c, fin_a] + fins)
+                if self.dp.active:
+                    self._exchange_sums()  # exchange (3)
+        # all weight gradients after both backward chains, alone on the GPU: one launch pair for the six hidden layers (shapes outside the
+        # kernel's range, or MLPTrainer.FUSED_WGRAD = False: library GEMMs, layer by layer)
+        wg_partial = self._wgrad_group.run((self._critic_tr, self._actor_tr), finish=not one_tail)
+        if defer and (self.dp.active or not self._defer_serial):
+            main.wait_stream(side)
+        if one_tail and self.dp.active:
+            # ranks: the sums, then ONE collective launch on this stream (gradient bucket: mean; loss / KL sums: sum; log-std gradient: mean -- exchanges
+            # (2) and (3) of SURVEY 8(e)), then the optimiser launch, which takes the norm of the averaged gradient
+            self.optimizer.tail_sums(wg_partial, [fin_c, fin_a] + fins)
+            self.dp.exchange_tail_(self.optimizer.grad, self._stats, self._grad_logstd)
+        elif not one_tail:
+            self.dp.average_(self.optimizer.grad)  # exchange (2): the one collective on the critical path
+        if fused_tail:
+            # clip + Adam + KL rule + statistics bookkeeping (and the zeroing of the accumulators for the next mini-epoch) in ONE launch
+            # ... and the copies of the weights that the layer kernels read (zero-padded first layers, transposed hidden layers): written by the
+            # same launch instead of six strided torch copies inside the chains of the next mini-epoch
+            if mirrors is None:
+                ms = self._critic_tr.mirror_descriptors(self.optimizer.flat) + self._actor_tr.mirror_descriptors(self.optimizer.flat)
+                mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 8 else None
+            if one_tail and not self.dp.active:
+                self.optimizer.step_tail(wg_partial, [fin_c, fin_a] + fins, self._stats, self._stats_acc, self._stats_last, 4, B, alg["desired_kl"],
+                                         grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
+            else:
+                self.optimizer.step_fused(self._stats, self._stats_acc, self._stats_last, 4, B * self.world_size, alg["desired_kl"],
+                                          grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)
+            self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = mirrors is not None
+        else:
+            self._logstd_grad_view.copy_(self._grad_logstd)  # (behind the bucket's all-reduce, which carries a stale value in this slot)
+            self.optimizer.step()
+            self._actor_tr.mirror_fresh = self._critic_tr.mirror_fresh = False  # this launch does not write the weight copies: the next pass copies them
+            if self._lr_restart:  # first step after a checkpoint load: see __init__
+                self.optimizer.lr.fill_(float(cfg["algorithm"]["learning_rate"]))
+                self._lr_restart = False
+            self.optimizer.adapt_lr(self._stats[4:5], B * self.world_size, alg["desired_kl"])
+            self._stats_acc += self._stats
+            self._stats_last.copy_(self._stats)
+            self._stats.zero_()
+            self._grad_logstd.zero_()
+        u.mirrors = mirrors
 
     def _plan_chain_split(self, rows_c, rows_a):
         """The two networks' chained forward launches of a mini-epoch run side by side on two streams, one workgroup per CU (128 KB of LDS).  Left to the
