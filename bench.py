@@ -7,9 +7,9 @@ A "step" is one PPO iteration on synthetic (randomly initialised) policy weights
 HIP simulator + 20 full-batch optimiser steps (BASELINE.json configs[1], flat terrain).  Rank 0 prints
 ONE JSON line.  `value` = world * N * T * K / wall (max over ranks).
 
-`roofline` = the symbols with the largest total time in this round's rocprofv3 summary of this command (profiles/r04_bench_kernel_stats.csv): the
+`roofline` = the symbols with the largest total time in this round's rocprofv3 summary of this command (profiles/r05_bench_kernel_stats.csv): the
 two networks' chained forward launches, priced over the span of each mini-epoch's pair; `roofline_wgrad` = the grouped weight gradients (the largest
-single launch); `roofline_env_step`, `roofline_aba` = the simulator kernels against the HBM roof; `other_configs` = BASELINE configs[2] and [4]
+single launch); `roofline_backward` = both backward-data chains over their span; `roofline_env_step`, `roofline_aba` = the simulator kernels against the HBM roof; `other_configs` = BASELINE configs[2] and [4]
 through the same loop; `cpu_baseline` = the oracle's CPU restatement of the same workload on the host cores.
 """
 import argparse
