@@ -499,18 +499,22 @@ __global__ __launch_bounds__(256) void critic_values_gae_kernel(int T, int N, co
         if ((threadIdx.x & 63) == 0) sd[k * 4 + (threadIdx.x >> 6)] = s;
     }
     __syncthreads();
-    if (threadIdx.x < 3) partial[(size_t)blockIdx.x * 3 + threadIdx.x] = sd[threadIdx.x * 4] + sd[threadIdx.x * 4 + 1] + sd[threadIdx.x * 4 + 2] + sd[threadIdx.x * 4 + 3];
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        __threadfence();
-        s_last = atomicAdd(ticket, 1u) == gridDim.x - 1 ? 1u : 0u;
+    // The triple is PUBLISHED, not fenced: an agent-scope store goes through the XCD's L2 to memory, and once the wave's vmcnt is back at zero it
+    // has arrived; the ticket is taken after that.  (A release fence -- __threadfence -- writes back the whole L2 of the XCD instead, every dirty
+    // line of the forward chain that runs beside this launch included, once per workgroup: this launch sits between the critic's forward pass and
+    // the actor's loss.)  The reader takes agent-scope loads, which do not hit a stale line of its own L2.
+    if (threadIdx.x < 3) {
+        __hip_atomic_store(&partial[(size_t)blockIdx.x * 3 + threadIdx.x], sd[threadIdx.x * 4] + sd[threadIdx.x * 4 + 1] + sd[threadIdx.x * 4 + 2] + sd[threadIdx.x * 4 + 3],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): threads 0..2 and the ticket's thread 0 are one wave
     }
     __syncthreads();
-    if (s_last) {  // every workgroup's triple is visible: fixed-order total
-        __threadfence();
+    if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {  // every workgroup's triple has arrived: fixed-order total
         for (int k = 0; k < 3; k++) {
             double s = 0.0;
-            for (int g = threadIdx.x; g < (int)gridDim.x; g += 256) s += __builtin_nontemporal_load(&partial[(size_t)g * 3 + k]);
+            for (int g = threadIdx.x; g < (int)gridDim.x; g += 256) s += __hip_atomic_load(&partial[(size_t)g * 3 + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             s = wave_sum_d(s);
             if ((threadIdx.x & 63) == 0) sd[k * 4 + (threadIdx.x >> 6)] = s;
         }

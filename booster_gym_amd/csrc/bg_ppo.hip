@@ -401,7 +401,8 @@ __global__ __launch_bounds__(OPT_THREADS) void optimizer_step_kernel(int n, floa
     }
     __syncthreads();
     if (t == 0) {
-        __threadfence();
+        // (no fence: the last workgroup needs the others' READS of lr and the log-std gradient to be over, which they are behind the barrier above --
+        // nothing they wrote; see tail_adam_kernel)
         const unsigned k = atomicAdd(ticket, 1u);
         if (k == gridDim.x - 1) {  // every workgroup has read lr and finished its slice
             if (stats) {

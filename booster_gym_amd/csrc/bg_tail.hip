@@ -173,7 +173,9 @@ __global__ __launch_bounds__(1024) void tail_adam_kernel(OptArgs o, ParamMirrors
     }
     __syncthreads();
     if (t == 0) {
-        __threadfence();
+        // No fence in front of the ticket: the last workgroup needs nothing the others WROTE, only that they have READ lr and the log-std gradient --
+        // and those loads have returned (their values went into every thread's arithmetic in front of the barrier above).  An agent-scope
+        // release here writes back the XCD's whole L2, once per workgroup.
         const unsigned k = atomicAdd(ticket, 1u);
         if (k == (unsigned)G - 1u) {  // every workgroup has read lr and the log-std gradient and finished its slice
             if (o.stats) {
