@@ -6,7 +6,8 @@ optimiser step: (1) [sum adv, sum adv^2, count] so that every rank normalises ad
 per-parameter hooks), averaged, (3) the loss / KL sums so that every rank takes the same learning-rate branch
 (runner.py:174-180).  With equal shards this is algebraically the reference update on the union of all shards.
 
-Backend: "nccl" (= RCCL on ROCm) on GPUs; `BG_DIST_BACKEND=gloo` lets the CPU tests run the same code path.  `BG_DIST_FORCE=1` takes the
+Backend: "nccl" (= RCCL on ROCm) on GPUs; `BG_DIST_BACKEND=gloo` lets the CPU tests run the same code path; `BG_OWN_RCCL=0` keeps the per-mini-epoch
+exchanges on torch.distributed's own communicator (utils/rccl.py otherwise).  `BG_DIST_FORCE=1` takes the
 collective path with a world of ONE process too (process group initialised, every exchange issued): the one-GPU box's way to execute the RCCL
 calls of this file (tests/test_gpu_rccl.py).
 """
@@ -57,7 +58,7 @@ class DataParallel:
         # the per-mini-epoch exchanges go through an own RCCL communicator, issued on the stream of the kernels around them (utils/rccl.py: the process
         # group's collectives run on its own stream between two event hand-overs, +54 us per mini-epoch in a world of one); gloo (CPU tests): the group
         self.comm = None
-        if self.active and self.backend == "nccl":
+        if self.active and self.backend == "nccl" and os.environ.get("BG_OWN_RCCL", "1") != "0":  # BG_OWN_RCCL=0: the process group's collectives
             from .rccl import RcclComm
 
             def exchange_id(raw):

@@ -125,3 +125,41 @@ def test_packed_form_refuses_the_body_gate(flat_model):
     with pytest.raises(RuntimeError, match="body contacts"):
         env.forward_dynamics(root, z(64, 12), z(64, 12), z(64, 12), packed=True)
     assert torch.isfinite(env.forward_dynamics(root, z(64, 12), z(64, 12), z(64, 12))).all()
+
+
+@pytest.mark.parametrize("standing", [False, True], ids=["airborne", "standing_on_the_plane"])
+@pytest.mark.parametrize("packed", [False, True], ids=["leg_per_lane", "env_per_lane"])
+def test_mirrored_pose_gives_mirrored_accelerations_on_the_gpu(flat_model, tmp_path, standing, packed):
+    """SURVEY section 8c, known-answer test (5) through the C ABI: on a SYMMETRISED copy of the model (conftest.symmetrised; loaded from a flat-model
+    file, per-env randomisation of the inertials and foot materials off) a state that is its own mirror image gives mirrored joint accelerations,
+    mirrored foot forces and no lateral / roll / yaw acceleration of the trunk.  In the lane-per-leg kernel the two legs are the two lanes of a pair
+    and the trunk's share is split between them; in the packed kernel they are the halves of register pairs: a left / right slip in either shows at
+    order one.  Tolerance: the parity tolerances of this file (fp32 sums in mirrored order differ in the last bits; stiff contacts amplify them)."""
+    from conftest import MIRROR_SIGN, mirrored_states, symmetrised
+
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+
+    n = 256
+    path = tmp_path / "T1_symmetrised.flat.json"
+    symmetrised(flat_model).save(str(path))
+    off = {f"randomization.{k}": None for k in ("base_com", "base_mass", "other_com", "other_mass", "friction", "compliance", "restitution")}
+    env = T1(load_cfg("T1", dict({"env.num_envs": n, "terrain.type": "plane", "asset.file": str(path)}, **off)))
+    assert np.all(env._mass_scale == 1.0) and np.all(env._com_off == 0.0) and np.ptp(env._foot_mat, axis=(0, 1)).max() == 0.0
+    root, q, qd, tau = mirrored_states(np.random.default_rng(3), n, standing)
+    f = lambda a: torch.tensor(a, dtype=torch.float32, device=env.device)
+    qacc = env.forward_dynamics(f(root), f(q), f(qd), f(tau), f(np.zeros((n, 6))), packed=packed).cpu().numpy().astype(np.float64)
+    cf = env.get_field("feet_contact_forces").cpu().numpy().reshape(n, 2, 3).astype(np.float64)
+    S, my = np.array(MIRROR_SIGN), np.array([1.0, -1.0, 1.0])
+    touching = np.abs(cf).max(axis=(1, 2)) > 0
+    scale = np.maximum(1.0, np.abs(qacc).max(axis=1))
+    joints = np.abs(qacc[:, 12:18] - S * qacc[:, 6:12]).max(axis=1) / scale
+    trunk = np.abs(qacc[:, [1, 3, 5]]).max(axis=1) / scale
+    feet = np.abs(cf[:, 1] - cf[:, 0] * my).max(axis=1) / np.maximum(1.0, np.abs(cf).max(axis=(1, 2)))
+    print(f"mirror asymmetry on the GPU ({'packed' if packed else 'lane per leg'}): joints {joints.max():.2e}, trunk {trunk.max():.2e}, foot forces {feet.max():.2e}; "
+          f"{int(touching.sum())} of {n} states with a contact")
+    assert np.isfinite(qacc).all()
+    tol = np.where(touching, 5e-4, 1e-4)
+    assert (joints < tol).all() and (trunk < tol).all(), (joints.max(), trunk.max())
+    assert (feet < 2e-3).all(), feet.max()
+    assert touching.sum() >= (n // 2 if standing else n // 10)

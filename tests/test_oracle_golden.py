@@ -534,6 +534,90 @@ def test_momentum_conserved_in_flight(flat_model):
     assert d_coarse < 0.02 * max(v0, 0.05) and d_fine < 0.5 * d_coarse, (d_coarse, d_fine, v0)
 
 
+def _system_totals(d, m, root, q, qd, g):
+    """Total mechanical energy, angular momentum about the world origin and linear momentum from the body states (origin velocity + angular velocity,
+    world frame) and the inertials of the model (com and inertia about it, body frame)."""
+    def rot(qx):  # xyzw
+        x, y, z, w = qx
+        return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                         [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    bs = d.body_states(root, q, qd)
+    E, L, P = 0.0, np.zeros(3), np.zeros(3)
+    for b in range(13):
+        R, w = rot(bs[b, 3:7]), bs[b, 10:13]
+        xx, yy, zz, xy, xz, yz = m.inertia[b]
+        Iw = R @ np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) @ R.T
+        c = bs[b, :3] + R @ m.com[b]
+        vc = bs[b, 7:10] + np.cross(w, R @ m.com[b])
+        E += 0.5 * m.mass[b] * vc @ vc + 0.5 * w @ Iw @ w + m.mass[b] * g * c[2]
+        L += m.mass[b] * np.cross(c, vc) + Iw @ w
+        P += m.mass[b] * vc
+    return E, L, P
+
+
+@pytest.mark.parametrize("g", [0.0, 9.81])
+def test_energy_and_angular_momentum_in_flight(flat_model, g):
+    """SURVEY section 8c, known-answer test (4): the unforced airborne system under the semi-implicit Euler step (play_mujoco.py:751-756 structure,
+    dt = 0.002).  Total energy drifts by O(dt) only -- bounded at dt = 0.002 and 4x smaller at dt / 4 -- and without gravity so do the angular momentum
+    about the origin and the linear momentum.  Computed from the BODY STATES (13 poses and twists), i.e. through the kinematics as well."""
+    from oracle.dyn_ref import DynRef
+
+    m = flat_model
+
+    def drift(dt):
+        d = DynRef(m, phys={"g": (0.0, 0.0, -g), "dt": dt, "clamp_qd": 0}, body_contacts=False)
+        rng = np.random.default_rng(11)
+        root = np.zeros(13); root[2], root[6] = 5.0, 1.0; root[7:13] = rng.normal(size=6) * 0.5
+        q = np.array([-0.2, 0, 0, 0.4, -0.25, 0] * 2, dtype=np.float64); qd = rng.normal(size=12) * 0.5
+        E0, L0, P0 = _system_totals(d, m, root, q, qd, g)
+        kin = E0 - m.mass.sum() * g * 5.0  # scale of the exchange: the kinetic energy at the start (+ what the fall adds)
+        for _ in range(int(round(0.2 / dt))):
+            d.step(root, q, qd, np.zeros(12))
+        E1, L1, P1 = _system_totals(d, m, root, q, qd, g)
+        return abs(E1 - E0), np.abs(L1 - L0).max(), np.abs(P1 - P0).max(), abs(kin) + m.mass.sum() * g * 0.2, np.abs(L0).max(), np.abs(P0).max()
+
+    dE, dL, dP, Es, Ls, Ps = drift(0.002)
+    dE4, dL4, dP4, *_ = drift(0.0005)
+    assert dE < 0.02 * Es and dE4 < 0.3 * dE, (dE, dE4, Es)
+    if g == 0.0:
+        assert dL < 1e-4 * Ls and dL4 < 0.3 * dL, (dL, dL4, Ls)
+        assert dP < 1e-4 * Ps and dP4 < 0.3 * dP, (dP, dP4, Ps)
+
+
+@pytest.mark.parametrize("standing", [False, True], ids=["airborne", "standing_on_the_plane"])
+def test_mirrored_pose_gives_mirrored_accelerations(flat_model, standing):
+    """SURVEY section 8c, known-answer test (5): a left-right mirrored state gives mirrored accelerations.  The shipped inertials are NOT mirror images
+    of each other (conftest.symmetrised), so the identity is asserted on a SYMMETRISED copy of the model, where it must hold to rounding -- any
+    left / right slip in the axis handling, the link chain, the sole contacts or the leg-against-leg contacts would break it at order one -- and
+    the shipped model's own asymmetry is reported beside it."""
+    from conftest import MIRROR_SIGN, mirrored_states, symmetrised
+    from oracle.dyn_ref import DynRef
+
+    S, my = np.array(MIRROR_SIGN), np.array([1.0, -1.0, 1.0])
+
+    def asymmetry(model):
+        d = DynRef(model, body_contacts=False)
+        root, q, qd, tau = mirrored_states(np.random.default_rng(3), 100, standing)
+        worst, touching = 0.0, 0
+        for e in range(100):
+            qacc, cf = d.forward(root[e], q[e], qd[e], tau[e])
+            touching += bool(np.abs(cf).max() > 0)
+            aL, aR = qacc[6:12], qacc[12:18]
+            scale = np.abs(aL) + np.abs(aR) + 1e-3 * np.abs(qacc[6:]).max()
+            worst = max(worst, (np.abs(aR - S * aL) / scale).max(), max(abs(qacc[1]), abs(qacc[3]), abs(qacc[5])) / np.abs(qacc[:6]).max())
+            if np.abs(cf).max() > 0:  # the two feet's forces mirror each other
+                worst = max(worst, np.abs(cf[12] - cf[6] * my).max() / np.abs(cf).max())
+        return worst, touching
+
+    w_sym, touching = asymmetry(symmetrised(flat_model))
+    w_real, _ = asymmetry(flat_model)
+    print(f"mirror asymmetry of the accelerations: symmetrised model {w_sym:.2e}, shipped model {w_real:.2e}; {touching} of 100 states with a contact "
+          "(sole or leg against leg)")
+    assert w_sym < 1e-5, w_sym
+    assert touching >= (50 if standing else 10)
+    assert 1e-4 < w_real < 1.0  # (the shipped model IS asymmetric at the per-cent level; nothing wild)
+
+
 def test_standing_normal_force(dyn, flat_model):
     """Held in the default pose by stiff PD, the robot settles with total normal force = weight (31.61 kg * 9.81)."""
     m = flat_model
