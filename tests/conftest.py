@@ -42,9 +42,10 @@ def symmetrised(model):
     return sym
 
 
-def mirrored_states(rng, n, standing):
+def mirrored_states(rng, n, standing, z_range=(0.64, 0.70)):
     """n states that are their own mirror image: trunk pitched only, velocities in the sagittal plane, right-leg joints / rates / torques = MIRROR_SIGN x
-    the left leg's.  standing: around the default pose with the soles on the plane z = 0; else airborne (the legs may touch each other)."""
+    the left leg's.  standing: around the default pose with the soles on (z_range: how deep in) the plane z = 0; else airborne (the legs may touch
+    each other)."""
     import numpy as np
 
     S = np.array(MIRROR_SIGN)
@@ -52,7 +53,7 @@ def mirrored_states(rng, n, standing):
     for e in range(n):
         if standing:
             qL = np.array([-0.2, 0, 0, 0.4, -0.25, 0]) + rng.normal(size=6) * 0.05
-            qdL, tL, z, vs = rng.normal(size=6) * 0.3, rng.uniform(-10, 10, 6), rng.uniform(0.64, 0.70), 0.2
+            qdL, tL, z, vs = rng.normal(size=6) * 0.3, rng.uniform(-10, 10, 6), rng.uniform(*z_range), 0.2
         else:
             qL, qdL, tL, z, vs = rng.uniform(-0.4, 0.4, 6), rng.normal(size=6), rng.uniform(-20, 20, 6), 5.0, 1.0
         q[e], qd[e], tau[e] = np.concatenate([qL, S * qL]), np.concatenate([qdL, S * qdL]), np.concatenate([tL, S * tL])

@@ -491,3 +491,60 @@ def test_stale_time_outs_flag_reproduces_the_reference_binding():
             assert torch.equal(x1["time_outs"], remembered)
             seen_stale += int(not torch.equal(fresh, remembered))
     assert seen_fresh >= 1 and seen_stale >= 1, (seen_fresh, seen_stale)  # both branches exercised, and the stale value really differed
+
+
+def test_mirrored_rollout_stays_mirrored(flat_model, tmp_path):
+    """The fused env-step kernel (10 substeps of dynamics + PD actuators + task logic per launch) on a SYMMETRISED copy of the model (conftest.symmetrised),
+    every randomisation, noise, kick and push off: mirrored standing states driven by mirrored actions stay mirrored over a rollout -- root on the sagittal
+    plane, no roll / yaw, right-leg joints = MIRROR_SIGN x left, mirrored foot forces, mirrored observation and torque rows.  (SURVEY section 8c KAT (5),
+    applied to the shipping kernel through bg_env_step: an independent physical identity, not a comparison with this build's own oracle.)  fp32 sums in
+    mirrored order differ in the last bits and stiff sole contacts amplify that from step to step: measured <= 5e-6 after 4 control steps (40 substeps),
+    bound 1e-4."""
+    from conftest import MIRROR_SIGN, mirrored_states, symmetrised
+
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+
+    n = 128
+    path = tmp_path / "T1_symmetrised.flat.json"
+    symmetrised(flat_model).save(str(path))
+    off = {f"randomization.{k}": None for k in ("init_dof_pos", "init_base_pos_xy", "init_base_lin_vel_xy", "kick_lin_vel", "kick_ang_vel", "push_force", "push_torque",
+                                                "dof_stiffness", "dof_damping", "dof_friction", "friction", "compliance", "restitution", "base_com", "base_mass",
+                                                "other_com", "other_mass")}
+    off.update({f"noise.{k}": None for k in ("gravity", "lin_vel", "ang_vel", "dof_pos", "dof_vel", "height")})
+    cfg = load_cfg("T1", dict({"env.num_envs": n, "terrain.type": "plane", "asset.file": str(path)}, **off))
+    env = T1(cfg)
+    env.reset()
+    rng = np.random.default_rng(21)
+    root, q, qd, _ = mirrored_states(rng, n, True, z_range=(0.695, 0.72))  # (soles up to 2.5 cm into the ground: deeper starts launch the robot)
+    root[:, :2] = env.get_field("root_states").cpu().numpy()[:, :2]  # keep every robot on its own origin
+    f = lambda a: torch.tensor(a, dtype=torch.float32, device=env.device)
+    env.set_field("root_states", f(root)); env.set_field("dof_pos", f(q)); env.set_field("dof_vel", f(qd))
+    env.set_field("last_dof_vel", f(qd))
+    cmd = env.get_field("commands"); cmd[:, 1:] = 0.0  # no lateral / yaw command (it only enters observations and rewards)
+    env.set_field("commands", cmd)
+    S, my = np.array(MIRROR_SIGN), np.array([1.0, -1.0, 1.0])
+    y0 = root[:, 1].copy()
+    worst, keep = {}, np.ones(n, dtype=bool)
+    for step in range(4):
+        aL = rng.uniform(-0.2, 0.2, (n, 6))  # (gentle: +-0.5 rad of random target jumps throws some robots over within two steps)
+        obs, rew, done, extras = env.step(f(np.concatenate([aL, S * aL], axis=1)))
+        keep &= ~done.cpu().numpy().astype(bool)  # a robot that was reset has left its mirrored state
+        r = env.get_field("root_states").cpu().numpy().astype(np.float64)[keep]
+        qn, qdn = env.get_field("dof_pos").cpu().numpy().astype(np.float64)[keep], env.get_field("dof_vel").cpu().numpy().astype(np.float64)[keep]
+        cf = env.get_field("feet_contact_forces").cpu().numpy().reshape(n, 2, 3).astype(np.float64)[keep]
+        tq = env.get_field("torques").cpu().numpy().astype(np.float64)[keep]
+        o = obs.cpu().numpy().astype(np.float64)[keep]
+        m = {"root_y": np.abs(r[:, 1] - y0[keep]).max(), "quat_xz": np.abs(r[:, [3, 5]]).max(), "vel_y": np.abs(r[:, 8]).max(), "ang_vel_xz": np.abs(r[:, [10, 12]]).max(),
+             "dof_pos": np.abs(qn[:, 6:] - S * qn[:, :6]).max(), "dof_vel": np.abs(qdn[:, 6:] - S * qdn[:, :6]).max() / max(1.0, np.abs(qdn).max()),
+             "torques": np.abs(tq[:, 6:] - S * tq[:, :6]).max() / max(1.0, np.abs(tq).max()),
+             "feet_forces": np.abs(cf[:, 1] - cf[:, 0] * my).max() / max(1.0, np.abs(cf).max()),
+             # observation row (envs/t1.py:574-603): the 12 joint positions / velocities / last actions sit in the last 36 entries
+             "obs_joints": max(np.abs(o[:, 11 + 12 * k + 6 : 11 + 12 * k + 12] - S * o[:, 11 + 12 * k : 11 + 12 * k + 6]).max() for k in range(3))}
+        for k, v in m.items():
+            worst[k] = max(worst.get(k, 0.0), float(v))
+    assert keep.sum() >= 0.9 * n, f"only {int(keep.sum())} of {n} robots stayed up"
+    print("mirrored rollout, worst asymmetry over 4 control steps:", {k: f"{v:.1e}" for k, v in worst.items()})
+    assert float(np.abs(cf).max()) > 50.0, "the robots are not standing on their soles"
+    for k, v in worst.items():
+        assert v < 1e-4, (k, v)
