@@ -163,3 +163,62 @@ def test_mirrored_pose_gives_mirrored_accelerations_on_the_gpu(flat_model, tmp_p
     assert (joints < tol).all() and (trunk < tol).all(), (joints.max(), trunk.max())
     assert (feet < 2e-3).all(), feet.max()
     assert touching.sum() >= (n // 2 if standing else n // 10)
+
+
+def _quat_mul(a, b):  # xyzw, batched
+    ax, ay, az, aw = a[..., 0], a[..., 1], a[..., 2], a[..., 3]
+    bx, by, bz, bw = b[..., 0], b[..., 1], b[..., 2], b[..., 3]
+    return np.stack([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw,
+                     aw * bw - ax * bx - ay * by - az * bz], axis=-1)
+
+
+@pytest.mark.parametrize("packed", [False, True], ids=["leg_per_lane", "env_per_lane"])
+def test_size_independent_identities_at_4096_envs(flat_model, packed):
+    """Properties of the forward dynamics that hold whatever the state, checked through the C ABI at the bench's size (4,096 envs, every per-env
+    randomisation on, the shipped model) -- nothing here is compared with this build's oracle:
+      * superposition: for a fixed state the accelerations are AFFINE in the joint torques, qacc(t1 + t2) - qacc(t1) - qacc(t2) + qacc(0) = 0
+        (airborne states: joint-limit and leg-against-leg forces depend on the state only);
+      * yaw / translation invariance on the plane: the whole state turned about the vertical by an angle and moved sideways gives the same joint
+        accelerations, and trunk accelerations / foot forces turned by the same angle (standing states, sole contacts active)."""
+    from booster_gym_amd.envs import T1
+    from booster_gym_amd.utils.config import load_cfg
+
+    n = 4096
+    env = T1(load_cfg("T1", {"env.num_envs": n, "terrain.type": "plane"}))
+    f = lambda a: torch.tensor(a, dtype=torch.float32, device=env.device)
+    fd = lambda root, q, qd, tau, w: env.forward_dynamics(f(root), f(q), f(qd), f(tau), f(w), packed=packed).cpu().numpy().astype(np.float64)
+    rng = np.random.default_rng(17)
+    # --- superposition in the torques (airborne)
+    root, q, qd, tau, w = _states(rng, flat_model, n, False)
+    t2 = rng.uniform(-flat_model.dof_effort, flat_model.dof_effort, (n, 12))
+    a12, a1, a2, a0 = fd(root, q, qd, tau + t2, w), fd(root, q, qd, tau, w), fd(root, q, qd, t2, w), fd(root, q, qd, np.zeros((n, 12)), w)
+    scale = np.maximum(1.0, np.maximum(np.abs(a12), np.abs(a1) + np.abs(a2)).max(axis=1))
+    sup = np.abs(a12 - a1 - a2 + a0).max(axis=1) / scale
+    print(f"superposition residual at {n} envs ({'packed' if packed else 'lane per leg'}): max {sup.max():.2e}, 99.9 % {np.quantile(sup, 0.999):.2e}")
+    assert np.isfinite(a12).all() and sup.max() < 5e-6, sup.max()  # (measured 4-5e-7)
+    # --- yaw + translation invariance (standing on the plane)
+    root, q, qd, tau, w = _states(rng, flat_model, n, True)
+    psi, shift = rng.uniform(-np.pi, np.pi, n), rng.uniform(-3.0, 3.0, (n, 2))
+    c, s = np.cos(psi), np.sin(psi)
+    rotz = lambda v: np.stack([c * v[:, 0] - s * v[:, 1], s * v[:, 0] + c * v[:, 1], v[:, 2]], axis=1)
+    r2 = root.copy()
+    r2[:, :3] = rotz(root[:, :3]); r2[:, :2] += shift
+    qz = np.stack([np.zeros(n), np.zeros(n), np.sin(psi / 2), np.cos(psi / 2)], axis=1)
+    r2[:, 3:7] = _quat_mul(qz, root[:, 3:7])
+    r2[:, 7:10], r2[:, 10:13] = rotz(root[:, 7:10]), rotz(root[:, 10:13])
+    # (the base wrench is LOCAL_SPACE, envs/t1.py:522-527: it turns with the trunk by itself)
+    qa = fd(root, q, qd, tau, w)
+    cfa = env.get_field("feet_contact_forces").cpu().numpy().reshape(n, 2, 3).astype(np.float64)
+    qb = fd(r2, q, qd, tau, w)
+    cfb = env.get_field("feet_contact_forces").cpu().numpy().reshape(n, 2, 3).astype(np.float64)
+    scale = np.maximum(1.0, np.abs(qa).max(axis=1))
+    inv = np.maximum(np.abs(qb[:, 6:] - qa[:, 6:]).max(axis=1), np.maximum(np.abs(qb[:, :3] - rotz(qa[:, :3])).max(axis=1), np.abs(qb[:, 3:6] - rotz(qa[:, 3:6])).max(axis=1))) / scale
+    fsc = np.maximum(1.0, np.abs(cfa).max(axis=(1, 2)))
+    finv = np.maximum(np.abs(cfb[:, 0] - rotz(cfa[:, 0])).max(axis=1), np.abs(cfb[:, 1] - rotz(cfa[:, 1])).max(axis=1)) / fsc
+    touching = np.abs(cfa).max(axis=(1, 2)) > 0
+    print(f"yaw / translation invariance at {n} envs: accelerations max {inv.max():.2e} (99.9 % {np.quantile(inv, 0.999):.2e}), foot forces max {finv.max():.2e}; "
+          f"{int(touching.sum())} envs with sole contact")
+    assert touching.sum() > n // 4
+    # (stiff contacts amplify the rounding of the turned inputs: the worst env sits an order of magnitude above the 99.9 % quantile)
+    assert np.quantile(inv, 0.999) < 1e-4 and inv.max() < 1e-3, (np.quantile(inv, 0.999), inv.max())  # (measured 1e-5 / 1e-4)
+    assert np.quantile(finv, 0.999) < 2e-4 and finv.max() < 2e-3, (np.quantile(finv, 0.999), finv.max())  # (measured 2e-5)
