@@ -436,7 +436,10 @@ def main():
                 d = tr._chain_descriptor()
                 tr.value_head = keep
                 us = solo_us(lambda: _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, _lib.current_stream_ptr()), "bg_mlp_chain_forward_group"))
-                alone[name] = {"avg_launch_us": us, "achieved": fl / (us * 1e-6) / 1e12, "frac": fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF}
+                alone[name] = {"avg_launch_us": us, "achieved": fl / (us * 1e-6) / 1e12, "frac": fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+                               # the loop's own launch geometry: a persistent grid on this network's share of the CUs (Runner._plan_chain_split), so
+                               # "alone" = nothing beside it on the chip, not "on all CUs"
+                               "workgroups": int(tr.chain_workgroups) or "one per 128-row slab"}
             headline["alone_on_the_gpu"] = alone
             layer_fwd["alone_on_the_gpu"] = alone["mlp_chain_fwd_kernel<2>"]
         wg_ev = wgrad_events
