@@ -321,6 +321,30 @@ def test_forward_passes_run_during_the_rollout_change_no_bit():
             assert torch.equal(a, b)
 
 
+def test_training_is_reproducible_run_to_run():
+    """Two runners built from the same configuration and seed give the same bits after three whole iterations -- parameters, Adam moments, loss
+    statistics, the rollout buffers and the command-curriculum grid -- on rough terrain with the curriculum on (the one place where the env uses
+    float atomics: equal increments, so their order does not matter).  What the long runs show at scale (profiles/r05_train_10000it_trimesh*.json: 100
+    logged rows identical across boxes and builds) as a test: every reduction of the update is fixed-order, every random draw is counter-based."""
+    from booster_gym_amd.utils.config import load_cfg
+    from booster_gym_amd.utils.runner import Runner
+
+    res = []
+    for _ in range(2):
+        cfg = load_cfg("T1", {"env.num_envs": 512, "runner.mini_epochs": 4, "basic.seed": 11, "terrain.type": "trimesh", "commands.curriculum": True})
+        r = Runner(cfg=cfg)
+        obs, infos = r.env.reset()
+        r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+        for _ in range(3):
+            stats = r.iteration().clone()
+        torch.cuda.synchronize()
+        res.append((r.optimizer.flat.clone(), r.optimizer.exp_avg.clone(), r.optimizer.exp_avg_sq.clone(), r.optimizer.lr.clone(), stats, r.buffer["obses"].clone(),
+                    r.buffer["rewards"].clone(), r.buffer["actions"].clone(), r.env.curriculum_prob.clone(), r.env.get_field("root_states").clone()))
+        del r
+    for k, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), f"item {k} differs between two identical runs"
+
+
 SWITCHES = {
     # name: (runner attributes, MLPTrainer class attributes) -- every branch of Runner.update() / MLPTrainer that a switch or a shape can select
     "default": ({}, {}),
