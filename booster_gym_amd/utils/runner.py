@@ -622,7 +622,13 @@ class Runner:
             return
         cost = lambda tr: sum(l.weight.shape[0] * (tr._kin if i == 0 else l.weight.shape[1]) for i, l in enumerate(tr.layers[:3]))
         fc, fa = cost(ct), cost(at)
-        best = min(range(1, cus), key=lambda a: (max(-(-sc // a) * fc, -(-sa // (cus - a)) * fa), abs(a - cus * sc * fc / (sc * fc + sa * fa))))
+        # Both counts are multiples of the number of XCDs (8 on MI355X: 32 CUs each).  The hardware deals the workgroups of a launch round-robin over the
+        # XCDs, so a count that is not a multiple puts one workgroup more on some XCDs; when both launches do that on the same XCD it holds 33 one-per-CU
+        # workgroups for 32 CUs and the 33rd runs its slabs after a whole persistent workgroup has retired: the launch takes twice as long.  (Seen at
+        # 16,384 envs with 165 + 91: the critic's launch 2,464 us instead of 1,344, 111 ms per iteration instead of 86, in two of three runners built in
+        # one process -- which XCDs get the extra workgroups depends on the launches before; tools/probe/two_runners.py, HISTORY.md round 5.)
+        xcds = 8 if cus % 8 == 0 else 1
+        best = min(range(xcds, cus, xcds), key=lambda a: (max(-(-sc // a) * fc, -(-sa // (cus - a)) * fa), abs(a - cus * sc * fc / (sc * fc + sa * fa))))
         ct.chain_workgroups, at.chain_workgroups = best, cus - best
 
     def _exchange_sums(self):
