@@ -41,6 +41,20 @@ from .utils import (actor_head_forward, actor_head_loss_backward, critic_head_ba
                     ppo_loss_fused)
 
 
+def plan_chain_split(slabs_c, slabs_a, cost_c, cost_a, cus, xcds=8):
+    """How many of the `cus` one-per-CU persistent workgroups each of the two forward launches of a mini-epoch gets (Runner._plan_chain_split): the
+    split that minimises the longer of the two launches, a launch costing ceil(slabs / workgroups) x its slab cost.
+    Both counts are multiples of the number of XCDs (8 on MI355X: 32 CUs each).  The hardware deals the workgroups of a launch round-robin over the
+    XCDs, so a count that is not a multiple puts one workgroup more on some XCDs; when both launches do that on the same XCD it holds 33 one-per-CU
+    workgroups for 32 CUs and the 33rd runs its slabs after a whole persistent workgroup has retired: the launch takes twice as long.  (Seen at
+    16,384 envs with 165 + 91: the critic's launch 2,464 us instead of 1,344, 111 ms per iteration instead of 86, in two of three runners built in
+    one process -- which XCDs get the extra workgroups depends on the launches before; tools/probe/two_runners.py, HISTORY.md round 5.)"""
+    step = xcds if xcds > 0 and cus % xcds == 0 and cus >= 2 * xcds else 1
+    best = min(range(step, cus, step), key=lambda a: (max(-(-slabs_c // a) * cost_c, -(-slabs_a // (cus - a)) * cost_a),
+                                                       abs(a - cus * slabs_c * cost_c / (slabs_c * cost_c + slabs_a * cost_a))))
+    return best, cus - best
+
+
 class FlatAdam:
     """Adam state on one flat fp32 buffer, stepped by bg_adam_step.  Exposes a torch.optim.Adam-compatible state_dict."""
 
@@ -621,15 +635,7 @@ class Runner:
         if sc + sa <= cus:
             return
         cost = lambda tr: sum(l.weight.shape[0] * (tr._kin if i == 0 else l.weight.shape[1]) for i, l in enumerate(tr.layers[:3]))
-        fc, fa = cost(ct), cost(at)
-        # Both counts are multiples of the number of XCDs (8 on MI355X: 32 CUs each).  The hardware deals the workgroups of a launch round-robin over the
-        # XCDs, so a count that is not a multiple puts one workgroup more on some XCDs; when both launches do that on the same XCD it holds 33 one-per-CU
-        # workgroups for 32 CUs and the 33rd runs its slabs after a whole persistent workgroup has retired: the launch takes twice as long.  (Seen at
-        # 16,384 envs with 165 + 91: the critic's launch 2,464 us instead of 1,344, 111 ms per iteration instead of 86, in two of three runners built in
-        # one process -- which XCDs get the extra workgroups depends on the launches before; tools/probe/two_runners.py, HISTORY.md round 5.)
-        xcds = 8 if cus % 8 == 0 else 1
-        best = min(range(xcds, cus, xcds), key=lambda a: (max(-(-sc // a) * fc, -(-sa // (cus - a)) * fa), abs(a - cus * sc * fc / (sc * fc + sa * fa))))
-        ct.chain_workgroups, at.chain_workgroups = best, cus - best
+        ct.chain_workgroups, at.chain_workgroups = plan_chain_split(sc, sa, cost(ct), cost(at), cus)
 
     def _exchange_sums(self):
         """Exchange (3), on the current (side) stream: the loss / KL sums and the log-std gradient of all ranks in one float64 all-reduce; the gradient

@@ -837,3 +837,21 @@ def test_config_keys_without_effect_are_reported():
     with pytest.warns(UserWarning, match="no effect"):
         bad = warn_ignored_keys(cfg2)
     assert sorted(bad) == ["asset.armature", "sim.physx.num_position_iterations", "sim.substeps"]
+
+
+def test_chain_split_gives_each_xcd_whole_workgroups():
+    """Runner._plan_chain_split's arithmetic (host only): the two forward launches of a mini-epoch share the 256 CUs as persistent one-per-CU workgroups, and
+    both counts must be multiples of the 8 XCDs -- the hardware deals workgroups round-robin over the XCDs, and 165 + 91 (the unconstrained optimum at
+    every size but 4,096 envs) can hand one XCD 33 workgroups for its 32 CUs, which doubled the critic's launch (HISTORY.md round 5)."""
+    from booster_gym_amd.utils.runner import plan_chain_split
+
+    fc, fa = 64 * 256 + 256 * 256 + 256 * 128, 64 * 256 + 256 * 128 + 128 * 128  # slab costs of the critic (61 -> 256 -> 256 -> 128) and the actor (47 -> 256 -> 128 -> 128)
+    for envs in (1024, 2048, 4096, 8192, 16384, 32768, 4096 + 128, 5000):
+        sc, sa = (25 * envs + 127) // 128, (24 * envs + 127) // 128
+        c, a = plan_chain_split(sc, sa, fc, fa, 256)
+        assert c + a == 256 and c % 8 == 0 and a % 8 == 0 and c > 0 and a > 0, (envs, c, a)
+        # ... at no more than 3 % above the cost of the unconstrained optimum
+        cost = lambda x: max(-(-sc // x) * fc, -(-sa // (256 - x)) * fa)
+        assert cost(c) <= 1.03 * min(cost(x) for x in range(1, 256)), (envs, c, cost(c))
+    assert plan_chain_split(800, 768, fc, fa, 256) == (160, 96)  # the bench shape
+    assert sum(plan_chain_split(800, 768, fc, fa, 250)) == 250   # a part whose CU count is no multiple of 8: any split
