@@ -334,6 +334,24 @@ int bg_mlp_layer_forward_split(int32_t M, int32_t K, int32_t N, const float* X, 
 int bg_mlp_layer_backward_split(int32_t M, int32_t K, int32_t N, const float* G, const uint16_t* planes_t, const float* act_below, float* Gout,
                                 float* bias_grad_below, float* scratch, int32_t terms, void* stream);
 
+/* bg_mlp_chain_forward_group on the bf16 matrix pipe with fp32 semantics (bg_mlp_chain_split.hip; reference utils/model.py:9-26 under
+ * utils/runner.py:132,147): the same three Linear + ELU layers per network in one launch, activations handed on in registers, every fp32 x fp32 product
+ * formed exactly from the 9 cross products of the operands' three bf16 planes (see bg_mlp_layer_forward_split; terms = 9 only).  P1 / P2 / P3: the
+ * layers' weight planes as bg_mlp_split_weights writes them (transpose = 0; P1 with k_out = K0 = 64, the zero-padded input width).  Same shapes, slab
+ * padding of Y1 / Y2 / Y3, `workgroups` and value head as bg_mlp_chain.  Not bit-identical to the fp32-MFMA chain (another summation order; the bias is
+ * the accumulators' initial value): both are exact-product fp32 sums.  1 to 4 networks per launch. */
+typedef struct bg_mlp_chain_split {
+    int32_t M, K0, N1, N2, N3;
+    int32_t workgroups;
+    const float* X;
+    const uint16_t *P1, *P2, *P3;
+    const float *b1, *b2, *b3;
+    float *Y1, *Y2, *Y3;
+    const float *v_w, *v_b;
+    float* v_out;
+} bg_mlp_chain_split;
+int bg_mlp_chain_forward_split(const bg_mlp_chain_split* nets, int32_t count, void* stream);
+
 /* Weight gradient of one Linear layer over the batch (the dW part of `loss.backward()`, utils/runner.py:163, for model.py:9-26's layers):
  * dW [C_out][C_in_real] = G [M][C_out]^T . A [M][C_in][:, :C_in_real], fp32 MFMA, the sum over the M rows split over `slices` x 4 waves
  * inside the launch and finished in a fixed order (deterministic, no atomics).  G = dL/dz of the layer, A = its input activations with
