@@ -96,26 +96,22 @@ __device__ __forceinline__ void mfma9(f32x16& acc, const u32x4 (&w)[3], const u3
     BG_MFMA(acc, w[0], x[0]); fill(IC<8>{}); BG_PIN();
 }
 
-// One 32-deep k-chunk of a layer's weight planes, [n][K / 32][48 dwords] in global memory, -> LDS with no register stop.  The LDS side of one
-// wave-instruction is 64 consecutive 16-byte slots; slot s = 12 n + sig holds piece (sig & ~3) | ((sig & 3) ^ ((n >> 2) & 3)) of row n
+// One wave-instruction (64 slots of 16 bytes = 1 KiB) of the copy of a 32-deep k-chunk of a layer's weight planes, [n][K / 32][48 dwords] in global
+// memory, -> LDS with no register stop.  Slot s = 12 n + sig of the chunk's LDS image holds piece (sig & ~3) | ((sig & 3) ^ ((n >> 2) & 3)) of row n
 // (piece = plane * 4 + step * 2 + lane half): the XOR spreads the 16 lanes of one read pass, whose rows are 192 bytes apart, over all bank groups.
-// 16 rows = 3 wave-instructions; rowpart / piecepart: this lane's row (x 192 bytes) and piece (x 16 bytes) in each of the three.
-template <int N>
-__device__ __forceinline__ void dma_chunk(const unsigned* __restrict__ P, int CH, int kc, unsigned* sbuf, int wave, const unsigned (&rowpart)[3],
+// 16 rows = 3 wave-instructions; piece q of a wave: rows 16 (4 (q / 3) + wave) .., instruction q % 3 of them; rowpart / piecepart: this lane's row
+// (x 192 bytes) and piece (x 16 bytes) in each of the three.  N * 3 / 64 pieces per wave and chunk.
+template <int Q>
+__device__ __forceinline__ void dma_piece(const unsigned* __restrict__ P, int CH, int kc, unsigned lds_chunk_bytes, int wave, const unsigned (&rowpart)[3],
                                           const unsigned (&piecepart)[3]) {
-#pragma unroll
-    for (int u = 0; u < N / 64; u++) {
-        const int g = u * 4 + wave;  // wave-uniform: rows 16 g .. 16 g + 15
-        const unsigned* base = P + ((size_t)(16 * g) * CH + kc) * SP_ROW;
-#pragma unroll
-        for (int m = 0; m < 3; m++) {
-            const unsigned lds = (unsigned)(uintptr_t)(sbuf + (g * 192 + m * 64) * 4);
-            const unsigned lofs = rowpart[m] * (unsigned)CH + piecepart[m];
-            // inline asm: the copies' bookkeeping is explicit (wait_vm), the compiler must not drain vmcnt for them; M0 cannot be named as a clobber
-            // (reserved), the backend never keeps a value of its own live in M0 across an inline asm (see bg_mlp_chain.hip)
-            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lofs), "s"(base), "s"(lds) : "memory");
-        }
-    }
+    constexpr int u = Q / 3, m = Q % 3;
+    const int g = u * 4 + wave;  // wave-uniform: rows 16 g .. 16 g + 15
+    const unsigned* base = P + ((size_t)(16 * g) * CH + kc) * SP_ROW;
+    const unsigned lds = lds_chunk_bytes + (unsigned)((g * 192 + m * 64) * 16);
+    const unsigned lofs = rowpart[m] * (unsigned)CH + piecepart[m];
+    // inline asm: the copies' bookkeeping is explicit (wait_vm), the compiler must not drain vmcnt for them; M0 cannot be named as a clobber
+    // (reserved), the backend never keeps a value of its own live in M0 across an inline asm (see bg_mlp_chain.hip)
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lofs), "s"(base), "s"(lds) : "memory");
 }
 
 struct Frag { u32x4 p[3]; };
@@ -124,11 +120,20 @@ __device__ __forceinline__ void read_w(Frag& f, const unsigned* sw) {
     for (int q = 0; q < 3; q++) f.p[q] = *reinterpret_cast<const u32x4*>(sw + q * 16);
 }
 
-// One 128-row slab of one network.  Y1 / Y2 / Y3 hold whole slabs (every store is unconditional: their number is part of the vmcnt bookkeeping).
-// sB: the three bias vectors, staged once per workgroup.
+// All slabs first, first + stride, ... < nslabs of one network: ONE continuous stream of weight chunks, the slabs' own prologues and epilogues folded
+// into their neighbours' MFMA shadows:
+//   * the copies of the next slab's first two chunks go out during this slab's last two chunks; the next slab's input rows are loaded during layer 3
+//     (the registers of the layer-1 input are free from layer 2 on) and the planes of its first k-step are split under layer 3's last MFMAs;
+//   * the accumulators start as the bias, read straight from LDS into the accumulator registers while the layer before runs (a1: during layer 3 of
+//     the slab before);
+//   * ELU + store + value head of ALL of layer 3's tiles ride in the gaps of layer 1 of the NEXT slab (behind the loop for the last slab).
+// Y1 / Y2 / Y3 hold whole slabs (every store is unconditional: their number is part of the vmcnt bookkeeping).
+// sB: the three bias vectors, then v_w [N3] (zeros without a value head), staged once per workgroup.
 template <int K0, int N1, int N2, int N3>
-__device__ __forceinline__ void split_slab(const bg_mlp_chain_split& a, int slab, unsigned* sW, const float* sB) {
+__device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first, int stride, int nslabs, unsigned* sW, const float* sB) {
     constexpr int C0 = K0 / 32, C1 = N1 / 32, C2 = N2 / 32, C = C0 + C1 + C2;
+    constexpr int NT1 = N1 / 32, NT2 = N2 / 32, NT3 = N3 / 32;
+    static_assert(K0 == 64 && NT1 == 8 && NT3 == 4 && (NT2 == 4 || NT2 == 8) && C2 >= 2, "the reference's widths");
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63, i = lane & 31, h = lane >> 5;
     unsigned rowpart[3], piecepart[3];
 #pragma unroll
@@ -140,102 +145,123 @@ __device__ __forceinline__ void split_slab(const bg_mlp_chain_split& a, int slab
     const unsigned* __restrict__ P1 = reinterpret_cast<const unsigned*>(a.P1);
     const unsigned* __restrict__ P2 = reinterpret_cast<const unsigned*>(a.P2);
     const unsigned* __restrict__ P3 = reinterpret_cast<const unsigned*>(a.P3);
-    // chunk cc of the stream: copies per wave, and the stores a lane issues during the chunk
+    // The stream: chunk cc (cc >= C: chunk cc - C of the next slab).  Per chunk and wave: the copies issued during it (those of chunk cc + 2), the
+    // stores and loads every lane issues during it.
     struct S {
-        static constexpr int ndma(int cc) { return (cc < 0 ? 0 : cc < C0 ? N1 : cc < C0 + C1 ? N2 : cc < C ? N3 : 0) * 3 / 64; }
-        // tile 0 of a layer is stored in the layer's last chunk, tile T >= 1 in chunk T - 1 of the next layer (the last layer's: behind the loop)
+        static constexpr int rows(int cc) { return (cc % C) < C0 ? N1 : (cc % C) < C0 + C1 ? N2 : N3; }
+        static constexpr int ndma(int cc) { return rows(cc) * 3 / 64; }
+        static constexpr int tilesteps(int cc) { return 2 * rows(cc) / 32; }
+        // copies per tile-step of chunk cc (those of chunk cc + 2, dealt from the chunk's first tile-step on)
+        static constexpr int pp(int cc) { return (ndma(cc + 2) + tilesteps(cc) - 1) / tilesteps(cc); }
         static constexpr int stores_in(int cc) {
-            int n = 0;
-            if (cc == C0 - 1 || cc == C0 + C1 - 1 || cc == C - 1) n += 4;
-            if (cc >= C0 && cc < C0 + C1 && cc - C0 + 1 < N1 / 32) n += 4;
-            if (cc >= C0 + C1 && cc < C && cc - C0 - C1 + 1 < N2 / 32) n += 4;
-            return n;
+            if (cc == 0) return 12;                       // layer 3 of the slab before: elements 0 .. 47
+            if (cc == 1) return 4 + 4;                    // ... 48 .. 63; tile 0 of layer 1
+            if (cc < C0 + C1) return 4;                   // tile cc - C0 + 1 of layer 1 (the last chunk: tile 0 of layer 2)
+            return cc - C0 - C1 + 1 < NT2 ? 4 : 0;        // tile cc - C0 - C1 + 1 of layer 2
         }
-        // what a wave has issued behind the copies of chunk cc when it arrives at the top of iteration cc: everything of iteration cc - 1 (the copies
-        // of chunk cc + 1 among it); before iteration 0: the copies of chunk 1
-        static constexpr int behind(int cc) { return ndma(cc + 1) + (cc > 0 ? stores_in(cc - 1) : 0); }
+        static constexpr int loads_in(int cc) { return cc == C0 + C1 ? K0 / 8 : 0; }  // the next slab's input rows
+        static constexpr int ops_in(int cc) { return ndma(cc + 2) + stores_in(cc) + loads_in(cc); }
+        // what a wave has issued behind the last copy of chunk cc when it arrives at the top of iteration cc: at most everything of iteration cc - 1
+        static constexpr int behind(int cc) { return ops_in((cc + C - 1) % C); }
     };
-    auto dma = [&](auto cc_) {
-        constexpr int cc = decltype(cc_)::value;
-        unsigned* dst = sW + (cc % NBUF) * BUFDW;
-        if constexpr (cc < C0) dma_chunk<N1>(P1, C0, cc, dst, wave, rowpart, piecepart);
-        else if constexpr (cc < C0 + C1) dma_chunk<N2>(P2, C1, cc - C0, dst, wave, rowpart, piecepart);
-        else if constexpr (cc < C) dma_chunk<N3>(P3, C2, cc - C0 - C1, dst, wave, rowpart, piecepart);
+    // LDS image of stream chunk cc: buffer (cc + phase) % 3, the phase advancing by C per slab; bb[r]: byte offset of the buffer of chunks cc % 3 == r
+    unsigned bb[3] = {0u, (unsigned)BUFDW * 4u, 2u * (unsigned)BUFDW * 4u};
+    const unsigned sWbase = (unsigned)(uintptr_t)sW;
+    auto dma = [&](auto cc_, auto q_) {
+        constexpr int cc = decltype(cc_)::value, q = decltype(q_)::value, c = cc % C;
+        if constexpr (q < S::ndma(cc)) {
+            const unsigned dst = sWbase + bb[cc % 3];
+            if constexpr (c < C0) dma_piece<q>(P1, C0, c, dst, wave, rowpart, piecepart);
+            else if constexpr (c < C0 + C1) dma_piece<q>(P2, C1, c - C0, dst, wave, rowpart, piecepart);
+            else dma_piece<q>(P3, C2, c - C0 - C1, dst, wave, rowpart, piecepart);
+        }
     };
 #ifdef BG_CHAIN_PROBE_STAMPS
     long long stamps[64];
-    stamps[62] = wall_clock64();
 #endif
-    BG_STAMP(0);
-    const int row = slab * 128 + wave * 32 + i;
-    const float* xrow = a.X + (size_t)(row < a.M ? row : a.M - 1) * K0 + 4 * h;
-    float x0[K0 / 2];
-#pragma unroll
-    for (int j = 0; j < K0 / 8; j++) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(xrow + 8 * j);
-        x0[4 * j + 0] = v.x; x0[4 * j + 1] = v.y; x0[4 * j + 2] = v.z; x0[4 * j + 3] = v.w;
-    }
-    BG_PIN();
-    dma(IC<0>{});
-    dma(IC<1>{});
-    BG_PIN();
-    const int sx = (i >> 2) & 3;                      // this lane's slot swizzle (rows 32 t + i: the tile offset does not change it)
-    const unsigned* swl = sW + i * SP_ROW;            // + buffer, + tile * 32 rows, + slot
+    const int sx = (i >> 2) & 3;                                 // this lane's slot swizzle (rows 32 t + i: the tile offset does not change it)
     const int s0 = ((0 + h) ^ sx) * 4, s1 = ((2 + h) ^ sx) * 4;  // step 0 / step 1 of a chunk
-    f32x16 a1[N1 / 32], a2[N2 / 32], a3[N3 / 32];
+    const unsigned* swl = sW + i * SP_ROW;                       // + buffer, + tile * 32 rows, + slot
+    f32x16 a1[NT1], a2[NT2], a3[NT3];
+    float x0[K0 / 2];
     u32x4 xp[3];
     unsigned xn[3][4];
-    // planes of the first k-step of the first layer (the only split outside an MFMA shadow)
+    f32x4 wv[3];   // value-head weights of the group of four layer-3 elements in work, of the one before (elements may still be pending) and of the next
+    float part = 0.f;
+    // bias -> accumulators: feature 32 t + 8 g + 4 h + q in register 4 g + q of tile t (one 16-byte LDS read, straight into the accumulator registers)
+    auto init4 = [&](auto& A, int ofs, auto t_, auto g_) {
+        constexpr int t = decltype(t_)::value, g = decltype(g_)::value;
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sB[ofs + 32 * t + 8 * g + 4 * h]);
+        A[t][4 * g + 0] = b4.x; A[t][4 * g + 1] = b4.y; A[t][4 * g + 2] = b4.z; A[t][4 * g + 3] = b4.w;
+    };
+    auto loadx = [&](int r, auto j_) {
+        constexpr int j = decltype(j_)::value;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + (size_t)(r < a.M ? r : a.M - 1) * K0 + 4 * h + 8 * j);
+        x0[4 * j + 0] = v.x; x0[4 * j + 1] = v.y; x0[4 * j + 2] = v.z; x0[4 * j + 3] = v.w;
+    };
+    auto fin = [&](auto& A, auto t_, auto r_) { constexpr int t = decltype(t_)::value, r = decltype(r_)::value; A[t][r] = elu_f(A[t][r]); };
+    auto store4 = [&](auto& A, float* __restrict__ Y, int r, auto N_, auto t_, auto g_) {
+        constexpr int N = decltype(N_)::value, t = decltype(t_)::value, g = decltype(g_)::value;
+        const f32x4 v = {A[t][4 * g + 0], A[t][4 * g + 1], A[t][4 * g + 2], A[t][4 * g + 3]};
+        *reinterpret_cast<f32x4*>(Y + (size_t)r * N + 32 * t + 8 * g + 4 * h) = v;
+    };
+    auto vw4 = [&](auto G_) { constexpr int G = decltype(G_)::value; wv[G % 3] = *reinterpret_cast<const f32x4*>(&sB[N1 + N2 + N3 + 32 * (G / 4) + 8 * (G % 4) + 4 * h]); };
+    // element e of layer 3 (tile e / 16, register e % 16): ELU in place + its term of the value head
+    auto l3_elem = [&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        fin(a3, IC<e / 16>{}, IC<e % 16>{});
+        part = fmaf(a3[e / 16][e % 16], wv[(e / 4) % 3][e % 4], part);
+    };
+    auto split_pair_at = [&](auto ph_, float v0, float v1, SplitTmp& st, auto p_) {
+        constexpr int p = decltype(p_)::value;
+        split_phase<decltype(ph_)::value>(v0, v1, st, xn[0][p], xn[1][p], xn[2][p]);
+    };
+
+    // ---- prologue of the first slab
+    int slab = first;
+    int row = slab * 128 + wave * 32 + i;
+    BG_STAMP(0);
+#ifdef BG_CHAIN_PROBE_STAMPS
+    stamps[62] = wall_clock64();
+#endif
+    static_for<K0 / 8>([&](auto j_) { loadx(row, j_); });
+    BG_PIN();
+    static_for<S::ndma(0)>([&](auto q_) { dma(IC<0>{}, q_); });
+    static_for<S::ndma(1)>([&](auto q_) { dma(IC<1>{}, q_); });
+    BG_PIN();
+    static_for<NT1>([&](auto t_) { static_for<4>([&](auto g_) { init4(a1, 0, t_, g_); }); });
+#pragma unroll
+    for (int t = 0; t < NT3; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) a3[t][r] = 0.f;
+    vw4(IC<0>{});
+    wait_vm<S::ndma(1)>();  // chunk 0 has landed (later slabs: the count of the chunk before covers it)
     {
         SplitTmp st;
         static_for<4>([&](auto p_) {
             constexpr int p = decltype(p_)::value;
-            unsigned hp, mp, lp;
-            split_phase<0>(x0[2 * p], x0[2 * p + 1], st, hp, mp, lp);
-            split_phase<1>(x0[2 * p], x0[2 * p + 1], st, hp, mp, lp);
-            split_phase<2>(x0[2 * p], x0[2 * p + 1], st, hp, mp, lp);
-            split_phase<3>(x0[2 * p], x0[2 * p + 1], st, hp, mp, lp);
-            xp[0][p] = hp; xp[1][p] = mp; xp[2][p] = lp;
+            static_for<4>([&](auto ph_) { split_pair_at(ph_, x0[2 * p], x0[2 * p + 1], st, p_); });
         });
+#pragma unroll
+        for (int q = 0; q < 3; q++) xp[q] = u32x4{xn[q][0], xn[q][1], xn[q][2], xn[q][3]};
     }
-    const size_t rowofs = (size_t)row;
-    // ELU of element r of tile t in place; store of 4 finished elements
-    auto fin = [&](auto& A, auto t_, auto r_) { constexpr int t = decltype(t_)::value, r = decltype(r_)::value; A[t][r] = elu_f(A[t][r]); };
-    auto store4 = [&](auto& A, float* __restrict__ Y, auto N_, auto t_, auto g_) {
-        constexpr int N = decltype(N_)::value, t = decltype(t_)::value, g = decltype(g_)::value;
-        const f32x4 v = {A[t][4 * g + 0], A[t][4 * g + 1], A[t][4 * g + 2], A[t][4 * g + 3]};
-        *reinterpret_cast<f32x4*>(Y + rowofs * N + 32 * t + 8 * g + 4 * h) = v;
-    };
-    // One layer: chunks base .. base + K / 32 - 1 of the stream.  xin(s): the lane's s'th input value (k-step J takes values 8 J .. 8 J + 7);
-    // prev / Yprev / NP: the layer below, whose tiles >= 1 are finished here (NP = 0: none); Y: this layer's activations; LAST: nothing follows.
-    auto layer = [&](auto& acc, auto xin, auto& prev, float* __restrict__ Yprev, auto NP_, auto K_, auto N_, auto base_, int bias_ofs, float* __restrict__ Y,
-                     auto LAST_) {
-        constexpr int K = decltype(K_)::value, N = decltype(N_)::value, NT = N / 32, CH = K / 32, base = decltype(base_)::value;
-        constexpr int NP = decltype(NP_)::value, NTP = NP / 32;
-        constexpr bool LAST = decltype(LAST_)::value;
+    int rowp = row;        // the slab whose layer 3 is finished during this slab's layer 1 (first slab: itself -- rewritten later with the real values)
+    bool has_prev = false;
+
+    // One layer: chunks base .. base + K / 32 - 1 of the stream.  xin(s): the lane's s'th input value (k-step J takes values 8 J .. 8 J + 7).
+    auto layer = [&](auto L_, auto& acc, auto xin, auto K_, auto N_, auto base_, int rown) {
+        constexpr int L = decltype(L_)::value, K = decltype(K_)::value, N = decltype(N_)::value, NT = N / 32, CH = K / 32, base = decltype(base_)::value;
         constexpr int EPT = 8 / NT;  // elements of the tile below finished per tile-step (8 per k-step)
-        static_assert(NT == 4 || NT == 8, "4 or 8 tiles per layer");
-        // bias = initial value of the accumulators (feature 32 t + 8 g + 4 h + q in register 4 g + q)
-#pragma unroll
-        for (int t = 0; t < NT; t++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sB[bias_ofs + 32 * t + 8 * g + 4 * h]);
-                acc[t][4 * g + 0] = b4.x; acc[t][4 * g + 1] = b4.y; acc[t][4 * g + 2] = b4.z; acc[t][4 * g + 3] = b4.w;
-            }
         static_for<CH>([&](auto kc_) {
-            constexpr int kc = decltype(kc_)::value, c = base + kc;
-            const unsigned* sw = swl + (c % NBUF) * BUFDW;
+            constexpr int kc = decltype(kc_)::value, c = base + kc, PP = S::pp(c);
+            const unsigned* sw = swl + bb[c % 3] / 4;
             // chunk c complete in LDS (this wave's part), then published by the barrier; what iteration c - 1 issued may stay in flight
             BG_PIN();
-            BG_STAMP(1 + 3 * c);
+            BG_STAMP(1 + 2 * c);
             wait_vm<S::behind(c)>();
             asm volatile("s_barrier" ::: "memory");  // no fence: a workgroup fence would drain vmcnt (stores and younger copies included)
-            BG_STAMP(2 + 3 * c);
+            BG_STAMP(2 + 2 * c);
             BG_PIN();
-            dma(IC<c + AHEAD>{});
-            BG_PIN();
-            BG_STAMP(3 + 3 * c);
             Frag fr[2];
             read_w(fr[0], sw + s0);
             static_for<2>([&](auto j_) {
@@ -246,67 +272,107 @@ __device__ __forceinline__ void split_slab(const bg_mlp_chain_split& a, int slab
                     SplitTmp st0, st1;
                     mfma9(acc[t], fr[ts & 1].p, xp, [&](auto g_) {
                         constexpr int g = decltype(g_)::value;
-                        // (A) the next tile-step's weight fragments
+                        // the next tile-step's weight fragments
                         if constexpr (g == 0 && ts + 1 < 2 * NT) read_w(fr[(ts + 1) & 1], sw + ((ts + 1) / NT ? s1 : s0) + ((ts + 1) % NT) * 32 * SP_ROW);
+                        // the copies of chunk c + 2: PP per tile-step from the chunk's first tile-step on
+                        if constexpr (g == 8) dma(IC<c + AHEAD>{}, IC<ts * PP>{});
+                        if constexpr (g == 2 && PP >= 2) dma(IC<c + AHEAD>{}, IC<ts * PP + 1>{});
+                        static_assert(PP <= 2, "");
                         if constexpr (!lastk) {
-                            // (B) the planes of k-step J + 1: one pair per NT / 4 tile-steps, pieces behind MFMAs 3 .. 6
+                            // the planes of k-step J + 1: one pair per NT / 4 tile-steps, pieces behind MFMAs 3 .. 6
                             if constexpr (t % (NT / 4) == 0 && g >= 3 && g <= 6) {
                                 constexpr int p = t / (NT / 4), s = 8 * (J + 1) + 2 * p;
-                                split_phase<g - 3>(xin(IC<s>{}), xin(IC<s + 1>{}), st0, xn[0][p], xn[1][p], xn[2][p]);
+                                split_pair_at(IC<g - 3>{}, xin(IC<s>{}), xin(IC<s + 1>{}), st0, IC<p>{});
                             }
-                            // (C) tile kc + 1 of the layer below: elements 8 j .. 8 j + 7 during this k-step, stored by fours
-                            if constexpr (NTP > 0 && kc + 1 < NTP) {
+                        }
+                        if constexpr (L == 1) {
+                            // layer 3 of the slab before: elements 0 .. 47 in chunk 0 (3 per tile-step), 48 .. 63 in k-step 2 (2 per tile-step)
+                            constexpr int tsg = kc * 2 * NT + ts, e0 = tsg < 16 ? 3 * tsg : 48 + 2 * (tsg - 16), cnt = tsg < 16 ? 3 : tsg < 24 ? 2 : 0;
+                            if constexpr (cnt > 0) {
+                                constexpr int k = g == 1 ? 0 : g == 2 ? 1 : g == 7 ? 2 : -1;
+                                if constexpr (k >= 0 && k < cnt) l3_elem(IC<e0 + k>{});
+                                if constexpr (g == 0) {  // value-head weights of the next group of four, one group ahead
+                                    if constexpr (e0 % 4 == 0 && e0 / 4 + 1 < 16) vw4(IC<e0 / 4 + 1>{});
+                                    else if constexpr ((e0 + 1) % 4 == 0 && (e0 + 1) / 4 + 1 < 16 && cnt > 1) vw4(IC<(e0 + 1) / 4 + 1>{});
+                                    else if constexpr ((e0 + 2) % 4 == 0 && (e0 + 2) / 4 + 1 < 16 && cnt > 2) vw4(IC<(e0 + 2) / 4 + 1>{});
+                                }
+                                if constexpr (g == 8) {
+                                    constexpr int el = e0 + cnt - 1, G = el / 4;  // a group is complete when its element 4 G + 3 is: at most one per tile-step
+                                    if constexpr (e0 <= 4 * G + 3 && 4 * G + 3 <= el) store4(a3, a.Y3, rowp, IC<N3>{}, IC<G / 4>{}, IC<G % 4>{});
+                                    else if constexpr (G >= 1 && e0 <= 4 * G - 1) store4(a3, a.Y3, rowp, IC<N3>{}, IC<(G - 1) / 4>{}, IC<(G - 1) % 4>{});
+                                }
+                            }
+                        } else if constexpr (!lastk) {
+                            // tile kc + 1 of the layer below: elements 8 j .. 8 j + 7 during this k-step, stored by fours
+                            constexpr int NTP = K / 32;
+                            auto& prev = [&]() -> auto& { if constexpr (L == 2) return a1; else return a2; }();
+                            float* __restrict__ Yprev = L == 2 ? a.Y1 : a.Y2;
+                            if constexpr (kc + 1 < NTP) {
                                 if constexpr (EPT == 1) {
                                     if constexpr (g == 1) fin(prev, IC<kc + 1>{}, IC<8 * j + t>{});
-                                    if constexpr (g == 8 && (t & 3) == 3) store4(prev, Yprev, IC<NP>{}, IC<kc + 1>{}, IC<(8 * j + t) / 4>{});
+                                    if constexpr (g == 8 && (t & 3) == 3) store4(prev, Yprev, row, IC<K>{}, IC<kc + 1>{}, IC<(8 * j + t) / 4>{});
                                 } else {
                                     if constexpr (g == 1) fin(prev, IC<kc + 1>{}, IC<8 * j + 2 * t>{});
                                     if constexpr (g == 7) fin(prev, IC<kc + 1>{}, IC<8 * j + 2 * t + 1>{});
-                                    if constexpr (g == 8 && (t & 1) == 1) store4(prev, Yprev, IC<NP>{}, IC<kc + 1>{}, IC<(8 * j + 2 * t) / 4>{});
+                                    if constexpr (g == 8 && (t & 1) == 1) store4(prev, Yprev, row, IC<K>{}, IC<kc + 1>{}, IC<(8 * j + 2 * t) / 4>{});
                                 }
                             }
-                        } else if constexpr (!LAST) {
-                            // the layer's last k-step: tile 0 is complete behind tile-step 0.  It is finished under the other tiles, and the planes of the
-                            // NEXT layer's first k-step (its elements 0 .. 7) are split at the end.
+                        }
+                        if constexpr (L == 3) {
+                            // the next slab's input rows (the registers of the layer-1 input are free), one 16-byte load per tile-step of the first chunk
+                            if constexpr (kc == 0 && g == 5) loadx(rown, IC<ts>{});
+                            // ... and its layer-1 accumulators = bias, over the last two chunks
+                            if constexpr (kc >= CH - 2 && (g == 2 || g == 6)) {
+                                constexpr int G = ((kc - (CH - 2)) * 2 * NT + ts) * 2 + (g == 6);
+                                init4(a1, 0, IC<G / 4>{}, IC<G % 4>{});
+                            }
+                        }
+                        if constexpr (lastk && L < 3) {
+                            // the layer's last k-step: tile 0 is complete behind tile-step 0; it is finished under the other tiles, then the planes of the
+                            // NEXT layer's first k-step (its elements 0 .. 7) are split; the next layer's accumulators = bias
+                            float* __restrict__ Y = L == 1 ? a.Y1 : a.Y2;
+                            if constexpr (L == 1) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT2) init4(a2, N1, IC<G / 4>{}, IC<G % 4>{}); } }
+                            if constexpr (L == 2) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT3) init4(a3, N1 + N2, IC<G / 4>{}, IC<G % 4>{}); } }
                             if constexpr (NT == 8) {
                                 if constexpr (t >= 1 && t <= 4) {
                                     if constexpr (g == 1 || g == 3 || g == 5 || g == 7) fin(acc, IC<0>{}, IC<4 * (t - 1) + (g - 1) / 2>{});
-                                    if constexpr (g == 8) store4(acc, Y, IC<N>{}, IC<0>{}, IC<t - 1>{});
+                                    if constexpr (g == 8) store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<t - 1>{});
                                 }
                                 if constexpr (t == 5 || t == 6) {
                                     constexpr int p = 2 * (t - 5);
-                                    if constexpr (g <= 3) split_phase<g>(acc[0][2 * p], acc[0][2 * p + 1], st0, xn[0][p], xn[1][p], xn[2][p]);
-                                    else if constexpr (g <= 7) split_phase<g - 4>(acc[0][2 * p + 2], acc[0][2 * p + 3], st1, xn[0][p + 1], xn[1][p + 1], xn[2][p + 1]);
+                                    if constexpr (g <= 3) split_pair_at(IC<g>{}, acc[0][2 * p], acc[0][2 * p + 1], st0, IC<p>{});
+                                    else if constexpr (g <= 7) split_pair_at(IC<g - 4>{}, acc[0][2 * p + 2], acc[0][2 * p + 3], st1, IC<p + 1>{});
                                 }
                             } else {
                                 if constexpr (t == 1 || t == 2) {
                                     if constexpr (g <= 7) fin(acc, IC<0>{}, IC<8 * (t - 1) + g>{});
-                                    if constexpr (g == 8) { store4(acc, Y, IC<N>{}, IC<0>{}, IC<2 * (t - 1)>{}); store4(acc, Y, IC<N>{}, IC<0>{}, IC<2 * (t - 1) + 1>{}); }
+                                    if constexpr (g == 8) { store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1)>{}); store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1) + 1>{}); }
                                 }
                                 if constexpr (t == 3 && g <= 7) {
                                     constexpr int p = g / 2;
-                                    if constexpr ((g & 1) == 0) {
-                                        split_phase<0>(acc[0][2 * p], acc[0][2 * p + 1], st0, xn[0][p], xn[1][p], xn[2][p]);
-                                        split_phase<1>(acc[0][2 * p], acc[0][2 * p + 1], st0, xn[0][p], xn[1][p], xn[2][p]);
-                                    } else {
-                                        split_phase<2>(acc[0][2 * p], acc[0][2 * p + 1], st0, xn[0][p], xn[1][p], xn[2][p]);
-                                        split_phase<3>(acc[0][2 * p], acc[0][2 * p + 1], st0, xn[0][p], xn[1][p], xn[2][p]);
-                                    }
+                                    split_pair_at(IC<2 * (g & 1)>{}, acc[0][2 * p], acc[0][2 * p + 1], st0, IC<p>{});
+                                    split_pair_at(IC<2 * (g & 1) + 1>{}, acc[0][2 * p], acc[0][2 * p + 1], st0, IC<p>{});
                                 }
                             }
-                        } else {
-                            // the last layer's last k-step: tile t - 1 whole under tile t (tile NT - 1: behind the loop)
-                            if constexpr (t >= 1 && g <= 7) {
-                                fin(acc, IC<t - 1>{}, IC<2 * g>{});
-                                fin(acc, IC<t - 1>{}, IC<2 * g + 1>{});
-                                if constexpr (g & 1) store4(acc, Y, IC<N>{}, IC<t - 1>{}, IC<g / 2>{});
+                        }
+                        if constexpr (lastk && L == 3) {
+                            // the planes of the next slab's first k-step, from its input rows
+                            if constexpr (t == NT - 1 && g <= 7) {
+                                constexpr int p = g / 2;
+                                split_pair_at(IC<2 * (g & 1)>{}, x0[2 * p], x0[2 * p + 1], st0, IC<p>{});
+                                split_pair_at(IC<2 * (g & 1) + 1>{}, x0[2 * p], x0[2 * p + 1], st0, IC<p>{});
                             }
                         }
                     });
                 });
-                if constexpr (!(lastk && LAST)) {
 #pragma unroll
-                    for (int q = 0; q < 3; q++) xp[q] = u32x4{xn[q][0], xn[q][1], xn[q][2], xn[q][3]};
+                for (int q = 0; q < 3; q++) xp[q] = u32x4{xn[q][0], xn[q][1], xn[q][2], xn[q][3]};
+                if constexpr (L == 1 && kc == 1 && j == 0) {
+                    // the slab before is complete: its value (the two halves of a sample's features sit in lanes i and i + 32)
+                    part += __shfl_xor(part, 32);
+                    if (a.v_out && has_prev && h == 0 && rowp < a.M) a.v_out[rowp] = part + a.v_b[0];
+                    part = 0.f;
+                    vw4(IC<0>{});
                 }
             });
         });
@@ -314,34 +380,37 @@ __device__ __forceinline__ void split_slab(const bg_mlp_chain_split& a, int slab
     auto x0in = [&](auto s_) { return x0[decltype(s_)::value]; };
     auto a1in = [&](auto s_) { constexpr int s = decltype(s_)::value; return a1[s >> 4][s & 15]; };
     auto a2in = [&](auto s_) { constexpr int s = decltype(s_)::value; return a2[s >> 4][s & 15]; };
-    layer(a1, x0in, a1, nullptr, IC<0>{}, IC<K0>{}, IC<N1>{}, IC<0>{}, 0, a.Y1, std::false_type{});
-    layer(a2, a1in, a1, a.Y1, IC<N1>{}, IC<N1>{}, IC<N2>{}, IC<C0>{}, N1, a.Y2, std::false_type{});
-    layer(a3, a2in, a2, a.Y2, IC<N2>{}, IC<N2>{}, IC<N3>{}, IC<C0 + C1>{}, N1 + N2, a.Y3, std::true_type{});
-    // the last tile of the last layer
-    {
-        constexpr int t = N3 / 32 - 1;
-        static_for<16>([&](auto r_) { fin(a3, IC<t>{}, r_); });
-        static_for<4>([&](auto g_) { store4(a3, a.Y3, IC<N3>{}, IC<t>{}, g_); });
+    for (;;) {
+        const int next = slab + stride;
+        const bool has_next = next < nslabs;
+        const int rown = (has_next ? next : slab) * 128 + wave * 32 + i;
+        layer(IC<1>{}, a1, x0in, IC<K0>{}, IC<N1>{}, IC<0>{}, rown);
+        layer(IC<2>{}, a2, a1in, IC<N1>{}, IC<N2>{}, IC<C0>{}, rown);
+        layer(IC<3>{}, a3, a2in, IC<N2>{}, IC<N3>{}, IC<C0 + C1>{}, rown);
+        // the stream's phase in the three LDS buffers advances by C chunks
+        if constexpr (C % 3 == 1) { const unsigned b0 = bb[0]; bb[0] = bb[1]; bb[1] = bb[2]; bb[2] = b0; }
+        if constexpr (C % 3 == 2) { const unsigned b0 = bb[0]; bb[0] = bb[2]; bb[2] = bb[1]; bb[1] = b0; }
+        rowp = row;
+        has_prev = true;
+        if (!has_next) break;
+        slab = next;
+        row = rown;
     }
-    if (a.v_out) {
-        // scalar output layer on the last activations, straight from the registers that hold them: the lane has 64 of its sample's 128 features
-        float part = 0.f;
-#pragma unroll
-        for (int t = 0; t < N3 / 32; t++)
-#pragma unroll
-            for (int g = 0; g < 4; g++) {
-                const f32x4 w4 = *reinterpret_cast<const f32x4*>(a.v_w + 32 * t + 8 * g + 4 * h);
-                part = fmaf(a3[t][4 * g + 0], w4.x, part); part = fmaf(a3[t][4 * g + 1], w4.y, part);
-                part = fmaf(a3[t][4 * g + 2], w4.z, part); part = fmaf(a3[t][4 * g + 3], w4.w, part);
-            }
-        part += __shfl_xor(part, 32);
-        if (h == 0 && row < a.M) a.v_out[row] = part + a.v_b[0];
-    }
+    // layer 3 of the last slab
+    static_for<16 * NT3>([&](auto e_) {
+        constexpr int e = decltype(e_)::value;
+        if constexpr (e % 4 == 0 && e / 4 + 1 < 16) vw4(IC<e / 4 + 1>{});
+        l3_elem(e_);
+        if constexpr (e % 4 == 3) store4(a3, a.Y3, rowp, IC<N3>{}, IC<e / 16>{}, IC<(e / 4) % 4>{});
+    });
+    part += __shfl_xor(part, 32);
+    if (a.v_out && h == 0 && rowp < a.M) a.v_out[rowp] = part + a.v_b[0];
+    wait_vm<0>();  // the copies issued for a slab that does not exist must have landed before the workgroup's LDS is handed on
 #ifdef BG_CHAIN_PROBE_STAMPS
-    stamps[1 + 3 * C] = clock64();
+    stamps[1 + 2 * C] = clock64();
     stamps[63] = wall_clock64();
     if (lane == 0 && blockIdx.x < 256)
-        for (int k = 0; k < 64; k++) bg_split_stamp_buf[(((size_t)(N2 == 256) * 256 + blockIdx.x) * 4 + wave) * 64 + k] = (k <= 1 + 3 * C || k >= 62) ? stamps[k] : 0;
+        for (int k = 0; k < 64; k++) bg_split_stamp_buf[(((size_t)(N2 == 256) * 256 + blockIdx.x) * 4 + wave) * 64 + k] = (k <= 1 + 2 * C || k >= 62) ? stamps[k] : 0;
 #endif
 }
 
@@ -350,7 +419,7 @@ __device__ __forceinline__ void split_slab(const bg_mlp_chain_split& a, int slab
 template <int TAG>
 __global__ __launch_bounds__(256) void mlp_chain_split_fwd_kernel(SplitGroup grp) {
     __shared__ __attribute__((aligned(16))) unsigned sW[NBUF * BUFDW];
-    __shared__ __attribute__((aligned(16))) float sB[3 * NMAX];
+    __shared__ __attribute__((aligned(16))) float sB[3 * NMAX + 128];
     int k = 0;
     if constexpr (TAG == 0) {
 #pragma unroll
@@ -358,17 +427,16 @@ __global__ __launch_bounds__(256) void mlp_chain_split_fwd_kernel(SplitGroup grp
             if (j < grp.n && (int)blockIdx.x >= grp.begin[j]) k = j;
     }
     const bg_mlp_chain_split& a = grp.net[k];
-    for (int j = threadIdx.x; j < a.N1 + a.N2 + a.N3; j += 256) sB[j] = j < a.N1 ? a.b1[j] : j < a.N1 + a.N2 ? a.b2[j - a.N1] : a.b3[j - a.N1 - a.N2];
+    const int nb = a.N1 + a.N2 + a.N3;
+    for (int j = threadIdx.x; j < nb + a.N3; j += 256)
+        sB[j] = j < a.N1 ? a.b1[j] : j < a.N1 + a.N2 ? a.b2[j - a.N1] : j < nb ? a.b3[j - a.N1 - a.N2] : a.v_w ? a.v_w[j - nb] : 0.f;
     __syncthreads();
     // One slab per workgroup, or (workgroups > 0) that many workgroups walking the network's slabs (see bg_mlp_chain.hip: two launches side by side
     // share the chip by CUs; counts that are multiples of the 8 XCDs)
-    const int nslabs = (a.M + 127) / 128, stride = grp.begin[k + 1] - grp.begin[k];
-    for (int slab = blockIdx.x - grp.begin[k]; slab < nslabs; slab += stride) {
-        if (TAG == 2 || (TAG == 0 && a.N2 == 256)) split_slab<64, 256, 256, 128>(a, slab, sW, sB);
-        else split_slab<64, 256, 128, 128>(a, slab, sW, sB);
-        // every wave has read the last chunk before anybody's copies of the next slab land in the buffers
-        asm volatile("s_barrier" ::: "memory");
-    }
+    const int nslabs = (a.M + 127) / 128, stride = grp.begin[k + 1] - grp.begin[k], first = blockIdx.x - grp.begin[k];
+    if (first >= nslabs) return;
+    if (TAG == 2 || (TAG == 0 && a.N2 == 256)) split_net<64, 256, 256, 128>(a, first, stride, nslabs, sW, sB);
+    else split_net<64, 256, 128, 128>(a, first, stride, nslabs, sW, sB);
 }
 
 int split_check(const bg_mlp_chain_split& q) {

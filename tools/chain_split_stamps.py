@@ -16,6 +16,8 @@ cases = {k: T._case(M, dims, seed=3, k_real=kr, wgs=wgs[k]) for k, (M, dims, kr)
 
 
 def report(name, tag):
+    """stamps: [0] kernel start, [1 + 2 c] arrival at the top of chunk c of the LAST slab of the workgroup, [2 + 2 c] released by its barrier,
+    [1 + 2 C] kernel end (behind the last slab's tail), [62] / [63] 100 MHz wall clock at start / end"""
     M, dims, _ = nets[name]
     K0, N1, N2, N3 = dims
     buf = np.zeros(2 * 256 * 4 * 64, dtype=np.int64)
@@ -24,16 +26,18 @@ def report(name, tag):
     chunks = [(K0 // 32, N1), (N1 // 32, N2), (N2 // 32, N3)]
     Cn = sum(c for c, _ in chunks)
     mf = [n // 32 * 2 * 9 * 32 for c, n in chunks for _ in range(c)]
-    arrive, released, issued = t[:, :, 1 : 1 + 3 * Cn : 3], t[:, :, 2 : 2 + 3 * Cn : 3], t[:, :, 3 : 3 + 3 * Cn : 3]
-    end = t[:, :, 1 + 3 * Cn]
+    arrive, released = t[:, :, 1 : 1 + 2 * Cn : 2], t[:, :, 2 : 2 + 2 * Cn : 2]
+    end = t[:, :, 1 + 2 * Cn]
     nxt = np.concatenate((arrive[:, :, 1:], end[:, :, None]), axis=2)
     med = lambda a: np.median(a.reshape(-1, a.shape[-1]), axis=0)
-    wait, dma, body = med(released - arrive), med(issued - released), med(nxt - issued)
+    wait, body = med(released - arrive), med(nxt - released)
+    slabs = -(-M // 128)
+    per_wg = -(-slabs // wgs[name])
     tot = np.median(end - t[:, :, 0])
     ghz = np.median((end - t[:, :, 0]) / np.maximum(1, t[:, :, 63] - t[:, :, 62])) * 0.1
-    print(f"{name} [{tag}]: slab {tot:.0f} cycles = {tot / ghz / 1e3:.1f} us at {ghz:.2f} GHz; MFMA {sum(mf)}; prologue {np.median(arrive[:, :, 0] - t[:, :, 0]):.0f}")
-    print("   chunk: wait / copies / body (MFMA)   " + "  ".join(f"{w:.0f}/{d:.0f}/{b:.0f}({f})" for w, d, b, f in zip(wait, dma, body, mf)), flush=True)
-    print(f"   sums: wait {wait.sum():.0f}  copies {dma.sum():.0f}  body {body.sum():.0f}", flush=True)
+    print(f"{name} [{tag}]: kernel {tot:.0f} cycles = {tot / ghz / 1e3:.1f} us at {ghz:.2f} GHz for {per_wg} slabs = {tot / per_wg:.0f} cycles per slab; MFMA {sum(mf)} per slab")
+    print("   last slab, chunk: wait / body (MFMA)   " + "  ".join(f"{w:.0f}/{b:.0f}({f})" for w, b, f in zip(wait, body, mf)), flush=True)
+    print(f"   sums: wait {wait.sum():.0f}  body {body.sum():.0f} (the last chunk's body includes the kernel's tail)", flush=True)
 
 
 for name in nets:
