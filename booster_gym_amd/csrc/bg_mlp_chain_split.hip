@@ -69,17 +69,36 @@ __device__ __forceinline__ void wait_vm() {
 __device__ __forceinline__ float elu_f(float x) { return x > 0.f ? x : __expf(x) - 1.0f; }
 
 // The split of one pair of fp32 values into the three planes' packed bf16 pairs (low half = x0), in four pieces that ride behind four MFMAs:
-// 1 + 4 + 1 + 5 VALU instructions.
-struct SplitTmp { unsigned u0, u1, v0, v1; float r0, r1; };
+// 3 + 3 + 3 + 2 VALU instructions (an MFMA gap takes four for free).
+struct SplitTmp { unsigned m0, m1, n0, n1; float r0, r1, s0; };
 template <int PH>
 __device__ __forceinline__ void split_phase(float x0, float x1, SplitTmp& s, unsigned& hp, unsigned& mp, unsigned& lp) {
-    if constexpr (PH == 0) { s.u0 = __float_as_uint(x0); s.u1 = __float_as_uint(x1); hp = __builtin_amdgcn_perm(s.u1, s.u0, 0x07060302u); }
-    if constexpr (PH == 1) { s.r0 = x0 - __uint_as_float(s.u0 & 0xffff0000u); s.r1 = x1 - __uint_as_float(s.u1 & 0xffff0000u); }
-    if constexpr (PH == 2) { s.v0 = __float_as_uint(s.r0); s.v1 = __float_as_uint(s.r1); mp = __builtin_amdgcn_perm(s.v1, s.v0, 0x07060302u); }
-    if constexpr (PH == 3) {
-        const float s0 = s.r0 - __uint_as_float(s.v0 & 0xffff0000u), s1 = s.r1 - __uint_as_float(s.v1 & 0xffff0000u);
-        lp = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s0), 0x07060302u);
+#ifndef BG_ABL_NOSPLIT
+    if constexpr (PH == 0) {
+        const unsigned u0 = __float_as_uint(x0), u1 = __float_as_uint(x1);
+        hp = __builtin_amdgcn_perm(u1, u0, 0x07060302u); s.m0 = u0 & 0xffff0000u; s.m1 = u1 & 0xffff0000u;
     }
+    if constexpr (PH == 1) {
+        s.r0 = x0 - __uint_as_float(s.m0); s.r1 = x1 - __uint_as_float(s.m1);
+        mp = __builtin_amdgcn_perm(__float_as_uint(s.r1), __float_as_uint(s.r0), 0x07060302u);
+    }
+    if constexpr (PH == 2) { s.n0 = __float_as_uint(s.r0) & 0xffff0000u; s.n1 = __float_as_uint(s.r1) & 0xffff0000u; s.s0 = s.r0 - __uint_as_float(s.n0); }
+    if constexpr (PH == 3) { const float s1 = s.r1 - __uint_as_float(s.n1); lp = __builtin_amdgcn_perm(__float_as_uint(s1), __float_as_uint(s.s0), 0x07060302u); }
+#endif
+}
+// ELU of an accumulator element in two pieces (3 + 1 issue slots: the exponential counts double; then 3)
+struct FinTmp { float v, e; };
+__device__ __forceinline__ void fin_a(FinTmp& f, float x) {
+#ifndef BG_ABL_NOFIN
+    f.v = x; f.e = __expf(x);
+#endif
+}
+__device__ __forceinline__ float fin_b(const FinTmp& f, float x) {
+#ifndef BG_ABL_NOFIN
+    return f.v > 0.f ? f.v : f.e - 1.0f;
+#else
+    return x;
+#endif
 }
 
 // One tile's nine products (small terms first); fill(gap) runs behind MFMA number gap, pinned there.
@@ -111,7 +130,9 @@ __device__ __forceinline__ void dma_piece(const unsigned* __restrict__ P, int CH
     const unsigned lofs = rowpart[m] * (unsigned)CH + piecepart[m];
     // inline asm: the copies' bookkeeping is explicit (wait_vm), the compiler must not drain vmcnt for them; M0 cannot be named as a clobber
     // (reserved), the backend never keeps a value of its own live in M0 across an inline asm (see bg_mlp_chain.hip)
+#ifndef BG_ABL_NODMA
     asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lofs), "s"(base), "s"(lds) : "memory");
+#endif
 }
 
 struct Frag { u32x4 p[3]; };
@@ -153,16 +174,23 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
         static constexpr int tilesteps(int cc) { return 2 * rows(cc) / 32; }
         // copies per tile-step of chunk cc (those of chunk cc + 2, dealt from the chunk's first tile-step on)
         static constexpr int pp(int cc) { return (ndma(cc + 2) + tilesteps(cc) - 1) / tilesteps(cc); }
+        // layer 3 of the slab before is finished two elements per tile-step during k-steps 0 .. 2 of layer 1 (48 elements) and one per tile-step during
+        // the first 16 tile-steps of layer 2 (chunk 0 at 8 tiles, chunks 0 and 1 at 4)
         static constexpr int stores_in(int cc) {
-            if (cc == 0) return 12;                       // layer 3 of the slab before: elements 0 .. 47
-            if (cc == 1) return 4 + 4;                    // ... 48 .. 63; tile 0 of layer 1
-            if (cc < C0 + C1) return 4;                   // tile cc - C0 + 1 of layer 1 (the last chunk: tile 0 of layer 2)
+            if (cc == 0) return 8;                        // layer 3 of the slab before: elements 0 .. 31
+            if (cc == 1) return 4 + 4;                    // ... 32 .. 47; tile 0 of layer 1
+            if (cc < C0 + C1) {                           // tile cc - C0 + 1 of layer 1 (the last chunk: tile 0 of layer 2) ...
+                const int kc = cc - C0;
+                return 4 + (NT2 == 8 ? (kc == 0 ? 4 : 0) : (kc <= 1 ? 2 : 0));  // ... and elements 48 .. 63 of layer 3
+            }
             return cc - C0 - C1 + 1 < NT2 ? 4 : 0;        // tile cc - C0 - C1 + 1 of layer 2
         }
         static constexpr int loads_in(int cc) { return cc == C0 + C1 ? K0 / 8 : 0; }  // the next slab's input rows
         static constexpr int ops_in(int cc) { return ndma(cc + 2) + stores_in(cc) + loads_in(cc); }
-        // what a wave has issued behind the last copy of chunk cc when it arrives at the top of iteration cc: at most everything of iteration cc - 1
-        static constexpr int behind(int cc) { return ops_in((cc + C - 1) % C); }
+        // The barrier that publishes chunk cc stands in front of the LAST tile-step of chunk cc - 1 (whose MFMAs then cover the latency of the first
+        // fragment read of chunk cc).  What a wave has issued behind the last copy of chunk cc (issued during chunk cc - 2) when it arrives there: at
+        // least everything of chunk cc - 1 but what its last tile-step issues (never more than 3 operations: a store or two, a load)
+        static constexpr int behind(int cc) { const int n = ops_in((cc + C - 1) % C) - 3; return n > 0 ? n : 0; }
     };
     // LDS image of stream chunk cc: buffer (cc + phase) % 3, the phase advancing by C per slab; bb[r]: byte offset of the buffer of chunks cc % 3 == r
     unsigned bb[3] = {0u, (unsigned)BUFDW * 4u, 2u * (unsigned)BUFDW * 4u};
@@ -185,9 +213,11 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
     f32x16 a1[NT1], a2[NT2], a3[NT3];
     float x0[K0 / 2];
     u32x4 xp[3];
-    unsigned xn[3][4];
+    unsigned xn[3][4] = {};
+    Frag fr[2];
     f32x4 wv[3];   // value-head weights of the group of four layer-3 elements in work, of the one before (elements may still be pending) and of the next
     float part = 0.f;
+    const float vbias = a.v_out ? a.v_b[0] : 0.f;  // (read once: a load in the middle of the stream would be waited for with everything else)
     // bias -> accumulators: feature 32 t + 8 g + 4 h + q in register 4 g + q of tile t (one 16-byte LDS read, straight into the accumulator registers)
     auto init4 = [&](auto& A, int ofs, auto t_, auto g_) {
         constexpr int t = decltype(t_)::value, g = decltype(g_)::value;
@@ -199,22 +229,47 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
         const f32x4 v = *reinterpret_cast<const f32x4*>(a.X + (size_t)(r < a.M ? r : a.M - 1) * K0 + 4 * h + 8 * j);
         x0[4 * j + 0] = v.x; x0[4 * j + 1] = v.y; x0[4 * j + 2] = v.z; x0[4 * j + 3] = v.w;
     };
-    auto fin = [&](auto& A, auto t_, auto r_) { constexpr int t = decltype(t_)::value, r = decltype(r_)::value; A[t][r] = elu_f(A[t][r]); };
+    // ELU of element r of tile t in place, in two pieces (fin_a / fin_b)
+    auto fa = [&](FinTmp& f, auto& A, auto t_, auto r_) { fin_a(f, A[decltype(t_)::value][decltype(r_)::value]); };
+    auto fb = [&](const FinTmp& f, auto& A, auto t_, auto r_) { constexpr int t = decltype(t_)::value, r = decltype(r_)::value; A[t][r] = fin_b(f, A[t][r]); };
     auto store4 = [&](auto& A, float* __restrict__ Y, int r, auto N_, auto t_, auto g_) {
+#ifndef BG_ABL_NOSTORE
         constexpr int N = decltype(N_)::value, t = decltype(t_)::value, g = decltype(g_)::value;
         const f32x4 v = {A[t][4 * g + 0], A[t][4 * g + 1], A[t][4 * g + 2], A[t][4 * g + 3]};
         *reinterpret_cast<f32x4*>(Y + (size_t)r * N + 32 * t + 8 * g + 4 * h) = v;
+#endif
     };
     auto vw4 = [&](auto G_) { constexpr int G = decltype(G_)::value; wv[G % 3] = *reinterpret_cast<const f32x4*>(&sB[N1 + N2 + N3 + 32 * (G / 4) + 8 * (G % 4) + 4 * h]); };
-    // element e of layer 3 (tile e / 16, register e % 16): ELU in place + its term of the value head
-    auto l3_elem = [&](auto e_) {
+    // element e of layer 3 (tile e / 16, register e % 16): ELU in place (two pieces) + its term of the value head; the weights of group e / 4 + 1 are
+    // fetched with the first element of group e / 4
+    auto l3_a = [&](FinTmp& f, auto e_) {
         constexpr int e = decltype(e_)::value;
-        fin(a3, IC<e / 16>{}, IC<e % 16>{});
+        if constexpr (e % 4 == 0 && e / 4 + 1 < 16) vw4(IC<e / 4 + 1>{});
+        fa(f, a3, IC<e / 16>{}, IC<e % 16>{});
+    };
+    auto l3_b = [&](const FinTmp& f, auto e_, int rowp) {
+        constexpr int e = decltype(e_)::value;
+        fb(f, a3, IC<e / 16>{}, IC<e % 16>{});
         part = fmaf(a3[e / 16][e % 16], wv[(e / 4) % 3][e % 4], part);
+        if constexpr (e % 4 == 3) store4(a3, a.Y3, rowp, IC<N3>{}, IC<e / 16>{}, IC<(e / 4) % 4>{});
     };
     auto split_pair_at = [&](auto ph_, float v0, float v1, SplitTmp& st, auto p_) {
         constexpr int p = decltype(p_)::value;
         split_phase<decltype(ph_)::value>(v0, v1, st, xn[0][p], xn[1][p], xn[2][p]);
+    };
+    // The top of chunk cc: its copies have landed (this wave's part), the barrier publishes them and tells that everybody has read chunk cc - 1's
+    // fragments (the copies of chunk cc + 2 will overwrite them); then the first fragment read of the chunk.
+    auto chunk_top = [&](auto cc_) {
+        constexpr int cc = decltype(cc_)::value;
+        BG_PIN();
+        BG_STAMP(1 + 2 * (cc % C));
+        wait_vm<S::behind(cc)>();
+        __builtin_amdgcn_s_waitcnt(0xC07F);      // lgkmcnt(0): this wave's fragment reads of the chunk before are in its registers
+        asm volatile("s_barrier" ::: "memory");  // no fence: a workgroup fence would drain vmcnt (stores and younger copies included)
+        BG_STAMP(2 + 2 * (cc % C));
+        BG_PIN();
+        read_w(fr[0], swl + bb[cc % 3] / 4 + s0);
+        BG_PIN();
     };
 
     // ---- prologue of the first slab
@@ -245,38 +300,34 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
 #pragma unroll
         for (int q = 0; q < 3; q++) xp[q] = u32x4{xn[q][0], xn[q][1], xn[q][2], xn[q][3]};
     }
-    int rowp = row;        // the slab whose layer 3 is finished during this slab's layer 1 (first slab: itself -- rewritten later with the real values)
+    chunk_top(IC<0>{});
+    int rowp = row;        // the slab whose layer 3 is finished during this slab's layers 1 / 2 (first slab: itself -- rewritten later with the real values)
     bool has_prev = false;
 
     // One layer: chunks base .. base + K / 32 - 1 of the stream.  xin(s): the lane's s'th input value (k-step J takes values 8 J .. 8 J + 7).
+    // What rides behind MFMA g of a tile-step: 0: the next fragments, a copy; 1, 2 and 7, 8: one element of an epilogue each (ELU in two pieces),
+    // stores behind 8; 3 .. 6: the split of one pair; 5: a load; 6: a second copy.  Four issue slots per gap are free.
     auto layer = [&](auto L_, auto& acc, auto xin, auto K_, auto N_, auto base_, int rown) {
         constexpr int L = decltype(L_)::value, K = decltype(K_)::value, N = decltype(N_)::value, NT = N / 32, CH = K / 32, base = decltype(base_)::value;
         constexpr int EPT = 8 / NT;  // elements of the tile below finished per tile-step (8 per k-step)
         static_for<CH>([&](auto kc_) {
             constexpr int kc = decltype(kc_)::value, c = base + kc, PP = S::pp(c);
             const unsigned* sw = swl + bb[c % 3] / 4;
-            // chunk c complete in LDS (this wave's part), then published by the barrier; what iteration c - 1 issued may stay in flight
-            BG_PIN();
-            BG_STAMP(1 + 2 * c);
-            wait_vm<S::behind(c)>();
-            asm volatile("s_barrier" ::: "memory");  // no fence: a workgroup fence would drain vmcnt (stores and younger copies included)
-            BG_STAMP(2 + 2 * c);
-            BG_PIN();
-            Frag fr[2];
-            read_w(fr[0], sw + s0);
             static_for<2>([&](auto j_) {
                 constexpr int j = decltype(j_)::value, J = 2 * kc + j;
                 constexpr bool lastk = (J == K / 16 - 1);
                 static_for<NT>([&](auto t_) {
                     constexpr int t = decltype(t_)::value, ts = j * NT + t;
                     SplitTmp st0, st1;
+                    FinTmp f0, f1;
+                    if constexpr (ts == 2 * NT - 1) chunk_top(IC<c + 1>{});  // (reads the next chunk's first fragments into fr[0]; this tile-step's are in fr[1])
                     mfma9(acc[t], fr[ts & 1].p, xp, [&](auto g_) {
                         constexpr int g = decltype(g_)::value;
                         // the next tile-step's weight fragments
                         if constexpr (g == 0 && ts + 1 < 2 * NT) read_w(fr[(ts + 1) & 1], sw + ((ts + 1) / NT ? s1 : s0) + ((ts + 1) % NT) * 32 * SP_ROW);
                         // the copies of chunk c + 2: PP per tile-step from the chunk's first tile-step on
-                        if constexpr (g == 8) dma(IC<c + AHEAD>{}, IC<ts * PP>{});
-                        if constexpr (g == 2 && PP >= 2) dma(IC<c + AHEAD>{}, IC<ts * PP + 1>{});
+                        if constexpr (g == 0) dma(IC<c + AHEAD>{}, IC<ts * PP>{});
+                        if constexpr (g == 6 && PP >= 2) dma(IC<c + AHEAD>{}, IC<ts * PP + 1>{});
                         static_assert(PP <= 2, "");
                         if constexpr (!lastk) {
                             // the planes of k-step J + 1: one pair per NT / 4 tile-steps, pieces behind MFMAs 3 .. 6
@@ -285,35 +336,35 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                                 split_pair_at(IC<g - 3>{}, xin(IC<s>{}), xin(IC<s + 1>{}), st0, IC<p>{});
                             }
                         }
-                        if constexpr (L == 1) {
-                            // layer 3 of the slab before: elements 0 .. 47 in chunk 0 (3 per tile-step), 48 .. 63 in k-step 2 (2 per tile-step)
-                            constexpr int tsg = kc * 2 * NT + ts, e0 = tsg < 16 ? 3 * tsg : 48 + 2 * (tsg - 16), cnt = tsg < 16 ? 3 : tsg < 24 ? 2 : 0;
-                            if constexpr (cnt > 0) {
-                                constexpr int k = g == 1 ? 0 : g == 2 ? 1 : g == 7 ? 2 : -1;
-                                if constexpr (k >= 0 && k < cnt) l3_elem(IC<e0 + k>{});
-                                if constexpr (g == 0) {  // value-head weights of the next group of four, one group ahead
-                                    if constexpr (e0 % 4 == 0 && e0 / 4 + 1 < 16) vw4(IC<e0 / 4 + 1>{});
-                                    else if constexpr ((e0 + 1) % 4 == 0 && (e0 + 1) / 4 + 1 < 16 && cnt > 1) vw4(IC<(e0 + 1) / 4 + 1>{});
-                                    else if constexpr ((e0 + 2) % 4 == 0 && (e0 + 2) / 4 + 1 < 16 && cnt > 2) vw4(IC<(e0 + 2) / 4 + 1>{});
-                                }
-                                if constexpr (g == 8) {
-                                    constexpr int el = e0 + cnt - 1, G = el / 4;  // a group is complete when its element 4 G + 3 is: at most one per tile-step
-                                    if constexpr (e0 <= 4 * G + 3 && 4 * G + 3 <= el) store4(a3, a.Y3, rowp, IC<N3>{}, IC<G / 4>{}, IC<G % 4>{});
-                                    else if constexpr (G >= 1 && e0 <= 4 * G - 1) store4(a3, a.Y3, rowp, IC<N3>{}, IC<(G - 1) / 4>{}, IC<(G - 1) % 4>{});
-                                }
-                            }
-                        } else if constexpr (!lastk) {
+                        if constexpr (L == 1 && J <= 2) {
+                            // layer 3 of the slab before: elements 0 .. 47, two per tile-step
+                            constexpr int e0 = 2 * (J * NT + t);
+                            if constexpr (g == 1) l3_a(f0, IC<e0>{});
+                            if constexpr (g == 2) l3_b(f0, IC<e0>{}, rowp);
+                            if constexpr (g == 7) l3_a(f1, IC<e0 + 1>{});
+                            if constexpr (g == 8) l3_b(f1, IC<e0 + 1>{}, rowp);
+                        }
+                        if constexpr (L == 2 && kc * 2 * NT + ts < 16) {
+                            // ... elements 48 .. 63, one per tile-step, behind MFMAs the split leaves lightly used
+                            constexpr int e = 48 + kc * 2 * NT + ts;
+                            if constexpr (g == 0) l3_a(f1, IC<e>{});
+                            if constexpr (g == 6) l3_b(f1, IC<e>{}, rowp);
+                        }
+                        if constexpr (L >= 2 && !lastk) {
                             // tile kc + 1 of the layer below: elements 8 j .. 8 j + 7 during this k-step, stored by fours
                             constexpr int NTP = K / 32;
                             auto& prev = [&]() -> auto& { if constexpr (L == 2) return a1; else return a2; }();
                             float* __restrict__ Yprev = L == 2 ? a.Y1 : a.Y2;
                             if constexpr (kc + 1 < NTP) {
                                 if constexpr (EPT == 1) {
-                                    if constexpr (g == 1) fin(prev, IC<kc + 1>{}, IC<8 * j + t>{});
+                                    if constexpr (g == 1) fa(f0, prev, IC<kc + 1>{}, IC<8 * j + t>{});
+                                    if constexpr (g == 2) fb(f0, prev, IC<kc + 1>{}, IC<8 * j + t>{});
                                     if constexpr (g == 8 && (t & 3) == 3) store4(prev, Yprev, row, IC<K>{}, IC<kc + 1>{}, IC<(8 * j + t) / 4>{});
                                 } else {
-                                    if constexpr (g == 1) fin(prev, IC<kc + 1>{}, IC<8 * j + 2 * t>{});
-                                    if constexpr (g == 7) fin(prev, IC<kc + 1>{}, IC<8 * j + 2 * t + 1>{});
+                                    if constexpr (g == 1) fa(f0, prev, IC<kc + 1>{}, IC<8 * j + 2 * t>{});
+                                    if constexpr (g == 2) fb(f0, prev, IC<kc + 1>{}, IC<8 * j + 2 * t>{});
+                                    if constexpr (g == 7) fa(f1, prev, IC<kc + 1>{}, IC<8 * j + 2 * t + 1>{});
+                                    if constexpr (g == 8) fb(f1, prev, IC<kc + 1>{}, IC<8 * j + 2 * t + 1>{});
                                     if constexpr (g == 8 && (t & 1) == 1) store4(prev, Yprev, row, IC<K>{}, IC<kc + 1>{}, IC<(8 * j + 2 * t) / 4>{});
                                 }
                             }
@@ -322,8 +373,8 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                             // the next slab's input rows (the registers of the layer-1 input are free), one 16-byte load per tile-step of the first chunk
                             if constexpr (kc == 0 && g == 5) loadx(rown, IC<ts>{});
                             // ... and its layer-1 accumulators = bias, over the last two chunks
-                            if constexpr (kc >= CH - 2 && (g == 2 || g == 6)) {
-                                constexpr int G = ((kc - (CH - 2)) * 2 * NT + ts) * 2 + (g == 6);
+                            if constexpr (kc >= CH - 2 && (g == 3 || g == 4)) {
+                                constexpr int G = ((kc - (CH - 2)) * 2 * NT + ts) * 2 + (g == 4);
                                 init4(a1, 0, IC<G / 4>{}, IC<G % 4>{});
                             }
                         }
@@ -334,8 +385,9 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                             if constexpr (L == 1) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT2) init4(a2, N1, IC<G / 4>{}, IC<G % 4>{}); } }
                             if constexpr (L == 2) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT3) init4(a3, N1 + N2, IC<G / 4>{}, IC<G % 4>{}); } }
                             if constexpr (NT == 8) {
-                                if constexpr (t >= 1 && t <= 4) {
-                                    if constexpr (g == 1 || g == 3 || g == 5 || g == 7) fin(acc, IC<0>{}, IC<4 * (t - 1) + (g - 1) / 2>{});
+                                if constexpr (t >= 1 && t <= 4 && g >= 1) {
+                                    constexpr int r = 4 * (t - 1) + (g - 1) / 2;
+                                    if constexpr (g & 1) fa(f0, acc, IC<0>{}, IC<r>{}); else fb(f0, acc, IC<0>{}, IC<r>{});
                                     if constexpr (g == 8) store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<t - 1>{});
                                 }
                                 if constexpr (t == 5 || t == 6) {
@@ -345,8 +397,11 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                                 }
                             } else {
                                 if constexpr (t == 1 || t == 2) {
-                                    if constexpr (g <= 7) fin(acc, IC<0>{}, IC<8 * (t - 1) + g>{});
-                                    if constexpr (g == 8) { store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1)>{}); store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1) + 1>{}); }
+                                    // eight elements: piece a of element g behind MFMA g, piece b behind the next (two temporaries in turn)
+                                    if constexpr (g >= 1) { if constexpr ((g - 1) & 1) fb(f1, acc, IC<0>{}, IC<8 * (t - 1) + g - 1>{}); else fb(f0, acc, IC<0>{}, IC<8 * (t - 1) + g - 1>{}); }
+                                    if constexpr (g <= 7) { if constexpr (g & 1) fa(f1, acc, IC<0>{}, IC<8 * (t - 1) + g>{}); else fa(f0, acc, IC<0>{}, IC<8 * (t - 1) + g>{}); }
+                                    if constexpr (g == 4) store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1)>{});
+                                    if constexpr (g == 8) store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1) + 1>{});
                                 }
                                 if constexpr (t == 3 && g <= 7) {
                                     constexpr int p = g / 2;
@@ -364,16 +419,16 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                             }
                         }
                     });
+                    if constexpr (L == 2 && kc * 2 * NT + ts == 15) {
+                        // the slab before is complete: its value (the two halves of a sample's features sit in lanes i and i + 32)
+                        part += __shfl_xor(part, 32);
+                        if (a.v_out && has_prev && h == 0 && rowp < a.M) a.v_out[rowp] = part + vbias;
+                        part = 0.f;
+                        vw4(IC<0>{});
+                    }
                 });
 #pragma unroll
                 for (int q = 0; q < 3; q++) xp[q] = u32x4{xn[q][0], xn[q][1], xn[q][2], xn[q][3]};
-                if constexpr (L == 1 && kc == 1 && j == 0) {
-                    // the slab before is complete: its value (the two halves of a sample's features sit in lanes i and i + 32)
-                    part += __shfl_xor(part, 32);
-                    if (a.v_out && has_prev && h == 0 && rowp < a.M) a.v_out[rowp] = part + a.v_b[0];
-                    part = 0.f;
-                    vw4(IC<0>{});
-                }
             });
         });
     };
@@ -398,13 +453,12 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
     }
     // layer 3 of the last slab
     static_for<16 * NT3>([&](auto e_) {
-        constexpr int e = decltype(e_)::value;
-        if constexpr (e % 4 == 0 && e / 4 + 1 < 16) vw4(IC<e / 4 + 1>{});
-        l3_elem(e_);
-        if constexpr (e % 4 == 3) store4(a3, a.Y3, rowp, IC<N3>{}, IC<e / 16>{}, IC<(e / 4) % 4>{});
+        FinTmp f;
+        l3_a(f, e_);
+        l3_b(f, e_, rowp);
     });
     part += __shfl_xor(part, 32);
-    if (a.v_out && h == 0 && rowp < a.M) a.v_out[rowp] = part + a.v_b[0];
+    if (a.v_out && h == 0 && rowp < a.M) a.v_out[rowp] = part + vbias;
     wait_vm<0>();  // the copies issued for a slab that does not exist must have landed before the workgroup's LDS is handed on
 #ifdef BG_CHAIN_PROBE_STAMPS
     stamps[1 + 2 * C] = clock64();

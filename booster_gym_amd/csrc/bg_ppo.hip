@@ -10,6 +10,7 @@
 #include <string>
 
 #include "../../include/booster_gym_amd.h"
+#include "bg_mirror.h"
 #include "bg_ppo_math.h"
 #include "bg_rng.h"
 
@@ -344,8 +345,7 @@ __global__ void adapt_lr_kernel(const double* __restrict__ kl_sum, float count, 
 //   mirrors  every updated parameter inside one of the caller's [rows][cols] weight matrices is also written to that matrix's mirror: a transposed
 //            copy (the operand layout of the backward layer kernel) or a copy with a wider row stride (the zero-padded first layer).  Six strided torch
 //            copies per mini-epoch (5-20 us each, inside the two chains) otherwise.
-constexpr int OPT_GRID = 64, OPT_THREADS = 1024, OPT_MAX_MIRRORS = 8;
-struct ParamMirrors { int n; bg_param_mirror m[OPT_MAX_MIRRORS]; };
+constexpr int OPT_GRID = 64, OPT_THREADS = 1024;
 __global__ __launch_bounds__(OPT_THREADS) void optimizer_step_kernel(int n, float* __restrict__ p, float* __restrict__ g, float* __restrict__ m,
                                                                      float* __restrict__ v, float* __restrict__ lr_dev, float bc1, float bc2_sqrt,
                                                                      float beta1, float beta2, float eps, float max_norm,
@@ -395,7 +395,7 @@ __global__ __launch_bounds__(OPT_THREADS) void optimizer_step_kernel(int n, floa
             const int j = i - mm.offset;
             if (j >= 0 && j < mm.rows * mm.cols) {
                 const int r = j / mm.cols, c = j - r * mm.cols;
-                mm.dst[mm.transpose ? (size_t)c * mm.ld + r : (size_t)r * mm.ld + c] = pn;
+                bg_mirror_write(mm, r, c, pn);
             }
         }
     }
@@ -580,13 +580,12 @@ extern "C" int bg_optimizer_step(int32_t n, float* params, float* grads, float* 
                                  double* stats_acc, double* stats_last, int32_t n_stats, int32_t kl_index, float kl_count, float desired_kl,
                                  float lr_min, float lr_max, uint32_t* ticket, const bg_param_mirror* mirrors, int32_t n_mirrors, void* stream) {
     if (n <= 0 || !params || !grads || !exp_avg || !exp_avg_sq || !lr_device || !ticket || step < 1) return bg_set_error(-1, "bg_optimizer_step: bad argument");
-    if (n_mirrors < 0 || n_mirrors > OPT_MAX_MIRRORS || (n_mirrors > 0 && !mirrors)) return bg_set_error(-1, "bg_optimizer_step: 0 to 8 mirrors");
+    if (n_mirrors < 0 || n_mirrors > OPT_MAX_MIRRORS || (n_mirrors > 0 && !mirrors)) return bg_set_error(-1, "bg_optimizer_step: 0 to 16 mirrors");
     ParamMirrors mir;
     mir.n = n_mirrors;
     for (int k = 0; k < n_mirrors; k++) {
         const bg_param_mirror& q = mirrors[k];
-        if (!q.dst || q.rows <= 0 || q.cols <= 0 || q.offset < 0 || (int64_t)q.offset + (int64_t)q.rows * q.cols > n || q.ld < (q.transpose ? q.rows : q.cols))
-            return bg_set_error(-1, "bg_optimizer_step: bad mirror descriptor");
+        if (!bg_mirror_ok(q, n)) return bg_set_error(-1, "bg_optimizer_step: bad mirror descriptor");
         mir.m[k] = q;
     }
     if ((((uintptr_t)grads) & 15) != 0) return bg_set_error(-1, "bg_optimizer_step: grads must be 16-byte aligned");

@@ -19,6 +19,7 @@
 #include <stdint.h>
 
 #include "../../include/booster_gym_amd.h"
+#include "bg_mirror.h"
 #include "bg_wgrad.h"
 
 extern int bg_set_error(int code, const char* msg);
@@ -26,9 +27,8 @@ extern int bg_wgrad_group_fill(const bg_wgrad_problem* problems, int32_t count, 
 
 namespace {
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int ADAM_GRID = 64, TAIL_THREADS = 256, RG_MAX = 8, OPT_MAX_MIRRORS = 8, TAIL_MAX_ITEMS = 8192;
+constexpr int ADAM_GRID = 64, TAIL_THREADS = 256, RG_MAX = 8, TAIL_MAX_ITEMS = 8192;
 struct ReduceGroup { int np; int begin[RG_MAX]; bg_reduce_problem p[RG_MAX]; };
-struct ParamMirrors { int n; bg_param_mirror m[OPT_MAX_MIRRORS]; };
 struct OptArgs {
     int n; float *p, *g, *m, *v, *lr_dev; float bc1, bc2_sqrt, beta1, beta2, eps, max_norm;
     double* grad_logstd; int ls_off, ls_n;
@@ -167,7 +167,7 @@ __global__ __launch_bounds__(1024) void tail_adam_kernel(OptArgs o, ParamMirrors
             const int j = i - mm.offset;
             if (j >= 0 && j < mm.rows * mm.cols) {
                 const int r = j / mm.cols, c = j - r * mm.cols;
-                mm.dst[mm.transpose ? (size_t)c * mm.ld + r : (size_t)r * mm.ld + c] = pn;
+                bg_mirror_write(mm, r, c, pn);
             }
         }
     }
@@ -250,7 +250,7 @@ extern "C" int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, co
     if (grad_logstd && (ls_n <= 0 || ls_n > 1024 || ls_off < 0 || ls_off + ls_n > n)) return bg_set_error(-1, "bg_update_tail: log-std slice outside the buffer");
     if (stats && (!stats_acc || !stats_last || n_stats <= 0 || kl_index < 0 || kl_index >= n_stats || !(kl_count > 0.f)))
         return bg_set_error(-1, "bg_update_tail: statistics arguments");
-    if (n_mirrors < 0 || n_mirrors > OPT_MAX_MIRRORS || (n_mirrors > 0 && !mirrors)) return bg_set_error(-1, "bg_update_tail: at most 8 weight mirrors");
+    if (n_mirrors < 0 || n_mirrors > OPT_MAX_MIRRORS || (n_mirrors > 0 && !mirrors)) return bg_set_error(-1, "bg_update_tail: at most 16 weight mirrors");
     WgradGroup wg;
     ReduceGroup rg;
     int blocks = 0, fin = 0;
@@ -262,8 +262,7 @@ extern "C" int bg_update_tail(const bg_wgrad_problem* wgrad, int32_t n_wgrad, co
     mir.n = n_mirrors;
     for (int k = 0; k < n_mirrors; k++) {
         const bg_param_mirror& q = mirrors[k];
-        if (!q.dst || q.rows <= 0 || q.cols <= 0 || q.offset < 0 || q.offset + q.rows * q.cols > n || q.ld < (q.transpose ? q.rows : q.cols))
-            return bg_set_error(-1, "bg_update_tail: bad weight mirror");
+        if (!bg_mirror_ok(q, n)) return bg_set_error(-1, "bg_update_tail: bad weight mirror");
         mir.m[k] = q;
     }
     OptArgs o;

@@ -126,6 +126,28 @@ class MLPTrainer:
     # per layer)
     CHAIN = True
 
+    # ... and that launch on the bf16 matrix pipe with fp32 semantics (bg_mlp_chain_split.hip: every fp32 operand the exact sum of three bf16 numbers, all
+    # 9 cross products accumulated in fp32 -- 9 x 32 cycles per 32 x 32 x 16 block against 8 x 64 on the fp32 pipe, error against float64 at or below the
+    # fp32-MFMA chain's).  The default; BG_CHAIN_SPLIT=0 (or CHAIN_SPLIT = False) runs the fp32-MFMA chain (bg_mlp_chain.hip).
+    CHAIN_SPLIT = __import__("os").environ.get("BG_CHAIN_SPLIT", "1") == "1"
+
+    def _chain_split(self):
+        return self.CHAIN_SPLIT and self._chainable()
+
+    def _fresh_planes(self):
+        """The bf16 planes of the three hidden layers' weights (what the chained split kernel reads): created on first use; rewritten from the
+        parameters unless the optimiser launch keeps them current (mirror_fresh)."""
+        ls, lib, stream = self.layers, _lib.load(), _lib.current_stream_ptr()
+        new = self.cplanes[0] is None
+        for i in range(3):
+            n_out, k_in = ls[i].weight.shape
+            kp = self._kin if i == 0 else k_in
+            if new:
+                self.cplanes[i] = torch.empty(n_out * kp * 3, dtype=torch.int16, device=ls[i].weight.device)
+            if new or not self.mirror_fresh:
+                _lib.check(lib.bg_mlp_split_weights(n_out, kp, _lib.ptr(ls[i].weight), k_in, n_out, k_in, 0, _lib.ptr(self.cplanes[i]), stream), "bg_mlp_split_weights")
+        return self.cplanes
+
     def _chainable(self):
         ls = self.layers
         return (self.CHAIN and self.FUSED and not self.SPLIT and len(ls) == 4 and self._kin == 64 and self.w0pad is not None
@@ -142,12 +164,17 @@ class MLPTrainer:
     def _chain_descriptor(self):
         """bg_mlp_chain of this network's hidden layers on the input of the forward pass in progress (self.x)."""
         ls = self.layers
-        if not self.mirror_fresh:
-            self.w0pad[:, : ls[0].weight.shape[1]].copy_(ls[0].weight)
         p = _lib.ptr
         vw, vb, vo = self.value_head if self.value_head is not None else (None, None, None)
         if vo is not None and (vo.numel() < self.x.shape[0] or vw.numel() != ls[2].weight.shape[0]):
             raise ValueError("value_head: weight [width of the last hidden layer], bias [1], output [rows]")
+        if self._chain_split():
+            P = self._fresh_planes()
+            return _lib.MlpChainSplit(self.x.shape[0], self._kin, ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0], int(self.chain_workgroups),
+                                      p(self.x), p(P[0]), p(P[1]), p(P[2]), p(ls[0].bias), p(ls[1].bias), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]),
+                                      p(self.acts[2]), p(vw), p(vb), p(vo))
+        if not self.mirror_fresh:
+            self.w0pad[:, : ls[0].weight.shape[1]].copy_(ls[0].weight)
         return _lib.MlpChain(self.x.shape[0], self._kin, ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0], int(self.chain_workgroups), p(self.x),
                              p(self.w0pad),
                              p(ls[0].bias), p(ls[1].weight), p(ls[1].bias), p(ls[2].weight), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]), p(self.acts[2]),
@@ -169,6 +196,9 @@ class MLPTrainer:
         for i, w in enumerate(self.wt):
             if w is not None:
                 w.copy_(ls[i].weight.t())
+        if self.cplanes[0] is not None:
+            self.mirror_fresh = False
+            self._fresh_planes()
         self.mirror_fresh = True
 
     def chain_rows_descriptor(self, row0, nrows):
@@ -190,8 +220,19 @@ class MLPTrainer:
     @staticmethod
     def forward_rows_group(jobs):
         """jobs = [(trainer, row0, nrows), ...]: the chained forward of those rows of every trainer's prepared pass in ONE launch (at most 4)."""
-        ds = (_lib.MlpChain * len(jobs))(*[tr.chain_rows_descriptor(r0, nr) for tr, r0, nr in jobs])
-        _lib.check(_lib.load().bg_mlp_chain_forward_group(ctypes.addressof(ds), len(jobs), _lib.current_stream_ptr()), "bg_mlp_chain_forward_group")
+        descs = [tr.chain_rows_descriptor(r0, nr) for tr, r0, nr in jobs]
+        MLPTrainer.launch_chain(descs)
+
+    @staticmethod
+    def launch_chain(descs):
+        """One launch for a list of chain descriptors of one kind (all bg_mlp_chain or all bg_mlp_chain_split); a mixed list runs as two launches."""
+        lib, st = _lib.load(), _lib.current_stream_ptr()
+        for kind, fn, name in ((_lib.MlpChainSplit, lib.bg_mlp_chain_forward_split, "bg_mlp_chain_forward_split"),
+                               (_lib.MlpChain, lib.bg_mlp_chain_forward_group, "bg_mlp_chain_forward_group")):
+            sel = [d for d in descs if isinstance(d, kind)]
+            if sel:
+                arr = (kind * len(sel))(*sel)
+                _lib.check(fn(ctypes.addressof(arr), len(sel), st), name)
 
     def __init__(self, seq, max_split=32):
         self.layers = [m for m in seq if isinstance(m, torch.nn.Linear)]
@@ -228,6 +269,7 @@ class MLPTrainer:
         # True while w0pad and wt ARE the current weights: the optimiser launch keeps them current (mirror_descriptors); False makes forward /
         # backward copy them first.  The owner of the optimiser sets it (utils/runner.py) and clears it wherever weights change by other means.
         self.mirror_fresh = False
+        self.cplanes = [None] * 3  # CHAIN_SPLIT: bf16 planes of the three hidden layers' weights for the chained forward kernel
         self.planes = [None] * len(self.layers)  # SPLIT: bf16 planes of the weights (forward) ...
         self.planes_t = [None] * len(self.layers)  # ... and of the transposed weights (backward)
         l0 = self.layers[0]
@@ -275,10 +317,10 @@ class MLPTrainer:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
             d = self._chain_descriptor()
-            _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, stream), "bg_mlp_chain_forward_group")
+            self.launch_chain([d])
             if timed:
                 e1.record()
-                self.timed_events.append((e0, e1, x.shape[0], self._kin, tuple(l.weight.shape[0] for l in self.layers[:3]), "chain"))
+                self.timed_events.append((e0, e1, x.shape[0], self._kin, tuple(l.weight.shape[0] for l in self.layers[:3]), "chain_split" if self._chain_split() else "chain"))
             first, h = 3, self.acts[2]
         for i, l in enumerate(self.layers):
             if i < first:
@@ -385,16 +427,19 @@ class MLPTrainer:
             torch.sum(self.dw[i], dim=0, out=l.weight.grad)
 
     def mirror_descriptors(self, flat):
-        """bg_param_mirror entries for the copies of this network's weights that the fp32 layer kernels read (the zero-padded first layer, the
-        transposed hidden layers): handed to bg_optimizer_step, which then writes them together with the parameters.  `flat`: the optimiser's flat
+        """bg_param_mirror entries for the copies of this network's weights that the layer kernels read (the bf16 planes of the chained split forward
+        or the zero-padded first layer of the fp32 chain; the transposed hidden layers of the backward kernels): handed to bg_optimizer_step, which then writes them together with the parameters.  `flat`: the optimiser's flat
         parameter buffer (the weights are views of it).  Only buffers that exist are listed (they are created by the first forward / backward)."""
         out = []
         if self.SPLIT or not self.FUSED:
             return out
+        split = self._chain_split() and self.cplanes[0] is not None
         for i, l in enumerate(self.layers):
             off = (l.weight.data_ptr() - flat.data_ptr()) // 4
             rows, cols = l.weight.shape
-            if i == 0 and self.w0pad is not None:
+            if split and i < 3:  # the chained split kernel's planes (the padded input columns of the first layer stay zero)
+                out.append(_lib.ParamMirror(off, rows, cols, 2, self._kin if i == 0 else cols, 0, _lib.ptr(self.cplanes[i])))
+            if i == 0 and self.w0pad is not None and not split:
                 out.append(_lib.ParamMirror(off, rows, cols, 0, self.w0pad.shape[1], 0, _lib.ptr(self.w0pad)))
             if self.wt[i] is not None:
                 out.append(_lib.ParamMirror(off, rows, cols, 1, rows, 0, _lib.ptr(self.wt[i])))

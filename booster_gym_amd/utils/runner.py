@@ -600,7 +600,7 @@ class Runner:
             # same launch instead of six strided torch copies inside the chains of the next mini-epoch
             if mirrors is None:
                 ms = self._critic_tr.mirror_descriptors(self.optimizer.flat) + self._actor_tr.mirror_descriptors(self.optimizer.flat)
-                mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 8 else None
+                mirrors = (_lib.ParamMirror * len(ms))(*ms) if 0 < len(ms) <= 16 else None
             if one_tail and not self.dp.active:
                 self.optimizer.step_tail(wg_partial, [fin_c, fin_a] + fins, self._stats, self._stats_acc, self._stats_last, 4, B, alg["desired_kl"],
                                          grad_logstd=self._grad_logstd, ls_off=self._logstd_off, mirrors=mirrors)

@@ -267,7 +267,10 @@ int bg_adam_step(int32_t n, float* params, const float* grads, float* exp_avg, f
 int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_min, float lr_max, float* lr_device, void* stream);
 /* A second copy of one [rows][cols] row-major weight matrix of the flat parameter buffer that bg_optimizer_step keeps current while it updates the
  * parameters: transpose = 0: dst[r * ld + c] (ld >= cols: e.g. the first layer with its input columns zero-padded; the padding is not touched),
- * transpose = 1: dst[c * ld + r] (ld >= rows: the operand layout of bg_mlp_layer_backward).  offset = index of W[0][0] in params. */
+ * transpose = 1: dst[c * ld + r] (ld >= rows: the operand layout of bg_mlp_layer_backward).  offset = index of W[0][0] in params.
+ * transpose = 2 / 3: dst = the bf16 planes of W / of W^T as bg_mlp_split_weights(transpose = 0 / 1) writes them (uint16_t [n_out][ld / 32][3][32],
+ * 16-byte aligned, ld = k_out a multiple of 32 and >= cols / rows): what the chained split kernels read.  Elements outside the matrix (the
+ * zero-padded input columns of a first layer) are not touched: write them once with bg_mlp_split_weights. */
 typedef struct bg_param_mirror {
     int32_t offset, rows, cols, transpose, ld, pad;
     float* dst;
@@ -276,7 +279,7 @@ typedef struct bg_param_mirror {
  * lr_device (as bg_adapt_lr, with kl_sum = stats[kl_index]), and the bookkeeping of the float64 loss statistics: stats_last = stats,
  * stats_acc += stats, stats = 0 (and grad_logstd = 0) for the next mini-epoch.  grad_logstd (optional, float64 [ls_n]) is the log-std gradient as
  * the head kernels accumulate it; it is written into grads[ls_off .. ls_off + ls_n) first.  stats may be NULL (no learning-rate rule, no
- * bookkeeping).  ticket: one zero-initialised uint32 of device memory owned by the caller.  mirrors (optional, up to 8): see bg_param_mirror.
+ * bookkeeping).  ticket: one zero-initialised uint32 of device memory owned by the caller.  mirrors (optional, up to 16): see bg_param_mirror.
  * Deterministic (no float atomics). */
 int bg_optimizer_step(int32_t n, float* params, float* grads, float* exp_avg, float* exp_avg_sq, float* lr_device, int32_t step, float beta1, float beta2,
                       float eps, float max_grad_norm, double* grad_logstd, int32_t ls_off, int32_t ls_n, double* stats, double* stats_acc,

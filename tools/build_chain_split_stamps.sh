@@ -1,4 +1,5 @@
 #!/bin/bash
+# EXTRA='-DBG_ABL_NODMA' NAME=libbg_split_nodma: ablation builds (wrong results, timing only).
 # Builds tools/probe/libbg_split_stamps.so: the product library with bg_mlp_chain_split.hip compiled -DBG_CHAIN_PROBE_STAMPS (shader-clock stamps of every
 # wave around every chunk barrier of the chained split-bf16 forward kernel), for tools/chain_split_stamps.py.  Run here (hipcc cross-compiles), then
 #   gpurun -- 'BG_LIB=$GRAFT_REPO_ROOT/tools/probe/libbg_split_stamps.so python tools/chain_split_stamps.py'
@@ -6,7 +7,8 @@ set -e
 R=$(cd "$(dirname "$0")/.." && pwd)
 cd $R/booster_gym_amd/csrc && make
 FL="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -fno-slp-vectorize -fno-signed-zeros -ffinite-math-only -fassociative-math -freciprocal-math -fno-trapping-math -mllvm -amdgpu-sched-strategy=max-ilp"
-/opt/rocm/bin/hipcc $FL -DBG_CHAIN_PROBE_STAMPS $EXTRA -c bg_mlp_chain_split.hip -o /tmp/bg_split_stamps.o
+NAME=${NAME:-libbg_split_stamps}
+/opt/rocm/bin/hipcc $FL -DBG_CHAIN_PROBE_STAMPS $EXTRA -c bg_mlp_chain_split.hip -o /tmp/$NAME.o
 OBJS=$(ls *.o | grep -v bg_mlp_chain_split.o)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/probe/libbg_split_stamps.so $OBJS /tmp/bg_split_stamps.o
-echo built $R/tools/probe/libbg_split_stamps.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/probe/$NAME.so $OBJS /tmp/$NAME.o
+echo built $R/tools/probe/$NAME.so
