@@ -130,6 +130,9 @@ class MLPTrainer:
     # 9 cross products accumulated in fp32 -- 9 x 32 cycles per 32 x 32 x 16 block against 8 x 64 on the fp32 pipe, error against float64 at or below the
     # fp32-MFMA chain's).  The default; BG_CHAIN_SPLIT=0 (or CHAIN_SPLIT = False) runs the fp32-MFMA chain (bg_mlp_chain.hip).
     CHAIN_SPLIT = __import__("os").environ.get("BG_CHAIN_SPLIT", "1") == "1"
+    # ... and the backward-data pass of the hidden layers as one launch of the same arithmetic (bg_mlp_chain_split_bwd.hip); BG_CHAIN_SPLIT_BWD=0: one
+    # fp32-MFMA launch per layer (bg_mlp_layer_backward)
+    CHAIN_SPLIT_BWD = __import__("os").environ.get("BG_CHAIN_SPLIT_BWD", "1") == "1"
 
     def _chain_split(self):
         return self.CHAIN_SPLIT and self._chainable()
@@ -147,6 +150,36 @@ class MLPTrainer:
             if new or not self.mirror_fresh:
                 _lib.check(lib.bg_mlp_split_weights(n_out, kp, _lib.ptr(ls[i].weight), k_in, n_out, k_in, 0, _lib.ptr(self.cplanes[i]), stream), "bg_mlp_split_weights")
         return self.cplanes
+
+    def _chain_split_bwd(self):
+        """Does backward_hidden run as ONE launch on the bf16 matrix pipe (bg_mlp_chain_split_bwd.hip)?  Same widths as the chained forward."""
+        return self.CHAIN_SPLIT_BWD and self._chain_split()
+
+    def _fresh_planes_t(self):
+        """The bf16 planes of the transposed weights of hidden layers 2 and 1 (what the chained backward kernel reads), as _fresh_planes."""
+        ls, lib, stream = self.layers, _lib.load(), _lib.current_stream_ptr()
+        new = self.cplanes_t[1] is None
+        for i in (1, 2):
+            c_out, c_in = ls[i].weight.shape
+            if new:
+                self.cplanes_t[i] = torch.empty(c_in * c_out * 3, dtype=torch.int16, device=ls[i].weight.device)
+            if new or not self.mirror_fresh:
+                _lib.check(lib.bg_mlp_split_weights(c_in, c_out, _lib.ptr(ls[i].weight), c_in, c_out, c_in, 1, _lib.ptr(self.cplanes_t[i]), stream), "bg_mlp_split_weights")
+        return self.cplanes_t
+
+    def chain_backward_descriptor(self, g=None):
+        """bg_mlp_chain_split_bwd of this network's backward-data pass from g = dL/dz of the last hidden layer (default: hidden_grad)."""
+        ls, B, p = self.layers, self._B, _lib.ptr
+        g = self.hidden_grad if g is None else g
+        PT = self._fresh_planes_t()
+        n1, n2, n3 = ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0]
+        slabs = (B + 127) // 128
+        wg = self.chain_bwd_workgroups if 0 < self.chain_bwd_workgroups < slabs else slabs
+        if self.chain_colsum is None or self.chain_colsum.numel() < wg * (n1 + n2):
+            self.chain_colsum = torch.empty(slabs * (n1 + n2), dtype=torch.float32, device=g.device)
+        self._pending_wgrad = [(2, g), (1, self.gin[2]), (0, self.gin[1])]
+        return _lib.MlpChainSplitBwd(B, n1, n2, n3, int(self.chain_bwd_workgroups), 0, p(g), p(PT[2]), p(PT[1]), p(self.acts[1]), p(self.acts[0]), p(self.gin[2]),
+                                     p(self.gin[1]), p(self.chain_colsum), p(ls[1].bias.grad), p(ls[0].bias.grad))
 
     def _chainable(self):
         ls = self.layers
@@ -196,9 +229,12 @@ class MLPTrainer:
         for i, w in enumerate(self.wt):
             if w is not None:
                 w.copy_(ls[i].weight.t())
-        if self.cplanes[0] is not None:
+        if self.cplanes[0] is not None or self.cplanes_t[1] is not None:
             self.mirror_fresh = False
-            self._fresh_planes()
+            if self.cplanes[0] is not None:
+                self._fresh_planes()
+            if self.cplanes_t[1] is not None:
+                self._fresh_planes_t()
         self.mirror_fresh = True
 
     def chain_rows_descriptor(self, row0, nrows):
@@ -242,6 +278,7 @@ class MLPTrainer:
         self.timed_layer, self.timed_events = None, []
         # workgroups of the full-batch chained forward launch (0: one per slab); the runner sets it when two networks' launches share the chip
         self.chain_workgroups = 0
+        self.chain_bwd_workgroups = 0  # ... of the chained backward launch
         # (weight [N3], bias [1], out [rows]): a scalar output layer evaluated by the chained forward kernel itself (the critic's values); None: not
         self.value_head = None
 
@@ -259,7 +296,8 @@ class MLPTrainer:
         # (rows rounded up to whole 128-row slabs: the chained forward kernel stores every slab in full)
         rows_pad = (rows + 127) // 128 * 128
         self.acts = [torch.empty(rows_pad, l.weight.shape[0], dtype=torch.float32, device=dev)[:rows] for l in self.layers]
-        self.gin = [None] + [torch.empty(B, l.weight.shape[1], dtype=torch.float32, device=dev) for l in self.layers[1:]]
+        B_pad = (B + 127) // 128 * 128  # (whole 128-row slabs: the chained backward kernel stores every slab in full)
+        self.gin = [None] + [torch.empty(B_pad, l.weight.shape[1], dtype=torch.float32, device=dev)[:B] for l in self.layers[1:]]
         self.cs = [torch.empty(((B + 127) // 128) * l.weight.shape[0], dtype=torch.float32, device=dev) for l in self.layers]
         # weight gradients: hand-written split-over-the-batch MFMA kernel (bg_mlp_weight_grad) where the shape allows, scratch = slices x dW
         self.wg_slices = [self._wgrad_slices(B, l.weight.shape[0], k_in if i == 0 else l.weight.shape[1]) for i, l in enumerate(self.layers)]
@@ -270,6 +308,8 @@ class MLPTrainer:
         # backward copy them first.  The owner of the optimiser sets it (utils/runner.py) and clears it wherever weights change by other means.
         self.mirror_fresh = False
         self.cplanes = [None] * 3  # CHAIN_SPLIT: bf16 planes of the three hidden layers' weights for the chained forward kernel
+        self.cplanes_t = [None] * 3  # ... and of the transposed weights of layers 1 and 2 for the chained backward kernel
+        self.chain_colsum = None     # ... whose workgroups each leave one record of column sums here
         self.planes = [None] * len(self.layers)  # SPLIT: bf16 planes of the weights (forward) ...
         self.planes_t = [None] * len(self.layers)  # ... and of the transposed weights (backward)
         l0 = self.layers[0]
@@ -385,7 +425,17 @@ class MLPTrainer:
         if timed:  # bench.py: HIP events on the launch stream around this network's backward-data chain
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g, finishes)
+        if self._chain_split_bwd():
+            d = self.chain_backward_descriptor(g)
+            fin = _lib.ReduceProblem()
+            _lib.check(_lib.load().bg_mlp_chain_backward_split(ctypes.addressof(d), 1, fin, _lib.current_stream_ptr()), "bg_mlp_chain_backward_split")
+            if finishes is not None:
+                finishes.append(fin)
+            else:
+                from .utils import reduce_group
+                reduce_group([fin])
+        else:
+            self._backward_from(len(self.layers) - 2, self.hidden_grad if g is None else g, finishes)
         if timed:
             e1.record()
             # dX = G W of every hidden layer but the first (whose input gradient nobody needs): 2 B C_out C_in each
@@ -441,6 +491,8 @@ class MLPTrainer:
                 out.append(_lib.ParamMirror(off, rows, cols, 2, self._kin if i == 0 else cols, 0, _lib.ptr(self.cplanes[i])))
             if i == 0 and self.w0pad is not None and not split:
                 out.append(_lib.ParamMirror(off, rows, cols, 0, self.w0pad.shape[1], 0, _lib.ptr(self.w0pad)))
+            if i in (1, 2) and self.cplanes_t[i] is not None:  # the chained backward kernel's planes of W^T
+                out.append(_lib.ParamMirror(off, rows, cols, 3, rows, 0, _lib.ptr(self.cplanes_t[i])))
             if self.wt[i] is not None:
                 out.append(_lib.ParamMirror(off, rows, cols, 1, rows, 0, _lib.ptr(self.wt[i])))
         return out

@@ -10,13 +10,78 @@ Backend: "nccl" (= RCCL on ROCm) on GPUs; `BG_DIST_BACKEND=gloo` lets the CPU te
 exchanges on torch.distributed's own communicator (utils/rccl.py otherwise).  `BG_DIST_FORCE=1` takes the
 collective path with a world of ONE process too (process group initialised, every exchange issued): the one-GPU box's way to execute the RCCL
 calls of this file (tests/test_gpu_rccl.py).
+
+Enqueue-order contract (two communicators, two streams).  A communicator executes its collectives in the order they were ENQUEUED, per rank; ranks
+that enqueue the same communicator's collectives in different orders dead-lock or mix up buffers.  This build drives
+  * the OWN communicator (utils/rccl.py) from two streams of a rank: the side stream (tag "moments": the advantage moments, once per mini-epoch, inside
+    Runner._epoch_critic_forward_and_gae) and the main stream (tag "bucket": the grouped gradient / statistics / log-std exchange, once per mini-epoch,
+    inside Runner._epoch_gradients_and_step);
+  * the PROCESS GROUP's communicator for everything outside the mini-epochs (seed, initial weights, curriculum grid, barriers).
+The host enqueues strictly in program order -- moments(e), bucket(e), moments(e + 1), ... -- on every rank, whatever the streams do on the device, and
+nothing else touches the own communicator; the process group's collectives are issued only between iterations.  Any change that makes the ORDER OF
+HOST CALLS depend on rank-local data (an early exit, a rank-dependent branch around an exchange) breaks the contract.  `BG_DP_LOG_ORDER=1` records the
+sequence of (tag, stream) per rank (DataParallel.order_log); tests/test_host_logic.py compares it across the ranks of a two-process job.
 """
 import os
+import sys
+import threading
 
 import torch
 import torch.distributed as dist
 
 from .rccl import NCCL_AVG, NCCL_SUM
+
+
+def own_comm_bring_up(rank, world_size, device_index, ok_device, prepare, finish, timeout_s=None):
+    """The ranks' agreement on the own communicator, written so that NO failure on one rank can desynchronise the process group's collectives:
+
+        1. local, cannot block: `prepare(rank)` -> (handle, rank 0's unique id or None); an exception is kept, not raised;
+        2. ALWAYS, on every rank: broadcast_object_list of rank 0's id (None if its prepare failed), then a MIN all-reduce of "my prepare worked and I
+           hold an id" -- the same two collectives in the same order whatever happened in step 1;
+        3. only if every rank said yes: `finish(handle, id, rank, world_size, device_index)` = ncclCommInitRank, which blocks until all ranks are in
+           it.  A watchdog thread bounds the wait: after `timeout_s` (BG_RCCL_INIT_TIMEOUT, default 120) it prints the rank and ends the process with
+           exit code 3 (os._exit: no re-exec, no hang -- the launcher sees a failed rank);
+        4. ALWAYS when step 3 was entered: a second MIN all-reduce of "my communicator came up", so that one rank's quick failure inside step 3
+           turns into the fallback everywhere (the ranks still blocked in ncclCommInitRank are ended by their watchdogs).
+
+    Returns (communicator or None, the local exception or None).  None = every rank uses the process group's collectives."""
+    timeout_s = float(os.environ.get("BG_RCCL_INIT_TIMEOUT", "120")) if timeout_s is None else float(timeout_s)
+    handle, raw, err = None, None, None
+    try:
+        handle, raw = prepare(rank)
+    except Exception as ex:  # (library without the C entry points, ncclGetUniqueId failed, ...)
+        err = ex
+    box = [raw if rank == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    raw = box[0]
+    ok = torch.tensor([1 if (err is None and raw is not None) else 0], dtype=torch.int32, device=ok_device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        return None, err
+    comm = None
+    done = threading.Event()
+
+    def watchdog():
+        if not done.wait(timeout_s):
+            sys.stderr.write(f"[booster_gym_amd] rank {rank}: ncclCommInitRank has not returned after {timeout_s:.0f} s (BG_RCCL_INIT_TIMEOUT); "
+                             "ending this process with exit code 3\n")
+            sys.stderr.flush()
+            os._exit(3)
+
+    t = threading.Thread(target=watchdog, daemon=True)
+    t.start()
+    try:
+        comm = finish(handle, raw, rank, world_size, device_index)
+    except Exception as ex:
+        err = ex
+    done.set()
+    ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=ok_device)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if int(ok.item()) != 1:
+        if comm is not None:
+            comm.destroy()
+        return None, err
+    return comm, None
 
 
 class DataParallel:
@@ -61,33 +126,26 @@ class DataParallel:
         if self.active and self.backend == "nccl" and os.environ.get("BG_OWN_RCCL", "1") != "0":  # BG_OWN_RCCL=0: the process group's collectives
             from .rccl import RcclComm
 
-            def exchange_id(raw):
-                box = [raw]
-                dist.broadcast_object_list(box, src=0)
-                return box[0]
-
-            comm, err = None, None
-            try:
-                comm = RcclComm(self.rank, self.world_size, self.device_index, exchange_id)
-            except Exception as ex:  # (library without the C entry points, a failed bootstrap, ...)
-                err = ex
             # every rank takes the same path: the own communicator only if it came up EVERYWHERE, otherwise the process group's collectives (still RCCL,
             # on the group's stream) -- loudly
-            ok = torch.tensor([0 if comm is None else 1], dtype=torch.int32, device=f"cuda:{self.device_index}")
-            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
-            if int(ok.item()) == 1:
-                self.comm = comm
-            else:
+            self.comm, err = own_comm_bring_up(self.rank, self.world_size, self.device_index, f"cuda:{self.device_index}", RcclComm.prepare, RcclComm)
+            if self.comm is None:
                 import warnings
 
                 warnings.warn(f"own RCCL communicator unavailable on at least one rank ({err!r} here): the per-mini-epoch exchanges go through torch.distributed's "
                               "NCCL backend (+0.5 ms per iteration of stream hand-overs, DESIGN.md section 8)")
-                if comm is not None:
-                    comm.destroy()
+        # BG_DP_LOG_ORDER=1: every collective this object issues is noted as (tag, stream kind); tests compare the sequences of the ranks (see the
+        # enqueue-order contract in the module docstring)
+        self.order_log = [] if os.environ.get("BG_DP_LOG_ORDER", "0") == "1" else None
 
     @property
     def active(self):
         return self.world_size > 1 or self.force
+
+    def _note(self, tag):
+        if self.order_log is not None:
+            main = torch.cuda.is_available() and torch.cuda.current_stream() == torch.cuda.default_stream()
+            self.order_log.append((tag or "untagged", "main" if main or not torch.cuda.is_available() else "side"))
 
     def _timed(self, tag, t):
         ev = self.timed_events
@@ -101,6 +159,7 @@ class DataParallel:
     def sum_(self, t, tag=None):
         """In-place SUM all-reduce (no-op for a single process).  tag: which exchange this is, for bench.py's per-exchange timing."""
         if self.active:
+            self._note(tag)
             e1 = self._timed(tag, t)
             if self.comm is not None and t.is_cuda:
                 self.comm.all_reduce_(t, NCCL_SUM)
@@ -114,6 +173,7 @@ class DataParallel:
         """In-place mean over ranks: the flat gradient bucket.  With `timed_events` armed (bench.py) every call is bracketed by events on the
         current stream: the span is the collective plus the wait for the slowest rank to arrive."""
         if self.active:
+            self._note("bucket")
             e1 = self._timed("bucket", t)
             if self.comm is not None and t.is_cuda:  # RCCL averages inside the collective: no second launch on the critical path of every mini-epoch
                 self.comm.all_reduce_(t, NCCL_AVG)
@@ -129,6 +189,7 @@ class DataParallel:
         loss / KL sums (sum) and the log-std gradient (mean) -- exchanges (2) and (3) of SURVEY 8(e).  Timed as "bucket" when bench.py arms the events."""
         if not self.active:
             return
+        self._note("bucket")
         e1 = self._timed("bucket", bucket)
         if self.comm is not None and bucket.is_cuda:
             with self.comm.group() as c:

@@ -39,18 +39,29 @@ def _load():
 
 
 class RcclComm:
-    """One communicator over all ranks of the job.  `exchange_id(bytes_or_None) -> bytes` moves rank 0's unique id to every rank."""
+    """One communicator over all ranks of the job, brought up in two LOCAL steps with the ranks' agreement in between (utils/parallel.py:
+    own_comm_bring_up): `prepare` (load the library; rank 0 draws the unique id) cannot block and may raise; `RcclComm(...)` = ncclCommInitRank blocks
+    until every rank has called it and is therefore entered only when every rank has reported a successful `prepare` and holds the id."""
 
-    def __init__(self, rank, world_size, device_index, exchange_id):
-        self.lib = _load()
-        self.rank, self.world_size = rank, world_size
+    @staticmethod
+    def prepare(rank):
+        """-> (library handle, rank 0: the 128-byte unique id, other ranks: None).  Raises where the library or its entry points are missing."""
+        lib = _load()
+        if rank != 0:
+            return lib, None
         uid = _UniqueId()
-        if rank == 0:
-            self._ok(self.lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        raw = exchange_id(C.string_at(C.byref(uid), 128) if rank == 0 else None)  # (not bytes(uid.internal): a c_char array stops at the first NUL)
-        if len(raw) != 128:
+        rc = lib.ncclGetUniqueId(C.byref(uid))
+        if rc != 0:
+            raise RuntimeError(f"ncclGetUniqueId failed ({rc}): {lib.ncclGetErrorString(rc).decode()}")
+        return lib, C.string_at(C.byref(uid), 128)  # (not bytes(uid.internal): a c_char array stops at the first NUL)
+
+    def __init__(self, lib, raw_id, rank, world_size, device_index):
+        self.lib = lib
+        self.rank, self.world_size = rank, world_size
+        if raw_id is None or len(raw_id) != 128:
             raise RuntimeError("RCCL unique id: expected 128 bytes")
-        C.memmove(C.byref(uid), raw, 128)
+        uid = _UniqueId()
+        C.memmove(C.byref(uid), raw_id, 128)
         torch.cuda.set_device(device_index)
         self.comm = C.c_void_p()
         self._ok(self.lib.ncclCommInitRank(C.byref(self.comm), world_size, uid, rank), "ncclCommInitRank")

@@ -249,6 +249,7 @@ class Runner:
         # the two networks' chained forward launches of a mini-epoch share the chip by CUs (each a persistent grid over its slabs, _plan_chain_split);
         # False: one workgroup per slab, dispatched as CUs fall free
         self._split_chain_cus = os.environ.get("BG_SPLIT_CHAIN_CUS", "1") == "1"
+        self._split_bwd_chain_cus = os.environ.get("BG_SPLIT_BWD_CHAIN_CUS", "1") == "1"  # ... and the two chained backward launches
         self._gae_scratch = torch.zeros(3 * ((self.env.num_envs + 15) // 16) + 1, dtype=torch.float64, device=self.device)
 
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value (utils/model.py); a model of
@@ -566,7 +567,7 @@ class Runner:
         # a layer that fell to the library path wrote its bias gradient outside both lists and the norm would miss it)
         one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and len(fins) + 2 <= 8
                     and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr))
-                    and len(fins) == sum(len(tr.layers) - 2 for tr in (self._critic_tr, self._actor_tr)))
+                    and len(fins) == sum(1 if tr._chain_split_bwd() else len(tr.layers) - 2 for tr in (self._critic_tr, self._actor_tr)))
         main.wait_stream(side)
         if one_tail:
             pass  # the deferred reductions run inside bg_update_tail
@@ -636,6 +637,11 @@ class Runner:
             return
         cost = lambda tr: sum(l.weight.shape[0] * (tr._kin if i == 0 else l.weight.shape[1]) for i, l in enumerate(tr.layers[:3]))
         ct.chain_workgroups, at.chain_workgroups = plan_chain_split(sc, sa, cost(ct), cost(at), cus)
+        # the chained backward launches likewise (both networks differentiate the same rows_a rows; slab cost ~ flops of the two backward layers)
+        ct.chain_bwd_workgroups = at.chain_bwd_workgroups = 0
+        if self._split_bwd_chain_cus and ct._chain_split_bwd() and at._chain_split_bwd():
+            bcost = lambda tr: sum(l.weight.shape[0] * l.weight.shape[1] for l in tr.layers[1:3])
+            ct.chain_bwd_workgroups, at.chain_bwd_workgroups = plan_chain_split(sa, sa, bcost(ct), bcost(at), cus)
 
     def _exchange_sums(self):
         """Exchange (3), on the current (side) stream: the loss / KL sums and the log-std gradient of all ranks in one float64 all-reduce; the gradient

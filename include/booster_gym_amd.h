@@ -433,6 +433,25 @@ typedef struct {
     uint64_t stat_base; int32_t n_stat, n_ls; uint32_t stat_skip; double entropy_coef; double* grad_logstd; double* stats;
 } bg_reduce_problem;
 int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stream); /* count <= 8 */
+/* The backward-data chain of one network in ONE launch on the bf16 matrix pipe with fp32 semantics (bg_mlp_chain_split_bwd.hip; the dX part of
+ * `loss.backward()`, utils/runner.py:163, through utils/model.py:9-26's hidden layers):  G2 [M][N2] = (G3 [M][N3] . W3 [N3][N2]) * elu'(A2),
+ * G1 [M][N1] = (G2 . W2 [N2][N1]) * elu'(A1), and the column sums of G2 / G1 (the bias gradients of layers 2 / 1: bg_mlp_layer_backward twice).
+ * PT3 / PT2: the planes of W3^T / W2^T as bg_mlp_split_weights(transpose = 1) writes them ([N2][N3 / 32][3][32], [N1][N2 / 32][3][32]); A2 / A1: the
+ * layers' stored outputs.  G2 / G1 must hold ceil(M / 128) * 128 rows (rows >= M are written with zeros).  Every workgroup leaves one record of
+ * column sums in colsum_partial ([workgroups or slabs][N2 + N1] floats); `finishes[k]` receives the descriptor of the fixed-order reduction that
+ * produces bias_grad2 [N2] and bias_grad1 [N1] when handed to bg_reduce_group / bg_update_tail.  Widths (N1, N2, N3): (256, 128, 128), (256, 256, 128). */
+typedef struct bg_mlp_chain_split_bwd {
+    int32_t M, N1, N2, N3;
+    int32_t workgroups, pad;
+    const float* G3;
+    const uint16_t *PT3, *PT2;
+    const float *A2, *A1;
+    float *G2, *G1;
+    float* colsum_partial;
+    float *bias_grad2, *bias_grad1;
+} bg_mlp_chain_split_bwd;
+int bg_mlp_chain_backward_split(const bg_mlp_chain_split_bwd* nets, int32_t count, bg_reduce_problem* finishes, void* stream);
+
 /* The tail of a mini-epoch behind bg_mlp_weight_grad_group_partial (runner.py:162-180: the last sums of loss.backward(), clip_grad_norm_,
  * optimizer.step(), the KL rule) as two launches: (1) the weight gradients' fixed-order finish over their slices (wgrad: the problems handed to the
  * _partial launch; 0: none) and the deferred reductions (reduce: as bg_reduce_group; 0: none), every block also leaving the sum of the squares of the

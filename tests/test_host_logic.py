@@ -633,6 +633,113 @@ def test_curriculum_grid_sync_after_resume_two_ranks():
         assert seed == 1234  # rank 0's draw everywhere
 
 
+def _bringup_worker(rank, world, port, q, mode):
+    os.environ.update(WORLD_SIZE=str(world), RANK=str(rank), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), BG_DIST_BACKEND="gloo",
+                      BG_DP_LOG_ORDER="1")
+    import time
+
+    import torch
+    import torch.distributed as dist
+
+    from booster_gym_amd.utils.parallel import DataParallel, own_comm_bring_up
+
+    dp = DataParallel()  # gloo: the process group only
+    calls = []
+
+    class FakeComm:
+        def destroy(self):
+            calls.append("destroy")
+
+    def prepare(r):
+        calls.append("prepare")
+        if mode == "rank1_prepare_raises" and r == 1:
+            raise OSError("librccl.so: cannot open shared object file (injected)")
+        if mode == "rank0_id_fails" and r == 0:
+            raise RuntimeError("ncclGetUniqueId failed (injected)")
+        return "lib", (b"u" * 128 if r == 0 else None)
+
+    def finish(handle, raw, r, w, dev):
+        calls.append("finish")
+        assert handle == "lib" and raw == b"u" * 128
+        if mode == "rank1_init_raises" and r == 1:
+            raise RuntimeError("ncclCommInitRank failed (injected)")
+        return FakeComm()
+
+    t0 = time.time()
+    comm, err = own_comm_bring_up(rank, world, 0, "cpu", prepare, finish, timeout_s=30)
+    dt = time.time() - t0
+    # the process group is still in step: a collective issued by both ranks right after gives the right answer
+    x = torch.tensor([float(rank + 1)])
+    dist.all_reduce(x)
+    # the order of the exchanges of two "mini-epochs", as the runner issues them
+    for _ in range(2):
+        dp.sum_(torch.zeros(3, dtype=torch.float64), tag="moments")
+        dp.exchange_tail_(torch.zeros(8), torch.zeros(5, dtype=torch.float64), torch.zeros(12, dtype=torch.float64))
+    q.put((rank, comm is not None, repr(err), calls, float(x.item()), dt, dp.order_log))
+    dp.shutdown()
+
+
+@pytest.mark.parametrize("mode", ["all_good", "rank1_prepare_raises", "rank0_id_fails", "rank1_init_raises"])
+def test_own_communicator_bring_up_cannot_desynchronise_the_ranks(mode):
+    """VERDICT r5 item 2 / ADVICE r5: whatever fails on one rank while the own RCCL communicator is brought up (the library missing, no unique id,
+    ncclCommInitRank raising), BOTH ranks end on the same path within the timeout -- the fallback, or the communicator -- the process group's
+    collectives still match afterwards, ncclCommInitRank is entered only when every rank is ready, and the ranks enqueue their exchanges in the same
+    (tag, stream) order (the contract in utils/parallel.py)."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bringup_worker, args=(r, 2, port, q, mode)) for r in range(2)]
+    for p in procs:
+        p.start()
+    try:
+        res = sorted(q.get(timeout=120) for _ in procs)
+        for p in procs:
+            p.join(timeout=60)
+            assert p.exitcode == 0
+    finally:
+        for p in procs:
+            if p.is_alive():
+                p.terminate()
+    (r0, has0, err0, calls0, x0, dt0, log0), (r1, has1, err1, calls1, x1, dt1, log1) = res
+    assert has0 == has1 == (mode == "all_good")
+    assert x0 == x1 == 3.0 and dt0 < 30 and dt1 < 30
+    if mode in ("rank1_prepare_raises", "rank0_id_fails"):
+        assert "finish" not in calls0 and "finish" not in calls1  # nobody enters ncclCommInitRank alone
+        assert "injected" in (err1 if mode == "rank1_prepare_raises" else err0)
+    if mode == "rank1_init_raises":
+        assert "finish" in calls0 and "destroy" in calls0 and "injected" in err1  # rank 0's communicator came up and is given back
+    assert log0 == log1 and [t for t, _ in log0] == ["moments", "bucket", "moments", "bucket"]
+
+
+def test_own_communicator_bring_up_is_bounded_by_a_watchdog():
+    """ncclCommInitRank blocks until every rank is inside it; a rank that never arrives must not hang the others for ever: the watchdog ends the process
+    with exit code 3 after BG_RCCL_INIT_TIMEOUT seconds (never a re-exec)."""
+    import subprocess
+    import sys
+
+    code = (
+        "import os, time, torch, torch.distributed as dist\n"
+        "os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=os.environ['PORT'])\n"
+        "dist.init_process_group('gloo', rank=0, world_size=1)\n"
+        "from booster_gym_amd.utils.parallel import own_comm_bring_up\n"
+        "own_comm_bring_up(0, 1, 0, 'cpu', lambda r: ('lib', b'u' * 128), lambda *a: time.sleep(60), timeout_s=2)\n"
+        "print('returned')\n")
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    p = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PORT=str(port), PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__)))),
+                       capture_output=True, text=True, timeout=120)
+    assert p.returncode == 3 and "returned" not in p.stdout and "ncclCommInitRank has not returned" in p.stderr, (p.returncode, p.stdout, p.stderr[-400:])
+
+
 def _synthetic_urdf(flat_model, path):
     """A URDF of the T1 topology written from the flat model, with the things the loader must fold: the trunk split into a root link plus two
     links behind FIXED joints (one of them rotated, one a chain of two), an inertial frame given with rpy, and a fixed sensor link on a shank."""
