@@ -503,13 +503,27 @@ __global__ __launch_bounds__(256) void critic_values_gae_kernel(int T, int N, co
     // has arrived; the ticket is taken after that.  (A release fence -- __threadfence -- writes back the whole L2 of the XCD instead, every dirty
     // line of the forward chain that runs beside this launch included, once per workgroup: this launch sits between the critic's forward pass and
     // the actor's loss.)  The reader takes agent-scope loads, which do not hit a stale line of its own L2.
+    // That argument rests on two properties of gfx942 / gfx950 that the HIP memory model does not promise (the return of an sc1 store into vmcnt =
+    // visible at agent scope; one vmcnt counter for loads and stores), so it is compiled for those targets only: anything else gets the portable
+    // release (fence + relaxed ticket), slower but correct by the model.  DESIGN.md section 5 records the assumption.
+#if defined(__gfx942__) || defined(__gfx950__)
     if (threadIdx.x < 3) {
         __hip_atomic_store(&partial[(size_t)blockIdx.x * 3 + threadIdx.x], sd[threadIdx.x * 4] + sd[threadIdx.x * 4 + 1] + sd[threadIdx.x * 4 + 2] + sd[threadIdx.x * 4 + 3],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0): threads 0..2 and the ticket's thread 0 are one wave
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // threads 0..2 and the ticket's thread 0 are one wave
     }
     __syncthreads();
     if (threadIdx.x == 0) s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+#else
+    if (threadIdx.x < 3)
+        __hip_atomic_store(&partial[(size_t)blockIdx.x * 3 + threadIdx.x], sd[threadIdx.x * 4] + sd[threadIdx.x * 4 + 1] + sd[threadIdx.x * 4 + 2] + sd[threadIdx.x * 4 + 3],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __threadfence();
+        s_last = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
+    }
+#endif
     __syncthreads();
     if (s_last) {  // every workgroup's triple has arrived: fixed-order total
         for (int k = 0; k < 3; k++) {

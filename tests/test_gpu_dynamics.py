@@ -83,7 +83,7 @@ def test_forward_dynamics_matches_oracle(flat_model, terrain, contact, tol, n, p
     f = lambda a: torch.tensor(a, dtype=torch.float32, device=dev)
     qacc = env.forward_dynamics(f(root), f(q), f(qd), f(tau), f(w), packed=packed).cpu().numpy().astype(np.float64)
     cf = env.get_field("feet_contact_forces").cpu().numpy().reshape(n, 2, 3)
-    worst, ncontact, nexcused = 0.0, 0, 0
+    worst, ncontact, nexcused, excused = 0.0, 0, 0, []
     for e in range(n):
         r32 = root[e].astype(np.float32).astype(np.float64)  # oracle sees the same rounded inputs
         args = (r32, q[e].astype(np.float32), qd[e].astype(np.float32), tau[e].astype(np.float32))
@@ -100,6 +100,8 @@ def test_forward_dynamics_matches_oracle(flat_model, terrain, contact, tol, n, p
             twin_err = np.abs(qt - qa).max() / max(1.0, np.abs(qa).max())
             assert raw <= twin_err, f"env {e}: relative qacc error {raw:.2e} beyond both the tolerance and the oracle's fp32 twin ({twin_err:.2e})"
             nexcused += 1
+            excused.append(e)
+            assert raw <= 3e-3, f"env {e}: relative qacc error {raw:.2e} above the absolute ceiling of an excused state"
             continue
         worst = max(worst, err)
         if np.abs(cfr).max() > 0:
@@ -107,7 +109,9 @@ def test_forward_dynamics_matches_oracle(flat_model, terrain, contact, tol, n, p
             assert np.abs(cf[e] - cfr[[6, 12]]).max() <= 2e-3 * max(1.0, np.abs(cfr).max())
     assert np.isfinite(qacc).all()
     assert worst < tol, f"worst relative qacc error {worst}"
-    assert nexcused <= max(1, n // 200), nexcused  # (sparse_crossed: env 13, a 3.4 kN shank contact, twin 1.2e-3; none in the other cases)
+    # the excused set is PINNED: one env of one case -- sparse_crossed: env 13, a 3.4 kN shank contact, twin 1.2e-3 -- and none anywhere else,
+    # so a regression confined to stiff-contact states cannot hide behind the twin's own ill-conditioning
+    assert excused == ([13] if contact == "sparse_crossed" and excused else []), (contact, nexcused, excused)
     if contact == "sparse_crossed":
         assert ncontact >= 8  # (32 of the 288 envs carry a crossed-leg state; 13 of them touch with this seed)
     elif contact:

@@ -740,6 +740,23 @@ def test_own_communicator_bring_up_is_bounded_by_a_watchdog():
     assert p.returncode == 3 and "returned" not in p.stdout and "ncclCommInitRank has not returned" in p.stderr, (p.returncode, p.stdout, p.stderr[-400:])
 
 
+def test_inline_asm_mfmas_of_the_backward_chain_keep_their_wait_states():
+    """bg_mlp_chain_split_bwd.hip issues its MFMAs through inline asm (layer B's operand planes are read from accumulator registers, which the compiler's
+    own MFMA will not do); the compiler does not know that those statements are MFMAs and puts operand moves directly in front of them without the
+    two wait states a vector write needs before an MFMA reads the register.  The kernel pins the operand planes to their register class where they are
+    assigned, so that no move is left to place; this checks the SHIPPED code object's assembly statement by statement (tools/isa_hazard_scan.py), and
+    that the check itself sees the hazards when the pinning is compiled out."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_hazard_scan
+
+    rep = isa_hazard_scan.scan()
+    assert len(rep) == 2, list(rep)
+    for name, (n, hazards, worst) in rep.items():
+        assert n in (864, 2592) and not hazards and (worst is None or worst >= 2), (name, n, hazards[:3], worst)
+    bad = isa_hazard_scan.scan(["-DBG_ABL_NOPIN"])
+    assert sum(len(h) for _, h, _ in bad.values()) > 0
+
+
 def _synthetic_urdf(flat_model, path):
     """A URDF of the T1 topology written from the flat model, with the things the loader must fold: the trunk split into a root link plus two
     links behind FIXED joints (one of them rotated, one a chain of two), an inertial frame given with rpy, and a fixed sensor link on a shank."""

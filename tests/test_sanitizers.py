@@ -12,13 +12,25 @@ import os
 import subprocess
 import sys
 
+import pytest
+
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 
 
 def test_native_host_code_is_clean_under_asan_and_ubsan():
     asan = subprocess.check_output(["gcc", "-print-file-name=libasan.so"], text=True).strip()
-    assert os.path.isabs(asan) and os.path.exists(asan), "libasan.so not found next to gcc"
+
+    def is_elf(path):  # (on RHEL-like distributions libasan.so is a linker script that LD_PRELOAD cannot load; some hosts have none at all)
+        try:
+            with open(path, "rb") as f:
+                return f.read(4) == b"\x7fELF"
+        except OSError:
+            return False
+
+    ubsan = subprocess.check_output(["gcc", "-print-file-name=libubsan.so"], text=True).strip()
+    if not (os.path.isabs(asan) and is_elf(os.path.realpath(asan)) and os.path.isabs(ubsan) and is_elf(os.path.realpath(ubsan))):
+        pytest.skip("no loadable libasan.so / libubsan.so next to gcc on this host")
     # libstdc++ beside it: the runtime resolves __cxa_throw when it starts, and python itself does not link the C++ library (the loader throws inside)
     cxx = subprocess.check_output(["gcc", "-print-file-name=libstdc++.so.6"], text=True).strip()
     env = dict(os.environ, BG_SANITIZE="1", LD_PRELOAD=asan + " " + cxx, ASAN_OPTIONS="detect_leaks=0:halt_on_error=1:abort_on_error=0",
@@ -33,4 +45,7 @@ def test_native_host_code_is_clean_under_asan_and_ubsan():
     assert "AddressSanitizer" not in tail and "runtime error" not in tail, tail
     # (every selected test ran: none of them was silently deselected by a rename)
     last = [l for l in p.stdout.splitlines() if " passed" in l][-1]
-    assert int(last.split(" passed")[0].split()[-1]) >= 7, last
+    # exactly the eight selected tests where the reference tree is present (test_c_urdf_loader_on_the_reference_asset skips without it): a rename that
+    # silently deselects one of them fails here
+    want = 8 if os.path.isdir("/root/reference") else 7
+    assert int(last.split(" passed")[0].split()[-1]) == want, (want, last)

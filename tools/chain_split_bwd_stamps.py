@@ -33,6 +33,8 @@ def report(name, tag):
     ghz = np.median((end - t[:, :, 0]) / np.maximum(1, t[:, :, 63] - t[:, :, 62])) * 0.1
     print(f"{name} [{tag}]: kernel {tot:.0f} cycles = {tot / ghz / 1e3:.1f} us at {ghz:.2f} GHz for {per_wg} slabs = {tot / per_wg:.0f} cycles per slab; MFMA {sum(mf)} per slab")
     print("   last slab, chunk: barrier wait / loads' wait / body (MFMA)   " + "  ".join(f"{w:.0f}/{u:.0f}/{b:.0f}({f})" for w, u, b, f in zip(wait, touch, body, mf)), flush=True)
+    ka, kb = np.diff(t[:, :, 40:48], axis=2), np.diff(t[:, :, 48:62], axis=2)
+    print("   layer A chunk 1, cycles per k-step (288 MFMA): " + " ".join(f"{v:.0f}" for v in med(ka)) + ";  layer B chunk 2: " + " ".join(f"{v:.0f}" for v in med(kb)))
     print(f"   sums: barrier wait {wait.sum():.0f}  loads' wait {touch.sum():.0f}  body {body.sum():.0f} (the first body holds the slab's last k-step and the last the kernel's tail)", flush=True)
 
 
