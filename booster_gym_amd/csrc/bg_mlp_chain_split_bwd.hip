@@ -11,8 +11,13 @@
 //     activations a tile's epilogue needs are loaded during the tile's own chunk; the next slab's input rows are loaded and split during layer B.
 //   * One wave per SIMD, one workgroup per CU, persistent; weight planes through three 48 KB LDS buffers by global_load_lds_dwordx4 two chunks ahead,
 //     one barrier per chunk (in front of the last k-step of the chunk before), copies / loads / stores counted by hand.
-//   * Column sums: across the 32 samples of a wave by DPP, across the slabs of a wave in LDS (ds_add_f32 by one lane: a fixed order), across the four
-//     waves at the end of the kernel; one record per workgroup, summed in a fixed order by the reduction the descriptor describes (deterministic).
+//   * The CU's vector-memory pipeline is what this kernel runs against (tools/chain_split_bwd_stamps.py: without its loads and stores a slab takes
+//     1.16 x its MFMA time, with them 2.3 x): a 16-byte-per-lane access in the accumulator layout touches 32 lines a quarter each.  So the activations
+//     under a tile come in as FOUR coalesced LDS-DMA pieces (8 rows x 128 bytes each, full lines, no register stop, swizzled at the source) into a
+//     4 KB corner of LDS per wave and are read from there in the accumulator layout a chunk later; the input rows of the next slab are counted asm
+//     loads; nothing the compiler would wait for by draining the copies is left in the stream.
+//   * Column sums: across the 32 samples of a wave by a transposing DPP butterfly (38 instructions per tile), one record per (slab, wave) in global
+//     memory, summed in a fixed order by the reduction the descriptor describes (deterministic).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string.h>
@@ -119,9 +124,9 @@ __device__ __forceinline__ void mfma9_asm(f32x16& acc, const u32x4 (&w)[3], cons
 }
 
 // All slabs first, first + stride, ... < nslabs of one network.  Stream: chunk c < TA: tile c of layer A (G3 -> G2), TA <= c < C: tile c - TA of
-// layer B (G2 -> G1).  sC: [4 waves][N2 + N1] column sums, zeroed by the caller.
+// layer B (G2 -> G1).  sT: 4 KB of LDS per wave.
 template <int N1, int N2, int N3>
-__device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int first, int stride, int nslabs, unsigned* sW, float* sC) {
+__device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int first, int stride, int nslabs, unsigned* sW, float* sT) {
     constexpr int KA = N3, KB = N2, TA = N2 / 32, TB = N1 / 32, C = TA + TB;
     constexpr int JA = KA / 16, JB = KB / 16, CHA = KA / 32, CHB = KB / 32;
     static_assert(N3 == 128 && N1 == 256 && (N2 == 128 || N2 == 256), "the reference's widths");
@@ -147,9 +152,22 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         static constexpr int xfirst() { return C - 1 - JA; }
         static constexpr int xloads_in(int cc) { return (cc >= xfirst() && cc < xfirst() + JA) ? 2 : 0; }
         static constexpr int ops_in(int cc) { return ndma(cc + 2) + 4 + 4 + xloads_in(cc); }
-        // the barrier that publishes chunk cc stands in front of the LAST k-step of chunk cc - 1: everything chunk cc - 1 issues but what that k-step
-        // issues (a copy at most: the stores and loads sit in earlier k-steps; 3 for safety) is behind the copies of chunk cc (issued during chunk cc - 2)
-        static constexpr int behind(int cc) { const int n = ops_in((cc + C - 1) % C) - 3; return n > 0 ? n : 0; }
+        // Where a chunk's vector-memory operations go -- at most two or three per k-step, none in the last (the CU's four waves run in step: eight in
+        // one k-step fill the memory pipeline's queue and all four stall at their next one): the copies of chunk cc + 2, pp() per k-step from the
+        // first; two pieces of the tile's activations in each of k-steps 0 and 1 (under load a piece takes ~2,000 cycles to land and to retire); the two loads of the next slab's input in k-step 0; the four stores of
+        // the tile before in k-steps ksteps / 2 - 1 .. ksteps / 2 + 2 (group k of its elements is finished by then).
+        static constexpr int store_first(int cc) { return ksteps(cc) / 2 - 1; }
+        // operations of chunk cc issued BEHIND the last one the next chunk's top must wait for (the activations' pieces of k-step 1): the copies of
+        // k-steps >= 2 and the stores
+        static constexpr int late_ops(int cc) {
+            int n = 4;   // (the stores: k-steps >= 3)
+            for (int J = 2; J < ksteps(cc) - 1; J++)
+                for (int k = 0; k < pp(cc); k++) n += (J * pp(cc) + k < ndma(cc + 2)) ? 1 : 0;
+            return n;
+        }
+        // the barrier that publishes chunk cc stands in front of the LAST k-step of chunk cc - 1, which issues nothing: exactly late_ops(cc - 1)
+        // operations are younger than the last piece of the activations (and than the copies of chunk cc, issued during chunk cc - 2); one for safety
+        static constexpr int behind(int cc) { const int n = late_ops((cc + C - 1) % C) - 1; return n > 0 ? n : 0; }
     };
     static_assert(S::xfirst() >= TA - 1 && JA == 8, "the next slab's planes are written when layer A of this slab is over");
     unsigned bb[3] = {0u, (unsigned)BUFDW * 4u, 2u * (unsigned)BUFDW * 4u};
@@ -164,16 +182,20 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
     };
     const int sx = (i >> 2) & 3;              // this lane's slot swizzle
     const unsigned* swl = sW + i * SP_ROW;    // + buffer, + k-chunk * 32 rows, + slot
-    float* sCw = sC + wave * (N2 + N1);       // this wave's column sums: G2's [N2], then G1's [N1]
+    // this wave's 4 KB of LDS for the activations under a tile: [32 rows][8 pieces of 16 bytes], piece P of row r at slot P ^ (r & 7)
+    const unsigned sTw = (unsigned)(uintptr_t)sT + (unsigned)wave * 4096u;
+    const float* sTr = sT + wave * 1024 + i * 32;   // this lane's row
+    // lane l of an activation piece: row l >> 3 of the piece's eight, source piece (l & 7) ^ (row & 7): byte offset in rows of ld floats
+    const unsigned aofsA = (unsigned)((lane >> 3) * N2 * 4 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
+    const unsigned aofsB = (unsigned)((lane >> 3) * N1 * 4 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
     // the feature of a tile whose column sum the butterfly leaves in this lane: register R = 8 b4 + 4 b3 + 2 b2 + b1 of the lane number's bits
     const int csR = ((i >> 4) & 1) * 8 + ((i >> 3) & 1) * 4 + ((i >> 2) & 1) * 2 + ((i >> 1) & 1), csofs = (csR & 3) + 8 * (csR >> 2) + 4 * h;
     const float sgn = 1.0f;
     u32x4 gp[JA][3];   // planes of the slab's input rows (G3), k-step J: values 8 J .. 8 J + 7 of the lane
     u32x4 hp[JB][3];   // planes of G2, filled as layer A's tiles are finished
     f32x16 acc[2];     // the tile in work and the tile being finished
-    f32x4 aux[2][4];   // the activations (layer outputs) under the tile in work (loaded at the top of its chunk: a whole chunk of lead -- half a chunk leaves
-                       // ~1,600 cycles of HBM latency exposed per chunk under load) and under the tile being finished (used)
-    f32x4 xin[2] = {}; // two 16-byte pieces of the next slab's input row on their way into gp
+    f32x4 aux[4];      // the activations (layer outputs) under the tile being finished, read from this wave's LDS corner at the top of the chunk
+    f32x4 xin[2][2] = {};  // two 16-byte pieces of the next slab's input row on their way into gp: loaded in one chunk, split in the next
     Frag fr[2];
     unsigned pn[3][4] = {}, pn2[3][4] = {};
 #ifdef BG_CHAIN_PROBE_STAMPS
@@ -181,18 +203,25 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
 #endif
     // input rows: 16-byte piece j of the lane = floats 8 j + 4 h .. + 3; rows >= M are ZERO (then so is everything computed from them: G2, G1 rows and
     // their share of the column sums)
-    // (the select for rows >= M is applied where the values are USED, in the split: a select directly behind the load makes the compiler wait for the
-    // load -- and with it for every copy in flight -- in the middle of the chunk)
+    // Prologue loads of the first slab's input rows (plain loads: the compiler's waits are fine there).  (The select for rows >= M is applied where
+    // the values are USED, in the split: a select directly behind a load makes the compiler wait for the load in place.)
     auto loadx = [&](int r, auto j_, f32x4& dst) {
         constexpr int j = decltype(j_)::value;
         dst = *reinterpret_cast<const f32x4*>(a.G3 + (size_t)(r < a.M ? r : a.M - 1) * N3 + 4 * h + 8 * j);
     };
-    auto load_aux = [&](const float* __restrict__ A, int ld, int r, int tile, auto g_, f32x4& dst) {
-        constexpr int g = decltype(g_)::value;
-#ifdef BG_ABL_NOAUX
-        return;
+    // ... inside the stream: a counted asm load (the compiler does not know it, does not wait for it -- and does not drain the copies for it)
+    auto loadx_asm = [&](const float* rowptr, auto j_, f32x4& dst) {
+        constexpr int j = decltype(j_)::value;
+        asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(dst) : "v"(rowptr), "i"(32 * j) : "memory");
+    };
+    // the activations under tile `tile` of rows row0 .. row0 + 31 (this wave's) -> this wave's LDS corner: four pieces of eight full 128-byte rows
+    auto aux_dma = [&](const float* __restrict__ A, int ld, unsigned lofs, int row0, int tile, auto k_) {
+        constexpr int k = decltype(k_)::value;
+#ifndef BG_ABL_NOAUX
+        const float* base = A + (size_t)(row0 + 8 * k) * ld + 32 * tile;
+        const unsigned lds = sTw + 1024u * k;
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(lofs), "s"(base), "s"(lds) : "memory");
 #endif
-        dst = *reinterpret_cast<const f32x4*>(A + (size_t)(r < a.M ? r : a.M - 1) * ld + 32 * tile + 8 * g + 4 * h);
     };
     auto store4 = [&](const f32x16& A, float* __restrict__ Y, int ld, int r, int tile, auto g_) {
 #ifndef BG_ABL_NOSTORE
@@ -211,15 +240,11 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         BG_STAMP(2 + 3 * (cc % C));
         BG_PIN();
         read_w(fr[0], swl + bb[cc % 3] / 4 + ((0 + h) ^ sx) * 4);
-        // The loads of the chunk that ends here (the activations under its tile, two pieces of the next slab's input) are used during the next chunk.
-        // The compiler places its own wait for them at their first use, counting only the operations it knows of -- put that wait HERE, where the
-        // copies in flight are old, not behind the next chunk's first copies, which it would drain.
-#ifndef BG_ABL_NOTOUCH
-        {
-            f32x4 (&t)[4] = aux[(cc + 1) & 1];
-            asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]), "+v"(xin[0]), "+v"(xin[1]));
-        }
-#endif
+        // the activations under the tile that chunk cc finishes (copied during chunk cc - 1): piece 2 g + h of this lane's row
+#pragma unroll
+        for (int g = 0; g < 4; g++) aux[g] = *reinterpret_cast<const f32x4*>(sTr + (((2 * g + h) ^ (i & 7)) << 2));
+        // the asm loads of chunk cc - 1 have landed (counted wait above): from here on their registers hold the values
+        asm volatile("" : "+v"(xin[(cc + 1) & 1][0]), "+v"(xin[(cc + 1) & 1][1]));
         BG_STAMP(3 + 3 * (cc % C));
         BG_PIN();
     };
@@ -252,10 +277,14 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
     wait_vm<0>();  // (once per workgroup)
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[1][r] = 0.f;   // "the tile before" of the first chunk: nothing (zeros: stored to rows that are rewritten, added as zeros)
-#pragma unroll
-    for (int g = 0; g < 4; g++) aux[1][g] = f32x4{1.f, 1.f, 1.f, 1.f};
+    // (the first chunk's "tile before" reads this wave's LDS corner before anything was copied there: zeros x whatever is finite -- make it so)
+    for (int j = lane; j < 1024; j += 64) sT[wave * 1024 + j] = 1.0f;
+    __builtin_amdgcn_s_waitcnt(0xC07F);
     chunk_top(IC<0>{});
     int rowp = row;   // the slab whose last tile is finished under this slab's first chunk (first slab: itself -- zeros, rewritten later)
+    const float* xnext = a.G3;   // this lane's part of the next slab's input row
+    int row0w = slab * 128 + wave * 32;   // first row of this wave in the slab in work (wave-uniform: the base of a copy is a scalar)
+    int slabp = slab;
 
     // One chunk = one tile: its MFMAs (acc[c & 1]), and in their gaps the tile BEFORE (acc[(c - 1) & 1], aux[(c - 1) & 1]): its 16 elements x
     // elu'(activation) during the FIRST half of the chunk's k-steps (layer B's first tile needs all of G2 in its last k-steps), stored and, for G2, split
@@ -268,16 +297,16 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         constexpr int T = A ? c : c - TA, Tp = pA ? cp : cp - TA;       // tile numbers inside their layers
         constexpr int JX = A ? JA : JB, PP = S::pp(c);
         constexpr int JE = JX / 2, EPK = 16 / JE;                       // k-steps that carry the elements; elements per k-step (2 or 4)
-        static_assert((C & 1) == 0 && (JX & 1) == 0 && (EPK == 2 || EPK == 4), "two accumulators / fragment buffers in turn");
+        static_assert((C & 1) == 0 && (JX & 1) == 0 && (EPK == 2 || EPK == 4) && S::store_first(c) + 4 <= JX - 1, "two accumulators / fragment buffers in turn");
         const unsigned* sw = swl + bb[c % 3] / 4;
         f32x16& cur = acc[c & 1];
         f32x16& prv = acc[(c + 1) & 1];
-        f32x4 (&xa)[4] = aux[c & 1];        // loaded during this chunk
-        f32x4 (&pa)[4] = aux[(c + 1) & 1];  // used during this chunk
+        f32x4 (&pa)[4] = aux;   // the activations under the tile being finished (read from LDS at the top of this chunk)
         const int prow = c == 0 ? rowp : row;                      // rows of the tile being finished
+        const int prow0w = (c == 0 ? slabp : slab) * 128 + wave * 32;   // ... its first row in this wave (wave-uniform; record (slab, wave) = row / 32)
         float* __restrict__ Yp = pA ? a.G2 : a.G1;
         constexpr int ldp = pA ? N2 : N1;
-        float* sCp = sCw + (pA ? 0 : N2) + 32 * Tp;
+        float* __restrict__ csp = a.colsum_partial + ((size_t)(prow0w >> 5)) * (N2 + N1) + (pA ? 0 : N2) + 32 * Tp + csofs;   // record (slab, wave)
         Bfly bf;
         static_for<JX>([&](auto J_) {
             constexpr int J = decltype(J_)::value;
@@ -292,18 +321,19 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
                 if constexpr (g == 4 && PP >= 2) dma(IC<c + AHEAD>{}, IC<J * PP + 1>{});
                 if constexpr (g == 7 && PP >= 3) dma(IC<c + AHEAD>{}, IC<J * PP + 2>{});
                 static_assert(PP <= 3, "");
-                // the activations under this tile (for its epilogue during the next chunk): four 16-byte loads in the chunk's first k-step
-                if constexpr (J == 0 && g >= 5) load_aux(A ? a.A2 : a.A1, A ? N2 : N1, row, T, IC<g - 5>{}, xa[g - 5]);
+                // the activations under this tile (for its epilogue during the next chunk): four coalesced copies into this wave's LDS corner, one in each
+                // of the chunk's first two k-steps, two each (behind the reads of the corner at the chunk's top, whose values MFMA 1's element has already used)
+                if constexpr (J < 2 && (g == 6 || g == 8)) aux_dma(A ? a.A2 : a.A1, A ? N2 : N1, A ? aofsA : aofsB, row0w, T, IC<2 * J + (g == 8)>{});
                 // the next slab's input rows: two 16-byte loads per chunk, split into planes during the chunk after
-                if constexpr (c >= S::xfirst() && c < S::xfirst() + JA && g == 8) {   // (each behind the last use of its register by the split below)
-                    if constexpr (J == 1) loadx(rown, IC<2 * (c - S::xfirst())>{}, xin[0]);
-                    if constexpr (J == 3) loadx(rown, IC<2 * (c - S::xfirst()) + 1>{}, xin[1]);
-                }
-                if constexpr (c > S::xfirst() && c <= S::xfirst() + JA && J < 4) {   // (pair J: xin[J >> 1]; this chunk's own loads follow at k-steps 1 and 3)
+                // the next slab's input rows: two 16-byte asm loads per chunk (first k-step), split into planes during the chunk after
+                if constexpr (c >= S::xfirst() && c < S::xfirst() + JA && J == 0 && (g == 2 || g == 3))
+                    loadx_asm(xnext, IC<2 * (c - S::xfirst()) + (g - 2)>{}, xin[c & 1][g - 2]);
+                if constexpr (c > S::xfirst() && c <= S::xfirst() + JA && J < 4) {   // (pair J of the two pieces the chunk before loaded)
                     constexpr int Jn = c - S::xfirst() - 1, q4 = J;  // planes gp[Jn] of the next slab (layer A of this slab is over), pair q4
                     static_assert(c <= S::xfirst() || c >= TA, "");
                     const bool okn = rown < a.M;
-                    const float v0 = okn ? xin[q4 >> 1][2 * (q4 & 1)] : 0.f, v1 = okn ? xin[q4 >> 1][2 * (q4 & 1) + 1] : 0.f;
+                    const f32x4 (&xq)[2] = xin[(c + 1) & 1];
+                    const float v0 = okn ? xq[q4 >> 1][2 * (q4 & 1)] : 0.f, v1 = okn ? xq[q4 >> 1][2 * (q4 & 1) + 1] : 0.f;
                     if constexpr (g >= 5) split_phase<g - 5>(v0, v1, st2, pn2[0][q4], pn2[1][q4], pn2[2][q4]);
                     if constexpr (q4 == 3 && g == 8) {
 #pragma unroll
@@ -319,8 +349,6 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
                         e[k] = prv[r] * (av > 0.f ? sgn : fmaf(av, sgn, sgn));
                         prv[r] = e[k];
                     }
-                    // a finished group of four goes to memory
-                    if constexpr (g == 5 && ((r0 + EPK - 1) & 3) == 3) store4(prv, Yp, ldp, prow, Tp, IC<(r0 + EPK - 1) / 4>{});
                     // G2's elements become planes of layer B: pair p of the tile (elements 2 p, 2 p + 1) is slot p % 4 of k-step 2 Tp + p / 4
                     if constexpr (pA && g >= 5) {
                         split_phase<g - 5>(e[0], e[1], st0, pn[0][(r0 / 2) & 3], pn[1][(r0 / 2) & 3], pn[2][(r0 / 2) & 3]);
@@ -331,14 +359,17 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
                             for (int q = 0; q < 3; q++) { hp[2 * Tp + plast / 4][q] = u32x4{pn[q][0], pn[q][1], pn[q][2], pn[q][3]}; BG_PLANES_IN_PLACE("+a", hp[2 * Tp + plast / 4][q]); }
                         }
                     }
-                } else if constexpr (g >= 1 && g <= 4) {
+                }
+                // the finished groups of four go to memory, one per k-step of the second half
+                if constexpr (J >= S::store_first(c) && J < S::store_first(c) + 4 && g == 6) store4(prv, Yp, ldp, prow, Tp, IC<J - S::store_first(c)>{});
+                if constexpr (J >= JE && g >= 1 && g <= 4) {
                     // the tile's column sums: 38 butterfly instructions over the second half's gaps 1 .. 4, then ONE ds_add per lane pair (lanes i and
                     // i ^ 1 hold the same sum: the odd one adds zero)
                     constexpr int slots = 4 * (JX - JE), per = (39 + slots - 1) / slots, first = ((J - JE) * 4 + (g - 1)) * per;
                     static_for<per>([&](auto k_) {
                         constexpr int op = first + decltype(k_)::value;
                         if constexpr (op < 38) bfly_op<op>(bf, prv, (i & 2) != 0);
-                        if constexpr (op == 38) atomicAdd(sCp + csofs, (i & 1) ? 0.f : bf.w);
+                        if constexpr (op == 38) { if ((i & 1) == 0) *csp = bf.w; }   // (lanes i and i ^ 1 hold the same sum)
                     });
                 }
             };
@@ -354,10 +385,13 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         const int next = slab + stride;
         const bool has_next = next < nslabs;
         const int rown = (has_next ? next : slab) * 128 + wave * 32 + i;
+        xnext = a.G3 + (size_t)(rown < a.M ? rown : a.M - 1) * N3 + 4 * h;
+        row0w = slab * 128 + wave * 32;
         static_for<C>([&](auto c_) { chunk(c_, rown); });
         if constexpr (C % 3 == 1) { const unsigned b0 = bb[0]; bb[0] = bb[1]; bb[1] = bb[2]; bb[2] = b0; }
         if constexpr (C % 3 == 2) { const unsigned b0 = bb[0]; bb[0] = bb[2]; bb[2] = bb[1]; bb[1] = b0; }
         rowp = row;
+        slabp = slab;
         if (!has_next) break;
         slab = next;
         row = rown;
@@ -368,7 +402,8 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(acc[(C - 1) & 1]));  // (tied to the accumulator: a plain statement would not keep the reads behind it)
     {
         f32x16& prv = acc[(C - 1) & 1];
-        f32x4 (&pa)[4] = aux[(C - 1) & 1];
+        // its activations: copied into the LDS corner during the last chunk; the chunk_top of the slab that does not exist has read them into aux
+        f32x4 (&pa)[4] = aux;
         static_for<16>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const float av = pa[r / 4][r % 4];
@@ -377,7 +412,7 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         });
         Bfly bf;
         static_for<38>([&](auto op_) { bfly_op<decltype(op_)::value>(bf, prv, (i & 2) != 0); });
-        atomicAdd(sCw + N2 + 32 * (TB - 1) + csofs, (i & 1) ? 0.f : bf.w);
+        if ((i & 1) == 0) a.colsum_partial[((size_t)(slabp * 4 + wave)) * (N2 + N1) + N2 + 32 * (TB - 1) + csofs] = bf.w;
     }
     wait_vm<0>();  // the copies issued for a slab that does not exist must have landed before the workgroup's LDS is handed on
 #ifdef BG_CHAIN_PROBE_STAMPS
@@ -391,7 +426,7 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
 template <int TAG>
 __global__ __launch_bounds__(256) void mlp_chain_split_bwd_kernel(BwdGroup grp) {
     __shared__ __attribute__((aligned(16))) unsigned sW[NBUF * BUFDW];
-    __shared__ __attribute__((aligned(16))) float sC[4 * 2 * NMAX];
+    __shared__ __attribute__((aligned(16))) float sT[4 * 1024];   // 4 KB per wave: the activations under the tile being finished
     int k = 0;
     if constexpr (TAG == 0) {
 #pragma unroll
@@ -399,17 +434,10 @@ __global__ __launch_bounds__(256) void mlp_chain_split_bwd_kernel(BwdGroup grp) 
             if (j < grp.n && (int)blockIdx.x >= grp.begin[j]) k = j;
     }
     const bg_mlp_chain_split_bwd& a = grp.net[k];
-    const int nc = a.N2 + a.N1;
-    for (int j = threadIdx.x; j < 4 * nc; j += 256) sC[j] = 0.f;
-    __syncthreads();
     const int nslabs = (a.M + 127) / 128, stride = grp.begin[k + 1] - grp.begin[k], first = blockIdx.x - grp.begin[k];
-    if (first < nslabs) {
-        if (TAG == 0 && a.N2 == 256) bwd_net<256, 256, 128>(a, first, stride, nslabs, sW, sC);
-        else bwd_net<256, 128, 128>(a, first, stride, nslabs, sW, sC);
-    }
-    __syncthreads();
-    // this workgroup's record of column sums: the four waves in a fixed order
-    for (int j = threadIdx.x; j < nc; j += 256) a.colsum_partial[(size_t)first * nc + j] = (sC[j] + sC[nc + j]) + (sC[2 * nc + j] + sC[3 * nc + j]);
+    if (first >= nslabs) return;
+    if (TAG == 0 && a.N2 == 256) bwd_net<256, 256, 128>(a, first, stride, nslabs, sW, sT);
+    else bwd_net<256, 128, 128>(a, first, stride, nslabs, sW, sT);
 }
 
 int bwd_check(const bg_mlp_chain_split_bwd& q) {
@@ -438,7 +466,7 @@ extern "C" int bg_mlp_chain_backward_split(const bg_mlp_chain_split_bwd* nets, i
         const int wg = nets[k].workgroups > 0 && nets[k].workgroups < slabs ? nets[k].workgroups : slabs;
         blocks += wg;
         memset(&finishes[k], 0, sizeof(finishes[k]));
-        finishes[k].partial = nets[k].colsum_partial; finishes[k].groups = wg; finishes[k].record = nets[k].N2 + nets[k].N1; finishes[k].n_out = nets[k].N2 + nets[k].N1;
+        finishes[k].partial = nets[k].colsum_partial; finishes[k].groups = slabs * 4; finishes[k].record = nets[k].N2 + nets[k].N1; finishes[k].n_out = nets[k].N2 + nets[k].N1;
         finishes[k].out[0] = nets[k].bias_grad2; finishes[k].n[0] = nets[k].N2;
         finishes[k].out[1] = nets[k].bias_grad1; finishes[k].n[1] = nets[k].N1;
     }

@@ -175,8 +175,8 @@ class MLPTrainer:
         n1, n2, n3 = ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0]
         slabs = (B + 127) // 128
         wg = self.chain_bwd_workgroups if 0 < self.chain_bwd_workgroups < slabs else slabs
-        if self.chain_colsum is None or self.chain_colsum.numel() < wg * (n1 + n2):
-            self.chain_colsum = torch.empty(slabs * (n1 + n2), dtype=torch.float32, device=g.device)
+        if self.chain_colsum is None or self.chain_colsum.numel() < slabs * 4 * (n1 + n2):  # one record of column sums per (slab, wave)
+            self.chain_colsum = torch.empty(slabs * 4 * (n1 + n2), dtype=torch.float32, device=g.device)
         self._pending_wgrad = [(2, g), (1, self.gin[2]), (0, self.gin[1])]
         return _lib.MlpChainSplitBwd(B, n1, n2, n3, int(self.chain_bwd_workgroups), 0, p(g), p(PT[2]), p(PT[1]), p(self.acts[1]), p(self.acts[0]), p(self.gin[2]),
                                      p(self.gin[1]), p(self.chain_colsum), p(ls[1].bias.grad), p(ls[0].bias.grad))
@@ -309,7 +309,7 @@ class MLPTrainer:
         self.mirror_fresh = False
         self.cplanes = [None] * 3  # CHAIN_SPLIT: bf16 planes of the three hidden layers' weights for the chained forward kernel
         self.cplanes_t = [None] * 3  # ... and of the transposed weights of layers 1 and 2 for the chained backward kernel
-        self.chain_colsum = None     # ... whose workgroups each leave one record of column sums here
+        self.chain_colsum = None     # ... whose waves leave one record of column sums per slab here
         self.planes = [None] * len(self.layers)  # SPLIT: bf16 planes of the weights (forward) ...
         self.planes_t = [None] * len(self.layers)  # ... and of the transposed weights (backward)
         l0 = self.layers[0]

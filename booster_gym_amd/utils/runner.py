@@ -642,6 +642,9 @@ class Runner:
         if self._split_bwd_chain_cus and ct._chain_split_bwd() and at._chain_split_bwd():
             bcost = lambda tr: sum(l.weight.shape[0] * l.weight.shape[1] for l in tr.layers[1:3])
             ct.chain_bwd_workgroups, at.chain_bwd_workgroups = plan_chain_split(sa, sa, bcost(ct), bcost(at), cus)
+            fixed = os.environ.get("BG_BWD_CHAIN_CUS")  # "critic,actor": a fixed split (A/B runs)
+            if fixed:
+                ct.chain_bwd_workgroups, at.chain_bwd_workgroups = (int(v) for v in fixed.split(","))
 
     def _exchange_sums(self):
         """Exchange (3), on the current (side) stream: the loss / KL sums and the log-std gradient of all ranks in one float64 all-reduce; the gradient

@@ -437,8 +437,9 @@ int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stre
  * `loss.backward()`, utils/runner.py:163, through utils/model.py:9-26's hidden layers):  G2 [M][N2] = (G3 [M][N3] . W3 [N3][N2]) * elu'(A2),
  * G1 [M][N1] = (G2 . W2 [N2][N1]) * elu'(A1), and the column sums of G2 / G1 (the bias gradients of layers 2 / 1: bg_mlp_layer_backward twice).
  * PT3 / PT2: the planes of W3^T / W2^T as bg_mlp_split_weights(transpose = 1) writes them ([N2][N3 / 32][3][32], [N1][N2 / 32][3][32]); A2 / A1: the
- * layers' stored outputs.  G2 / G1 must hold ceil(M / 128) * 128 rows (rows >= M are written with zeros).  Every workgroup leaves one record of
- * column sums in colsum_partial ([workgroups or slabs][N2 + N1] floats); `finishes[k]` receives the descriptor of the fixed-order reduction that
+ * layers' stored outputs, holding ceil(M / 128) * 128 rows of finite values as bg_mlp_chain_forward_split leaves them (whole 128-byte rows of a
+ * slab are copied; rows >= M do not enter the results).  G2 / G1 must hold ceil(M / 128) * 128 rows (rows >= M are written with zeros).  Every wave
+ * leaves one record of column sums per slab in colsum_partial ([ceil(M / 128) * 4][N2 + N1] floats); `finishes[k]` receives the descriptor of the fixed-order reduction that
  * produces bias_grad2 [N2] and bias_grad1 [N1] when handed to bg_reduce_group / bg_update_tail.  Widths (N1, N2, N3): (256, 128, 128), (256, 256, 128). */
 typedef struct bg_mlp_chain_split_bwd {
     int32_t M, N1, N2, N3;

@@ -58,16 +58,33 @@ def scan(extra=()):
                 states += 1
                 if states >= NEED + 2:
                     break
-        report[name] = (n_mfma, hazards, worst)
+        # the asm loads of the next slab's input rows: nothing may touch their destination registers before the barrier of the next chunk's top (the
+        # counted wait that makes them valid sits in front of it)
+        early = []
+        for k, (l, a) in enumerate(ins):
+            if not (a and l.startswith("global_load_dwordx4 v")):
+                continue
+            dst = regs(l.split(None, 1)[1].split(",")[0])
+            for l2, _ in ins[k + 1:]:
+                if l2.startswith("s_barrier"):
+                    break
+                toks = re.findall(r"[av]\[\d+:\d+\]|[av]\d+", l2)
+                if any(regs(t) & dst for t in toks):
+                    early.append((l, l2))
+                    break
+        report[name] = (n_mfma, hazards, worst, early)
     return report
 
 
 if __name__ == "__main__":
     rep = scan(sys.argv[1:])
     bad = 0
-    for name, (n, hz, worst) in rep.items():
-        print(f"{name}: {n} inline-asm MFMAs, {len(hz)} with fewer than {NEED} wait states behind a vector write of an operand (closest: {worst})")
+    for name, (n, hz, worst, early) in rep.items():
+        print(f"{name}: {n} inline-asm MFMAs, {len(hz)} with fewer than {NEED} wait states behind a vector write of an operand (closest: {worst}); "
+              f"{len(early)} asm loads whose registers are touched before the next chunk's barrier")
         for p, l, s in hz[:6]:
             print(f"    {s} wait states: {p}  ->  {l}")
-        bad += len(hz)
+        for l, l2 in early[:6]:
+            print(f"    {l}  touched by  {l2}")
+        bad += len(hz) + len(early)
     sys.exit(1 if bad else 0)
