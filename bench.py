@@ -396,8 +396,8 @@ def main():
             return g0.elapsed_time(g1) / reps * 1e3
 
         lib = _lib.load()
-        evc = [e for e in runner._critic_tr.timed_events if e[5] == "chain"]
-        eva = [e for e in runner._actor_tr.timed_events if e[5] == "chain"]
+        evc = [e for e in runner._critic_tr.timed_events if e[5] in ("chain", "chain_split")]
+        eva = [e for e in runner._actor_tr.timed_events if e[5] in ("chain", "chain_split")]
         if not (evc and len(evc) == len(eva)):
             raise SystemExit("bench.py expects the chained forward kernels (the default path) on both networks")
         # The symbols with the largest total time of the iteration (profiles/<PMC_TAG>_bench_kernel_stats.csv) are the two networks' chained forward

@@ -68,13 +68,14 @@ class MlpChain(C.Structure):
 
 class MlpChainSplit(C.Structure):
     """bg_mlp_chain_split: the forward chain of one network on the bf16 matrix pipe (9 exact products) for bg_mlp_chain_forward_split."""
-    _fields_ = [("M", C.c_int32), ("K0", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("N3", C.c_int32), ("workgroups", C.c_int32)] + \
+    _fields_ = [("M", C.c_int32), ("K0", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("N3", C.c_int32), ("workgroups", C.c_int32),
+                ("alternate", C.c_int32), ("pad", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("X", "P1", "P2", "P3", "b1", "b2", "b3", "Y1", "Y2", "Y3", "v_w", "v_b", "v_out")]
 
 
 class MlpChainSplitBwd(C.Structure):
     """bg_mlp_chain_split_bwd: the backward-data chain of one network on the bf16 matrix pipe (9 exact products) for bg_mlp_chain_backward_split."""
-    _fields_ = [("M", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("N3", C.c_int32), ("workgroups", C.c_int32), ("pad", C.c_int32)] + \
+    _fields_ = [("M", C.c_int32), ("N1", C.c_int32), ("N2", C.c_int32), ("N3", C.c_int32), ("workgroups", C.c_int32), ("alternate", C.c_int32)] + \
                [(n, C.c_void_p) for n in ("G3", "PT3", "PT2", "A2", "A1", "G2", "G1", "colsum_partial", "bias_grad2", "bias_grad1")]
 
 
@@ -194,6 +195,7 @@ def load():
         "bg_critic_values_gae": (i32, [i32, i32, vp, vp, vp, vp, vp, vp, f32, f32, vp, vp, vp, vp, vp, vp]),
         "bg_mlp_layer_backward": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
         "bg_mlp_split_weights": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, vp]),
+        "bg_mlp_split_weights_pm": (i32, [i32, i32, vp, i32, i32, i32, i32, vp, vp]),
         "bg_mlp_layer_forward_split": (i32, [i32, i32, i32, vp, vp, vp, vp, i32, i32, vp]),
         "bg_mlp_layer_backward_split": (i32, [i32, i32, i32, vp, vp, vp, vp, vp, vp, i32, vp]),
         "bg_mlp_weight_grad": (i32, [i32, i32, i32, i32, vp, vp, vp, vp, i32, vp]),

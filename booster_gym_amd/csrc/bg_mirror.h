@@ -25,6 +25,12 @@ __device__ __forceinline__ void bg_mirror_write(const bg_param_mirror& mm, int r
         d[0] = (unsigned short)(u >> 16);
         d[32] = (unsigned short)(v >> 16);
         d[64] = (unsigned short)(__float_as_uint(r2) >> 16);
+        if (mm.pad > 0) {  // ... and the planes of -W, mm.pad uint16 behind (bg_mlp_split_weights_pm's layout)
+            d += mm.pad;
+            d[0] = (unsigned short)((u >> 16) ^ 0x8000u);
+            d[32] = (unsigned short)((v >> 16) ^ 0x8000u);
+            d[64] = (unsigned short)((__float_as_uint(r2) >> 16) ^ 0x8000u);
+        }
     }
 }
 // host-side check of a descriptor against a flat buffer of n floats

@@ -39,6 +39,7 @@ extern "C" int bg_probe_read_split_stamps(void* dst, size_t bytes) { return (int
 namespace {
 
 struct SplitGroup { int n; int begin[CHAIN_MAX + 1]; bg_mlp_chain_split net[CHAIN_MAX]; };
+constexpr int SBNEG = 3 * NMAX + 128;   // floats between a bias in LDS and its negated copy
 
 // All slabs first, first + stride, ... < nslabs of one network: ONE continuous stream of weight chunks, the slabs' own prologues and epilogues folded
 // into their neighbours' MFMA shadows:
@@ -94,13 +95,18 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
     // LDS image of stream chunk cc: buffer (cc + phase) % 3, the phase advancing by C per slab; bb[r]: byte offset of the buffer of chunks cc % 3 == r
     unsigned bb[3] = {0u, (unsigned)BUFDW * 4u, 2u * (unsigned)BUFDW * 4u};
     const unsigned sWbase = (unsigned)(uintptr_t)sW;
+    // Odd slabs accumulate the NEGATED sums when a.alternate is set (planes of -W, -bias as the accumulators' start; include/booster_gym_amd.h: the
+    // rounding bias of the MFMA accumulator then cancels in what is summed over rows); sgn / sgnp put a finished tile of this slab / the one before right
+    bool negc = false, negn = false;
+    float sgn = 1.0f, sgnp = 1.0f;
     auto dma = [&](auto cc_, auto q_) {
         constexpr int cc = decltype(cc_)::value, q = decltype(q_)::value, c = cc % C;
         if constexpr (q < S::ndma(cc)) {
             const unsigned dst = sWbase + bb[cc % 3];
-            if constexpr (c < C0) dma_piece<q>(P1, C0, c, dst, wave, rowpart, piecepart);
-            else if constexpr (c < C0 + C1) dma_piece<q>(P2, C1, c - C0, dst, wave, rowpart, piecepart);
-            else dma_piece<q>(P3, C2, c - C0 - C1, dst, wave, rowpart, piecepart);
+            const bool neg = cc < C ? negc : negn;   // (the slab the chunk belongs to: this one or the next; odd slabs read the planes of -W)
+            if constexpr (c < C0) dma_piece<q>(P1 + (neg ? (size_t)N1 * K0 * 3 / 2 : 0), C0, c, dst, wave, rowpart, piecepart);
+            else if constexpr (c < C0 + C1) dma_piece<q>(P2 + (neg ? (size_t)N2 * N1 * 3 / 2 : 0), C1, c - C0, dst, wave, rowpart, piecepart);
+            else dma_piece<q>(P3 + (neg ? (size_t)N3 * N2 * 3 / 2 : 0), C2, c - C0 - C1, dst, wave, rowpart, piecepart);
         }
     };
 #ifdef BG_CHAIN_PROBE_STAMPS
@@ -118,9 +124,9 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
     float part = 0.f;
     const float vbias = a.v_out ? a.v_b[0] : 0.f;  // (read once: a load in the middle of the stream would be waited for with everything else)
     // bias -> accumulators: feature 32 t + 8 g + 4 h + q in register 4 g + q of tile t (one 16-byte LDS read, straight into the accumulator registers)
-    auto init4 = [&](auto& A, int ofs, auto t_, auto g_) {
+    auto init4 = [&](auto& A, int ofs, bool neg, auto t_, auto g_) {   // (neg: the negated biases, SBNEG floats further)
         constexpr int t = decltype(t_)::value, g = decltype(g_)::value;
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sB[ofs + 32 * t + 8 * g + 4 * h]);
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(&sB[(neg ? SBNEG : 0) + ofs + 32 * t + 8 * g + 4 * h]);
         A[t][4 * g + 0] = b4.x; A[t][4 * g + 1] = b4.y; A[t][4 * g + 2] = b4.z; A[t][4 * g + 3] = b4.w;
     };
     auto loadx = [&](int r, auto j_) {
@@ -129,7 +135,7 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
         x0[4 * j + 0] = v.x; x0[4 * j + 1] = v.y; x0[4 * j + 2] = v.z; x0[4 * j + 3] = v.w;
     };
     // ELU of element r of tile t in place, in two pieces (fin_a / fin_b)
-    auto fa = [&](FinTmp& f, auto& A, auto t_, auto r_) { fin_a(f, A[decltype(t_)::value][decltype(r_)::value]); };
+    auto fa = [&](FinTmp& f, auto& A, auto t_, auto r_, float sg) { fin_a(f, A[decltype(t_)::value][decltype(r_)::value] * sg); };
     auto fb = [&](const FinTmp& f, auto& A, auto t_, auto r_) { constexpr int t = decltype(t_)::value, r = decltype(r_)::value; A[t][r] = fin_b(f, A[t][r]); };
     auto store4 = [&](auto& A, float* __restrict__ Y, int r, auto N_, auto t_, auto g_) {
 #ifndef BG_ABL_NOSTORE
@@ -144,7 +150,7 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
     auto l3_a = [&](FinTmp& f, auto e_) {
         constexpr int e = decltype(e_)::value;
         if constexpr (e % 4 == 0 && e / 4 + 1 < 16) vw4(IC<e / 4 + 1>{});
-        fa(f, a3, IC<e / 16>{}, IC<e % 16>{});
+        fa(f, a3, IC<e / 16>{}, IC<e % 16>{}, sgnp);
     };
     auto l3_b = [&](const FinTmp& f, auto e_, int rowp) {
         constexpr int e = decltype(e_)::value;
@@ -174,6 +180,8 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
     // ---- prologue of the first slab
     int slab = first;
     int row = slab * 128 + wave * 32 + i;
+    negc = a.alternate && (slab & 1);
+    sgn = sgnp = negc ? -1.0f : 1.0f;
     BG_STAMP(0);
 #ifdef BG_CHAIN_PROBE_STAMPS
     stamps[62] = wall_clock64();
@@ -183,7 +191,7 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
     static_for<S::ndma(0)>([&](auto q_) { dma(IC<0>{}, q_); });
     static_for<S::ndma(1)>([&](auto q_) { dma(IC<1>{}, q_); });
     BG_PIN();
-    static_for<NT1>([&](auto t_) { static_for<4>([&](auto g_) { init4(a1, 0, t_, g_); }); });
+    static_for<NT1>([&](auto t_) { static_for<4>([&](auto g_) { init4(a1, 0, negc, t_, g_); }); });
 #pragma unroll
     for (int t = 0; t < NT3; t++)
 #pragma unroll
@@ -256,13 +264,13 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                             float* __restrict__ Yprev = L == 2 ? a.Y1 : a.Y2;
                             if constexpr (kc + 1 < NTP) {
                                 if constexpr (EPT == 1) {
-                                    if constexpr (g == 1) fa(f0, prev, IC<kc + 1>{}, IC<8 * j + t>{});
+                                    if constexpr (g == 1) fa(f0, prev, IC<kc + 1>{}, IC<8 * j + t>{}, sgn);
                                     if constexpr (g == 2) fb(f0, prev, IC<kc + 1>{}, IC<8 * j + t>{});
                                     if constexpr (g == 8 && (t & 3) == 3) store4(prev, Yprev, row, IC<K>{}, IC<kc + 1>{}, IC<(8 * j + t) / 4>{});
                                 } else {
-                                    if constexpr (g == 1) fa(f0, prev, IC<kc + 1>{}, IC<8 * j + 2 * t>{});
+                                    if constexpr (g == 1) fa(f0, prev, IC<kc + 1>{}, IC<8 * j + 2 * t>{}, sgn);
                                     if constexpr (g == 2) fb(f0, prev, IC<kc + 1>{}, IC<8 * j + 2 * t>{});
-                                    if constexpr (g == 7) fa(f1, prev, IC<kc + 1>{}, IC<8 * j + 2 * t + 1>{});
+                                    if constexpr (g == 7) fa(f1, prev, IC<kc + 1>{}, IC<8 * j + 2 * t + 1>{}, sgn);
                                     if constexpr (g == 8) fb(f1, prev, IC<kc + 1>{}, IC<8 * j + 2 * t + 1>{});
                                     if constexpr (g == 8 && (t & 1) == 1) store4(prev, Yprev, row, IC<K>{}, IC<kc + 1>{}, IC<(8 * j + 2 * t) / 4>{});
                                 }
@@ -274,19 +282,19 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                             // ... and its layer-1 accumulators = bias, over the last two chunks
                             if constexpr (kc >= CH - 2 && (g == 3 || g == 4)) {
                                 constexpr int G = ((kc - (CH - 2)) * 2 * NT + ts) * 2 + (g == 4);
-                                init4(a1, 0, IC<G / 4>{}, IC<G % 4>{});
+                                init4(a1, 0, negn, IC<G / 4>{}, IC<G % 4>{});
                             }
                         }
                         if constexpr (lastk && L < 3) {
                             // the layer's last k-step: tile 0 is complete behind tile-step 0; it is finished under the other tiles, then the planes of the
                             // NEXT layer's first k-step (its elements 0 .. 7) are split; the next layer's accumulators = bias
                             float* __restrict__ Y = L == 1 ? a.Y1 : a.Y2;
-                            if constexpr (L == 1) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT2) init4(a2, N1, IC<G / 4>{}, IC<G % 4>{}); } }
-                            if constexpr (L == 2) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT3) init4(a3, N1 + N2, IC<G / 4>{}, IC<G % 4>{}); } }
+                            if constexpr (L == 1) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT2) init4(a2, N1, negc, IC<G / 4>{}, IC<G % 4>{}); } }
+                            if constexpr (L == 2) { if constexpr (g == 2 || g == 4 || g == 6 || g == 8) { constexpr int G = 4 * t + (g - 2) / 2; if constexpr (G < 4 * NT3) init4(a3, N1 + N2, negc, IC<G / 4>{}, IC<G % 4>{}); } }
                             if constexpr (NT == 8) {
                                 if constexpr (t >= 1 && t <= 4 && g >= 1) {
                                     constexpr int r = 4 * (t - 1) + (g - 1) / 2;
-                                    if constexpr (g & 1) fa(f0, acc, IC<0>{}, IC<r>{}); else fb(f0, acc, IC<0>{}, IC<r>{});
+                                    if constexpr (g & 1) fa(f0, acc, IC<0>{}, IC<r>{}, sgn); else fb(f0, acc, IC<0>{}, IC<r>{});
                                     if constexpr (g == 8) store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<t - 1>{});
                                 }
                                 if constexpr (t == 5 || t == 6) {
@@ -298,7 +306,7 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
                                 if constexpr (t == 1 || t == 2) {
                                     // eight elements: piece a of element g behind MFMA g, piece b behind the next (two temporaries in turn)
                                     if constexpr (g >= 1) { if constexpr ((g - 1) & 1) fb(f1, acc, IC<0>{}, IC<8 * (t - 1) + g - 1>{}); else fb(f0, acc, IC<0>{}, IC<8 * (t - 1) + g - 1>{}); }
-                                    if constexpr (g <= 7) { if constexpr (g & 1) fa(f1, acc, IC<0>{}, IC<8 * (t - 1) + g>{}); else fa(f0, acc, IC<0>{}, IC<8 * (t - 1) + g>{}); }
+                                    if constexpr (g <= 7) { if constexpr (g & 1) fa(f1, acc, IC<0>{}, IC<8 * (t - 1) + g>{}, sgn); else fa(f0, acc, IC<0>{}, IC<8 * (t - 1) + g>{}, sgn); }
                                     if constexpr (g == 4) store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1)>{});
                                     if constexpr (g == 8) store4(acc, Y, row, IC<N>{}, IC<0>{}, IC<2 * (t - 1) + 1>{});
                                 }
@@ -338,6 +346,7 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
         const int next = slab + stride;
         const bool has_next = next < nslabs;
         const int rown = (has_next ? next : slab) * 128 + wave * 32 + i;
+        negn = a.alternate && ((has_next ? next : slab) & 1);
         layer(IC<1>{}, a1, x0in, IC<K0>{}, IC<N1>{}, IC<0>{}, rown);
         layer(IC<2>{}, a2, a1in, IC<N1>{}, IC<N2>{}, IC<C0>{}, rown);
         layer(IC<3>{}, a3, a2in, IC<N2>{}, IC<N3>{}, IC<C0 + C1>{}, rown);
@@ -345,10 +354,13 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
         if constexpr (C % 3 == 1) { const unsigned b0 = bb[0]; bb[0] = bb[1]; bb[1] = bb[2]; bb[2] = b0; }
         if constexpr (C % 3 == 2) { const unsigned b0 = bb[0]; bb[0] = bb[2]; bb[2] = bb[1]; bb[1] = b0; }
         rowp = row;
+        sgnp = sgn;
         has_prev = true;
         if (!has_next) break;
         slab = next;
         row = rown;
+        negc = negn;
+        sgn = negc ? -1.0f : 1.0f;
     }
     // layer 3 of the last slab
     static_for<16 * NT3>([&](auto e_) {
@@ -372,7 +384,7 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
 template <int TAG>
 __global__ __launch_bounds__(256) void mlp_chain_split_fwd_kernel(SplitGroup grp) {
     __shared__ __attribute__((aligned(16))) unsigned sW[NBUF * BUFDW];
-    __shared__ __attribute__((aligned(16))) float sB[3 * NMAX + 128];
+    __shared__ __attribute__((aligned(16))) float sB[2 * SBNEG];   // biases [N1 | N2 | N3], value-head weights [N3]; SBNEG further: the negated biases
     int k = 0;
     if constexpr (TAG == 0) {
 #pragma unroll
@@ -381,8 +393,11 @@ __global__ __launch_bounds__(256) void mlp_chain_split_fwd_kernel(SplitGroup grp
     }
     const bg_mlp_chain_split& a = grp.net[k];
     const int nb = a.N1 + a.N2 + a.N3;
-    for (int j = threadIdx.x; j < nb + a.N3; j += 256)
-        sB[j] = j < a.N1 ? a.b1[j] : j < a.N1 + a.N2 ? a.b2[j - a.N1] : j < nb ? a.b3[j - a.N1 - a.N2] : a.v_w ? a.v_w[j - nb] : 0.f;
+    for (int j = threadIdx.x; j < nb + a.N3; j += 256) {
+        const float v = j < a.N1 ? a.b1[j] : j < a.N1 + a.N2 ? a.b2[j - a.N1] : j < nb ? a.b3[j - a.N1 - a.N2] : a.v_w ? a.v_w[j - nb] : 0.f;
+        sB[j] = v;
+        if (j < nb) sB[SBNEG + j] = -v;
+    }
     __syncthreads();
     // One slab per workgroup, or (workgroups > 0) that many workgroups walking the network's slabs (see bg_mlp_chain.hip: two launches side by side
     // share the chip by CUs; counts that are multiples of the 8 XCDs)

@@ -172,12 +172,17 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
     static_assert(S::xfirst() >= TA - 1 && JA == 8, "the next slab's planes are written when layer A of this slab is over");
     unsigned bb[3] = {0u, (unsigned)BUFDW * 4u, 2u * (unsigned)BUFDW * 4u};
     const unsigned sWbase = (unsigned)(uintptr_t)sW;
+    // Odd slabs accumulate the negated sums when a.alternate is set (see include/booster_gym_amd.h: the MFMA accumulator's rounding bias then cancels in
+    // everything summed over rows); sgn / sgnp: the sign that puts a finished tile of the slab in work / of the slab before right again
+    bool negc = false, negn = false;
+    float sgn = 1.0f, sgnp = 1.0f;
     auto dma = [&](auto cc_, auto q_) {
         constexpr int cc = decltype(cc_)::value, q = decltype(q_)::value, c = cc % C;
         if constexpr (q < S::ndma(cc)) {
             const unsigned dst = sWbase + bb[cc % 3];
-            if constexpr (c < TA) dma_tile_piece<q>(PA, CHA, c, dst, wave, rowpart, piecepart);
-            else dma_tile_piece<q>(PB, CHB, c - TA, dst, wave, rowpart, piecepart);
+            const bool neg = cc < C ? negc : negn;   // (the slab the chunk belongs to: this one or the next; odd slabs read the planes of -W^T)
+            if constexpr (c < TA) dma_tile_piece<q>(PA + (neg ? (size_t)N2 * N3 * 3 / 2 : 0), CHA, c, dst, wave, rowpart, piecepart);
+            else dma_tile_piece<q>(PB + (neg ? (size_t)N1 * N2 * 3 / 2 : 0), CHB, c - TA, dst, wave, rowpart, piecepart);
         }
     };
     const int sx = (i >> 2) & 3;              // this lane's slot swizzle
@@ -190,7 +195,7 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
     const unsigned aofsB = (unsigned)((lane >> 3) * N1 * 4 + (((lane & 7) ^ ((lane >> 3) & 7)) << 4));
     // the feature of a tile whose column sum the butterfly leaves in this lane: register R = 8 b4 + 4 b3 + 2 b2 + b1 of the lane number's bits
     const int csR = ((i >> 4) & 1) * 8 + ((i >> 3) & 1) * 4 + ((i >> 2) & 1) * 2 + ((i >> 1) & 1), csofs = (csR & 3) + 8 * (csR >> 2) + 4 * h;
-    const float sgn = 1.0f;
+
     u32x4 gp[JA][3];   // planes of the slab's input rows (G3), k-step J: values 8 J .. 8 J + 7 of the lane
     u32x4 hp[JB][3];   // planes of G2, filled as layer A's tiles are finished
     f32x16 acc[2];     // the tile in work and the tile being finished
@@ -256,6 +261,8 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
     // ---- prologue of the first slab: its input rows, split; the first two chunks' copies
     int slab = first;
     int row = slab * 128 + wave * 32 + i;
+    negc = a.alternate && (slab & 1);
+    sgn = sgnp = negc ? -1.0f : 1.0f;
     static_for<S::ndma(0)>([&](auto q_) { dma(IC<0>{}, q_); });
     static_for<S::ndma(1)>([&](auto q_) { dma(IC<1>{}, q_); });
     BG_PIN();
@@ -346,7 +353,8 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
                     if constexpr (g >= 1 && g <= EPK) {
                         constexpr int k = g - 1, r = r0 + k;
                         const float av = pa[r / 4][r % 4];
-                        e[k] = prv[r] * (av > 0.f ? sgn : fmaf(av, sgn, sgn));
+                        const float sg = c == 0 ? sgnp : sgn;
+                        e[k] = prv[r] * (av > 0.f ? sg : fmaf(av, sg, sg));
                         prv[r] = e[k];
                     }
                     // G2's elements become planes of layer B: pair p of the tile (elements 2 p, 2 p + 1) is slot p % 4 of k-step 2 Tp + p / 4
@@ -385,6 +393,7 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         const int next = slab + stride;
         const bool has_next = next < nslabs;
         const int rown = (has_next ? next : slab) * 128 + wave * 32 + i;
+        negn = a.alternate && ((has_next ? next : slab) & 1);
         xnext = a.G3 + (size_t)(rown < a.M ? rown : a.M - 1) * N3 + 4 * h;
         row0w = slab * 128 + wave * 32;
         static_for<C>([&](auto c_) { chunk(c_, rown); });
@@ -392,9 +401,12 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         if constexpr (C % 3 == 2) { const unsigned b0 = bb[0]; bb[0] = bb[2]; bb[2] = bb[1]; bb[1] = b0; }
         rowp = row;
         slabp = slab;
+        sgnp = sgn;
         if (!has_next) break;
         slab = next;
         row = rown;
+        negc = negn;
+        sgn = negc ? -1.0f : 1.0f;
     }
     // the last tile of the last slab (tile TB - 1 of layer B: acc[(C - 1) & 1], aux[(C - 1) & 1]).  Its last MFMA has just been issued, and the compiler
     // does not know that the statement was one: the wait states a vector read of an MFMA's result needs, by hand (in the loop a whole MFMA and more
@@ -407,7 +419,7 @@ __device__ __forceinline__ void bwd_net(const bg_mlp_chain_split_bwd& a, int fir
         static_for<16>([&](auto r_) {
             constexpr int r = decltype(r_)::value;
             const float av = pa[r / 4][r % 4];
-            prv[r] = prv[r] * (av > 0.f ? sgn : fmaf(av, sgn, sgn));
+            prv[r] = prv[r] * (av > 0.f ? sgnp : fmaf(av, sgnp, sgnp));
             if constexpr ((r & 3) == 3) store4(prv, a.G1, N1, rowp, TB - 1, IC<r / 4>{});
         });
         Bfly bf;

@@ -208,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void mlp_split_kernel(int M, int ldy, const
 // first layers).  Inside a chunk, k = s * 8 + 4 h + q (s 0..3, h 0..1, q 0..3) sits at position (s / 2) * 16 + h * 8 + (s % 2) * 4 + q: the
 // 8 values lane (., h) of MFMA step j = s / 2 needs are 16 contiguous bytes.
 __global__ __launch_bounds__(256) void split_planes_kernel(int n_out, int k_out, const float* __restrict__ W, int ldw, int src_rows, int src_cols,
-                                                           int transpose, unsigned short* __restrict__ planes) {
+                                                           int transpose, unsigned short* __restrict__ planes, int negated_copy) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= n_out * k_out) return;
     const int n = idx / k_out, k = idx % k_out;
@@ -225,6 +225,12 @@ __global__ __launch_bounds__(256) void split_planes_kernel(int n_out, int k_out,
     dst[0] = (unsigned short)(u >> 16);
     dst[32] = (unsigned short)(v >> 16);
     dst[64] = (unsigned short)(__float_as_uint(s2) >> 16);
+    if (negated_copy) {  // the planes of -W (the split is symmetric in the sign: every plane's sign bit flipped), behind the planes of W
+        unsigned short* neg = dst + (size_t)n_out * k_out * 3;
+        neg[0] = (unsigned short)((u >> 16) ^ 0x8000u);
+        neg[32] = (unsigned short)((v >> 16) ^ 0x8000u);
+        neg[64] = (unsigned short)((__float_as_uint(s2) >> 16) ^ 0x8000u);
+    }
 }
 
 extern "C" int bg_mlp_split_weights(int32_t n_out, int32_t k_out, const float* W, int32_t ldw, int32_t src_rows, int32_t src_cols, int32_t transpose,
@@ -233,7 +239,18 @@ extern "C" int bg_mlp_split_weights(int32_t n_out, int32_t k_out, const float* W
         return bg_set_error(-1, "bg_mlp_split_weights: bad argument");
     if (((uintptr_t)planes & 15) != 0) return bg_set_error(-1, "bg_mlp_split_weights: planes must be 16-byte aligned");
     hipLaunchKernelGGL(split_planes_kernel, dim3((n_out * k_out + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_out, k_out, W, ldw, src_rows, src_cols,
-                       transpose, planes);
+                       transpose, planes, 0);
+    HIP_OK(hipGetLastError());
+    return 0;
+}
+
+extern "C" int bg_mlp_split_weights_pm(int32_t n_out, int32_t k_out, const float* W, int32_t ldw, int32_t src_rows, int32_t src_cols, int32_t transpose,
+                                       uint16_t* planes, void* stream) {
+    if (n_out <= 0 || k_out <= 0 || k_out % 32 || !W || !planes || ldw <= 0 || src_rows <= 0 || src_cols <= 0)
+        return bg_set_error(-1, "bg_mlp_split_weights_pm: bad argument");
+    if (((uintptr_t)planes & 15) != 0) return bg_set_error(-1, "bg_mlp_split_weights_pm: planes must be 16-byte aligned");
+    hipLaunchKernelGGL(split_planes_kernel, dim3((n_out * k_out + 255) / 256), dim3(256), 0, (hipStream_t)stream, n_out, k_out, W, ldw, src_rows, src_cols,
+                       transpose, planes, 1);
     HIP_OK(hipGetLastError());
     return 0;
 }

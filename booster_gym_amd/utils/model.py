@@ -133,6 +133,10 @@ class MLPTrainer:
     # ... and the backward-data pass of the hidden layers as one launch of the same arithmetic (bg_mlp_chain_split_bwd.hip); BG_CHAIN_SPLIT_BWD=0: one
     # fp32-MFMA launch per layer (bg_mlp_layer_backward)
     CHAIN_SPLIT_BWD = __import__("os").environ.get("BG_CHAIN_SPLIT_BWD", "1") == "1"
+    # Odd 128-row slabs of the chained split kernels accumulate the NEGATED sums (planes of -W beside the planes of W) and put the sign back where a tile
+    # is finished: the bf16 MFMA's accumulator does not round to nearest, every accumulated element carries a small bias of one sign, and what is summed
+    # over the rows downstream (bias gradients, weight gradients) would collect it; alternating makes it cancel.  BG_CHAIN_ALTERNATE=0: off.
+    CHAIN_ALTERNATE = __import__("os").environ.get("BG_CHAIN_ALTERNATE", "1") == "1"
 
     def _chain_split(self):
         return self.CHAIN_SPLIT and self._chainable()
@@ -145,10 +149,10 @@ class MLPTrainer:
         for i in range(3):
             n_out, k_in = ls[i].weight.shape
             kp = self._kin if i == 0 else k_in
-            if new:
-                self.cplanes[i] = torch.empty(n_out * kp * 3, dtype=torch.int16, device=ls[i].weight.device)
+            if new:  # (the planes of W, then the planes of -W)
+                self.cplanes[i] = torch.zeros(2 * n_out * kp * 3, dtype=torch.int16, device=ls[i].weight.device)
             if new or not self.mirror_fresh:
-                _lib.check(lib.bg_mlp_split_weights(n_out, kp, _lib.ptr(ls[i].weight), k_in, n_out, k_in, 0, _lib.ptr(self.cplanes[i]), stream), "bg_mlp_split_weights")
+                _lib.check(lib.bg_mlp_split_weights_pm(n_out, kp, _lib.ptr(ls[i].weight), k_in, n_out, k_in, 0, _lib.ptr(self.cplanes[i]), stream), "bg_mlp_split_weights_pm")
         return self.cplanes
 
     def _chain_split_bwd(self):
@@ -162,9 +166,9 @@ class MLPTrainer:
         for i in (1, 2):
             c_out, c_in = ls[i].weight.shape
             if new:
-                self.cplanes_t[i] = torch.empty(c_in * c_out * 3, dtype=torch.int16, device=ls[i].weight.device)
+                self.cplanes_t[i] = torch.zeros(2 * c_in * c_out * 3, dtype=torch.int16, device=ls[i].weight.device)
             if new or not self.mirror_fresh:
-                _lib.check(lib.bg_mlp_split_weights(c_in, c_out, _lib.ptr(ls[i].weight), c_in, c_out, c_in, 1, _lib.ptr(self.cplanes_t[i]), stream), "bg_mlp_split_weights")
+                _lib.check(lib.bg_mlp_split_weights_pm(c_in, c_out, _lib.ptr(ls[i].weight), c_in, c_out, c_in, 1, _lib.ptr(self.cplanes_t[i]), stream), "bg_mlp_split_weights_pm")
         return self.cplanes_t
 
     def chain_backward_descriptor(self, g=None):
@@ -178,7 +182,7 @@ class MLPTrainer:
         if self.chain_colsum is None or self.chain_colsum.numel() < slabs * 4 * (n1 + n2):  # one record of column sums per (slab, wave)
             self.chain_colsum = torch.empty(slabs * 4 * (n1 + n2), dtype=torch.float32, device=g.device)
         self._pending_wgrad = [(2, g), (1, self.gin[2]), (0, self.gin[1])]
-        return _lib.MlpChainSplitBwd(B, n1, n2, n3, int(self.chain_bwd_workgroups), 0, p(g), p(PT[2]), p(PT[1]), p(self.acts[1]), p(self.acts[0]), p(self.gin[2]),
+        return _lib.MlpChainSplitBwd(B, n1, n2, n3, int(self.chain_bwd_workgroups), int(self.CHAIN_ALTERNATE), p(g), p(PT[2]), p(PT[1]), p(self.acts[1]), p(self.acts[0]), p(self.gin[2]),
                                      p(self.gin[1]), p(self.chain_colsum), p(ls[1].bias.grad), p(ls[0].bias.grad))
 
     def _chainable(self):
@@ -204,7 +208,7 @@ class MLPTrainer:
         if self._chain_split():
             P = self._fresh_planes()
             return _lib.MlpChainSplit(self.x.shape[0], self._kin, ls[0].weight.shape[0], ls[1].weight.shape[0], ls[2].weight.shape[0], int(self.chain_workgroups),
-                                      p(self.x), p(P[0]), p(P[1]), p(P[2]), p(ls[0].bias), p(ls[1].bias), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]),
+                                      int(self.CHAIN_ALTERNATE), 0, p(self.x), p(P[0]), p(P[1]), p(P[2]), p(ls[0].bias), p(ls[1].bias), p(ls[2].bias), p(self.acts[0]), p(self.acts[1]),
                                       p(self.acts[2]), p(vw), p(vb), p(vo))
         if not self.mirror_fresh:
             self.w0pad[:, : ls[0].weight.shape[1]].copy_(ls[0].weight)
@@ -488,11 +492,12 @@ class MLPTrainer:
             off = (l.weight.data_ptr() - flat.data_ptr()) // 4
             rows, cols = l.weight.shape
             if split and i < 3:  # the chained split kernel's planes (the padded input columns of the first layer stay zero)
-                out.append(_lib.ParamMirror(off, rows, cols, 2, self._kin if i == 0 else cols, 0, _lib.ptr(self.cplanes[i])))
+                kp = self._kin if i == 0 else cols
+                out.append(_lib.ParamMirror(off, rows, cols, 2, kp, rows * kp * 3, _lib.ptr(self.cplanes[i])))  # (pad: the planes of -W behind)
             if i == 0 and self.w0pad is not None and not split:
                 out.append(_lib.ParamMirror(off, rows, cols, 0, self.w0pad.shape[1], 0, _lib.ptr(self.w0pad)))
             if i in (1, 2) and self.cplanes_t[i] is not None:  # the chained backward kernel's planes of W^T
-                out.append(_lib.ParamMirror(off, rows, cols, 3, rows, 0, _lib.ptr(self.cplanes_t[i])))
+                out.append(_lib.ParamMirror(off, rows, cols, 3, rows, rows * cols * 3, _lib.ptr(self.cplanes_t[i])))
             if self.wt[i] is not None:
                 out.append(_lib.ParamMirror(off, rows, cols, 1, rows, 0, _lib.ptr(self.wt[i])))
         return out

@@ -270,7 +270,8 @@ int bg_adapt_lr(const double* kl_sum, float count, float desired_kl, float lr_mi
  * transpose = 1: dst[c * ld + r] (ld >= rows: the operand layout of bg_mlp_layer_backward).  offset = index of W[0][0] in params.
  * transpose = 2 / 3: dst = the bf16 planes of W / of W^T as bg_mlp_split_weights(transpose = 0 / 1) writes them (uint16_t [n_out][ld / 32][3][32],
  * 16-byte aligned, ld = k_out a multiple of 32 and >= cols / rows): what the chained split kernels read.  Elements outside the matrix (the
- * zero-padded input columns of a first layer) are not touched: write them once with bg_mlp_split_weights. */
+ * zero-padded input columns of a first layer) are not touched: write them once with bg_mlp_split_weights.  pad > 0 (kinds 2 / 3): the planes of
+ * -W are kept as well, pad uint16 behind dst (bg_mlp_split_weights_pm's layout: pad = n_out * k_out * 3). */
 typedef struct bg_param_mirror {
     int32_t offset, rows, cols, transpose, ld, pad;
     float* dst;
@@ -332,6 +333,10 @@ int bg_mlp_layer_backward(int32_t M, int32_t K, int32_t N, const float* G, const
  * Same shape limits and error codes as bg_mlp_layer_forward / _backward. */
 int bg_mlp_split_weights(int32_t n_out, int32_t k_out, const float* W, int32_t ldw, int32_t src_rows, int32_t src_cols, int32_t transpose,
                          uint16_t* planes, void* stream);
+/* bg_mlp_split_weights, and behind its planes (n_out * k_out * 3 uint16 further) the planes of -W: what the chained split kernels read with
+ * `alternate` set (planes must hold 2 * n_out * k_out * 3 uint16). */
+int bg_mlp_split_weights_pm(int32_t n_out, int32_t k_out, const float* W, int32_t ldw, int32_t src_rows, int32_t src_cols, int32_t transpose,
+                            uint16_t* planes, void* stream);
 int bg_mlp_layer_forward_split(int32_t M, int32_t K, int32_t N, const float* X, const uint16_t* planes, const float* bias, float* Y, int32_t elu,
                                int32_t terms, void* stream);
 int bg_mlp_layer_backward_split(int32_t M, int32_t K, int32_t N, const float* G, const uint16_t* planes_t, const float* act_below, float* Gout,
@@ -346,6 +351,11 @@ int bg_mlp_layer_backward_split(int32_t M, int32_t K, int32_t N, const float* G,
 typedef struct bg_mlp_chain_split {
     int32_t M, K0, N1, N2, N3;
     int32_t workgroups;
+    /* alternate != 0: odd slabs accumulate the NEGATED sums (the planes of -W: P1 / P2 / P3 then hold both sets, bg_mlp_split_weights_pm) and the
+     * sign is put back where a tile is finished.  The bf16 MFMA's accumulator does not round to nearest: every accumulated element carries a small
+     * bias of one sign (measured: -0.05 of the rms error), which adds up in everything summed over rows downstream (bias and weight gradients);
+     * alternating the sign of the accumulation slab by slab makes the bias cancel.  Same products, same exactness. */
+    int32_t alternate, pad;
     const float* X;
     const uint16_t *P1, *P2, *P3;
     const float *b1, *b2, *b3;
@@ -443,7 +453,7 @@ int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stre
  * produces bias_grad2 [N2] and bias_grad1 [N1] when handed to bg_reduce_group / bg_update_tail.  Widths (N1, N2, N3): (256, 128, 128), (256, 256, 128). */
 typedef struct bg_mlp_chain_split_bwd {
     int32_t M, N1, N2, N3;
-    int32_t workgroups, pad;
+    int32_t workgroups, alternate;   /* alternate: as bg_mlp_chain_split (PT3 / PT2 then hold the planes of W^T and of -W^T) */
     const float* G3;
     const uint16_t *PT3, *PT2;
     const float *A2, *A1;

@@ -12,15 +12,16 @@ DEV = "cuda:0"
 
 
 def _planes(w, n_out, k_out):
+    """the planes of W and, behind them, of -W (bg_mlp_split_weights_pm)"""
     from booster_gym_amd import _lib
 
-    p = torch.empty(n_out * k_out * 3, dtype=torch.int16, device=DEV)
-    _lib.check(_lib.load().bg_mlp_split_weights(n_out, k_out, _lib.ptr(w), w.shape[1], w.shape[0], w.shape[1], 0, _lib.ptr(p), _lib.current_stream_ptr()),
-               "bg_mlp_split_weights")
+    p = torch.zeros(2 * n_out * k_out * 3, dtype=torch.int16, device=DEV)
+    _lib.check(_lib.load().bg_mlp_split_weights_pm(n_out, k_out, _lib.ptr(w), w.shape[1], w.shape[0], w.shape[1], 0, _lib.ptr(p), _lib.current_stream_ptr()),
+               "bg_mlp_split_weights_pm")
     return p
 
 
-def _case(M, dims, seed, k_real=None, wgs=0):
+def _case(M, dims, seed, k_real=None, wgs=0, alternate=1):
     from booster_gym_amd import _lib
 
     K0, N1, N2, N3 = dims
@@ -37,7 +38,7 @@ def _case(M, dims, seed, k_real=None, wgs=0):
     ys = [torch.full((pad, n), float("nan"), device=DEV) for n in (N1, N2, N3)]
     Ps = [_planes(Ws[0], N1, K0), _planes(Ws[1], N2, N1), _planes(Ws[2], N3, N2)]
     p = _lib.ptr
-    d = _lib.MlpChainSplit(M, K0, N1, N2, N3, wgs, p(x), p(Ps[0]), p(Ps[1]), p(Ps[2]), p(bs[0]), p(bs[1]), p(bs[2]), p(ys[0]), p(ys[1]), p(ys[2]), None, None, None)
+    d = _lib.MlpChainSplit(M, K0, N1, N2, N3, wgs, alternate, 0, p(x), p(Ps[0]), p(Ps[1]), p(Ps[2]), p(bs[0]), p(bs[1]), p(bs[2]), p(ys[0]), p(ys[1]), p(ys[2]), None, None, None)
     return d, x, Ws, bs, ys, Ps
 
 
@@ -85,6 +86,36 @@ def test_split_chain_forward_matches_float64_as_well_as_the_fp32_chain(M, dims, 
     _lib.check(_lib.load().bg_mlp_chain_forward_split(ctypes.addressof(d), 1, _lib.current_stream_ptr()), "bg_mlp_chain_forward_split")
     stats = _check(M, dims, x, Ws, bs, ys)
     print(f"split chain M={M} dims={dims}: (rms, rms fp32-MFMA, max, max fp32-MFMA) per layer = {stats}")
+
+
+def test_alternating_the_sign_of_the_accumulation_removes_the_bias():
+    """The bf16 MFMA's accumulator does not round to nearest: measured, a POSITIVE accumulated value comes out low and a negative one unbiased, so
+    accumulated the plain way every output carries a bias of one sign (mean signed error 7 % of the rms error here) that everything summed over rows
+    downstream collects.  With `alternate` odd slabs accumulate the negated sums: same exact products, same rms error, and the bias becomes
+    sign-symmetric (toward zero, half the size): it cancels in sums of values of both signs -- the gradients; tests/test_gpu_mlp_chain_split_bwd.py
+    shows the column sums at the fp32 kernels' level -- and is halved in the mean of these all-but-positive ELU outputs.  Also: the planes of -W are
+    the planes of W with the sign bits flipped."""
+    from booster_gym_amd import _lib
+
+    M, dims = 98304, (64, 256, 256, 128)
+    out = {}
+    for alt in (0, 1):
+        d, x, Ws, bs, ys, Ps = _case(M, dims, seed=5, k_real=61, alternate=alt)
+        _lib.check(_lib.load().bg_mlp_chain_forward_split(ctypes.addressof(d), 1, _lib.current_stream_ptr()), "bg_mlp_chain_forward_split")
+        ref = x.double()[:, :61]
+        for l in range(3):
+            ref = torch.nn.functional.elu(ref @ Ws[l].double().t() + bs[l].double())
+        err = ys[2][:M].double() - ref
+        out[alt] = (err.mean().abs().item(), err.pow(2).mean().sqrt().item())
+        half = Ps[1].numel() // 2
+        assert torch.equal(Ps[1][:half] ^ -32768, Ps[1][half:])   # (int16 view: xor with the sign bit)
+    zs = _fp32_chain(M, dims, x, Ws, bs)
+    e32 = zs[2][:M].double() - ref
+    bias32, rms32 = e32.mean().abs().item(), e32.pow(2).mean().sqrt().item()
+    (bias0, rms0), (bias1, rms1) = out[0], out[1]
+    print(f"layer 3 outputs, |mean signed error| / rms: plain {bias0:.2e} / {rms0:.2e}, alternating {bias1:.2e} / {rms1:.2e}, fp32 MFMA {bias32:.2e} / {rms32:.2e}")
+    assert rms1 <= 1.05 * rms0 and rms1 <= 1.05 * rms32
+    assert bias1 <= 0.6 * bias0 and bias0 > 5.0 * bias32
 
 
 def test_split_chain_value_head_group_and_bad_arguments():

@@ -17,12 +17,12 @@ def _planes_t(w):
     from booster_gym_amd import _lib
 
     k, n = w.shape
-    p = torch.empty(n * k * 3, dtype=torch.int16, device=DEV)
-    _lib.check(_lib.load().bg_mlp_split_weights(n, k, _lib.ptr(w), n, k, n, 1, _lib.ptr(p), _lib.current_stream_ptr()), "bg_mlp_split_weights")
+    p = torch.zeros(2 * n * k * 3, dtype=torch.int16, device=DEV)   # (the planes of W^T, then of -W^T)
+    _lib.check(_lib.load().bg_mlp_split_weights_pm(n, k, _lib.ptr(w), n, k, n, 1, _lib.ptr(p), _lib.current_stream_ptr()), "bg_mlp_split_weights_pm")
     return p
 
 
-def _case(M, dims, seed, wgs=0):
+def _case(M, dims, seed, wgs=0, alternate=1):
     from booster_gym_amd import _lib
 
     N1, N2, N3 = dims
@@ -43,7 +43,7 @@ def _case(M, dims, seed, wgs=0):
     b2, b1 = torch.full((N2,), float("nan"), device=DEV), torch.full((N1,), float("nan"), device=DEV)
     P3, P2 = _planes_t(W3), _planes_t(W2)
     p = _lib.ptr
-    d = _lib.MlpChainSplitBwd(M, N1, N2, N3, wgs, 0, p(G3), p(P3), p(P2), p(A2), p(A1), p(G2), p(G1), p(part), p(b2), p(b1))
+    d = _lib.MlpChainSplitBwd(M, N1, N2, N3, wgs, alternate, p(G3), p(P3), p(P2), p(A2), p(A1), p(G2), p(G1), p(part), p(b2), p(b1))
     return d, dict(G3=G3, W3=W3, W2=W2, A2=A2, A1=A1, G2=G2, G1=G1, part=part, b2=b2, b1=b1, P3=P3, P2=P2)
 
 
@@ -68,12 +68,12 @@ def _fp32_layers(M, t):
     return outs
 
 
-def _run_and_check(M, dims, wgs, seed):
+def _run_and_check(M, dims, wgs, seed, alternate=1):
     from booster_gym_amd import _lib
     from booster_gym_amd.utils.utils import reduce_group
 
     lib, st = _lib.load(), _lib.current_stream_ptr()
-    d, t = _case(M, dims, seed, wgs)
+    d, t = _case(M, dims, seed, wgs, alternate)
     fin = _lib.ReduceProblem()
     _lib.check(lib.bg_mlp_chain_backward_split(ctypes.addressof(d), 1, fin, st), "bg_mlp_chain_backward_split")
     reduce_group([fin])
@@ -91,7 +91,10 @@ def _run_and_check(M, dims, wgs, seed):
         assert err <= 2.0 * err32 + 1e-7 and rms <= 1.05 * rms32 + 1e-9, (name, err, err32, rms, rms32)
         cs = ref.sum(0)
         cerr, cerr32 = (b.double() - cs).abs().max().item(), (zb.double() - cs).abs().max().item()
-        assert torch.isfinite(b).all() and cerr <= 1.5 * cerr32 + 2e-5 * cs.abs().max().item(), (name, cerr, cerr32)
+        # the column sums (bias gradients): with the alternating accumulation at the fp32 kernels' level (3 x + 1e-6 of the largest sum: both are a few
+        # units of fp32 rounding of sums over up to 98,304 rows); accumulated the plain way the MFMA's rounding bias adds up over the rows (looser bound)
+        slack = (3.0 * cerr32 + 1e-6 * cs.abs().max().item()) if alternate else (1.5 * cerr32 + 2e-5 * cs.abs().max().item())
+        assert torch.isfinite(b).all() and cerr <= slack, (name, cerr, cerr32)
         stats.append((name, rms, rms32, err, err32, cerr, cerr32))
     return t, stats
 
@@ -103,6 +106,13 @@ def _run_and_check(M, dims, wgs, seed):
 def test_split_chain_backward_matches_float64_as_well_as_the_fp32_layers(M, dims, wgs):
     t, stats = _run_and_check(M, dims, wgs, seed=M + dims[1] + wgs)
     print(f"split backward chain M={M} dims={dims} wgs={wgs}: (name, rms, rms fp32-MFMA, max, max fp32-MFMA, colsum err, colsum err fp32-MFMA) = {stats}")
+
+
+def test_plain_accumulation_still_works_and_shows_the_bias_the_alternation_removes():
+    t, plain = _run_and_check(98304, (256, 256, 128), 160, seed=9, alternate=0)
+    t, alt = _run_and_check(98304, (256, 256, 128), 160, seed=9, alternate=1)
+    print(f"column-sum error (G2, G1): plain {plain[0][5]:.2e} {plain[1][5]:.2e}, alternating {alt[0][5]:.2e} {alt[1][5]:.2e}, fp32 MFMA {alt[0][6]:.2e} {alt[1][6]:.2e}")
+    assert alt[0][5] < 0.5 * plain[0][5] and alt[1][5] < 0.5 * plain[1][5]
 
 
 def test_split_chain_backward_is_deterministic_groups_and_refusals():
