@@ -7,10 +7,13 @@ A "step" is one PPO iteration on synthetic (randomly initialised) policy weights
 HIP simulator + 20 full-batch optimiser steps (BASELINE.json configs[1], flat terrain).  Rank 0 prints
 ONE JSON line.  `value` = world * N * T * K / wall (max over ranks).
 
-`roofline` = the symbols with the largest total time in this round's rocprofv3 summary of this command (profiles/r05_bench_kernel_stats.csv): the
-two networks' chained forward launches, priced over the span of each mini-epoch's pair; `roofline_wgrad` = the grouped weight gradients (the largest
-single launch); `roofline_backward` = both backward-data chains over their span; `roofline_env_step`, `roofline_aba` = the simulator kernels against the HBM roof; `other_configs` = BASELINE configs[2] and [4]
-through the same loop; `cpu_baseline` = the oracle's CPU restatement of the same workload on the host cores.
+`roofline` = the two networks' chained forward launches (bg_mlp_chain_split.hip: fp32 operands as exact three-way bf16 splits, all 9 products on the
+bf16 matrix pipe, fp32 accumulation), priced over the span of each mini-epoch's pair, against the 9-product equivalent of the bf16 pipe's peak AND
+against the fp32 matrix pipe's; `roofline_backward` = both backward-data chains (bg_mlp_chain_split_bwd.hip) over their span; `roofline_wgrad` = the
+grouped weight gradients (fp32 MFMA: the largest single launch of the iteration, profiles/r06_bench_kernel_stats.csv); `fp32_mfma_loop` = the SAME loop in
+the same run with both chains on the fp32 matrix pipe (last round's headline path); `gemm_errors_vs_float64` = the measured error pair (split chain,
+fp32-MFMA kernels) of each GEMM family; `roofline_env_step`, `roofline_aba` = the simulator kernels against the HBM roof; `other_configs` = BASELINE
+configs[2] and [4] through the same loop; `cpu_baseline` = the oracle's CPU restatement of the same workload on the host cores.
 """
 import argparse
 import ctypes
@@ -27,6 +30,8 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0      # MI355X spec (MI355X_MICROARCH.md: 8.0 TB/s spec, 6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak (same guide)
+MFMA_BF16_PEAK_TF = 2516.6 # bf16 MFMA dense peak (same guide: 16 x the fp32-input rate)
+SPLIT9_PEAK_TF = MFMA_BF16_PEAK_TF / 9.0  # fp32-exact flops per second of the bf16 pipe when every fp32 x fp32 product costs 9 bf16 x bf16 products
 
 # Algorithmic HBM bytes of the fused env-step kernel per env per env-step: every per-env field it reads
 # or writes once per launch, 4 bytes each.
@@ -58,7 +63,7 @@ ABA_BYTES = 4 * (13 + 12 + 12 + 12 + 6 + 18 + 6 + 58)  # forward_dynamics_kernel
 from booster_gym_amd import _lib  # noqa: E402  (raw ABI calls for the kernel-level timings)
 
 
-PMC_TAG = "r05"
+PMC_TAG = "r06"
 KERNEL_EVENTS_EVERY = 4  # the timed region's iterations whose kernels are bracketed by HIP timing events (see arm_kernel_events)
 PMC_SOURCE = (f"profiles/{PMC_TAG}_bench_pmc.json / profiles/{PMC_TAG}_env_pmc.json: rocprofv3 --kernel-trace --pmc FETCH_SIZE | WRITE_SIZE in separate passes of "
               "`bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra` and `tools/prof_env.py 4096 plane` (tools/profile.sh); "
@@ -232,6 +237,48 @@ def cpu_baseline(n_envs=4096):
     return out
 
 
+def gemm_error_pairs(rows=16384):
+    """Measured error against float64 of each GEMM family of the update, the split-bf16 chain beside the fp32-MFMA kernels of the same op on the same
+    inputs (the weights and the layer shapes of the two networks, synthetic inputs of the update's scale): rms, largest, and mean signed error."""
+    import ctypes as C
+
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import test_gpu_mlp_chain_split as TF
+    import test_gpu_mlp_chain_split_bwd as TB
+
+    lib, st = _lib.load(), _lib.current_stream_ptr()
+
+    def stat(y, ref):
+        e = y.double() - ref
+        return {"rms": float(e.pow(2).mean().sqrt()), "max": float(e.abs().max()), "mean_signed": float(e.mean())}
+
+    out = {}
+    for name, dims, kr in (("critic", (64, 256, 256, 128), 61), ("actor", (64, 256, 128, 128), 47)):
+        d, x, Ws, bs, ys, Ps = TF._case(rows, dims, seed=7, k_real=kr)
+        _lib.check(lib.bg_mlp_chain_forward_split(C.addressof(d), 1, st), "bg_mlp_chain_forward_split")
+        zs = TF._fp32_chain(rows, dims, x, Ws, bs)
+        ref = x.double()[:, :kr]
+        for l in range(3):
+            ref = torch.nn.functional.elu(ref @ Ws[l].double().t() + bs[l].double())
+            out[f"forward_{name}_layer{l + 1}"] = {"split9_chain": stat(ys[l][:rows], ref), "fp32_mfma_chain": stat(zs[l][:rows], ref)}
+        bd = (dims[1], dims[2], dims[3])
+        db, t = TB._case(rows, bd, 7, 0)
+        fin = _lib.ReduceProblem()
+        _lib.check(lib.bg_mlp_chain_backward_split(C.addressof(db), 1, fin, st), "bg_mlp_chain_backward_split")
+        from booster_gym_amd.utils.utils import reduce_group
+        reduce_group([fin])
+        r2 = (t["G3"].double() @ t["W3"].double()) * TB._elup(t["A2"][:rows].double())
+        r1 = (r2 @ t["W2"].double()) * TB._elup(t["A1"][:rows].double())
+        f32 = TB._fp32_layers(rows, t)
+        for nm, y, ref, (z, zb), b in (("G2", t["G2"], r2, f32[0], t["b2"]), ("G1", t["G1"], r1, f32[1], t["b1"])):
+            out[f"backward_{name}_{nm}"] = {"split9_chain": stat(y[:rows], ref), "fp32_mfma_layers": stat(z, ref)}
+            out[f"backward_{name}_bias_gradient_of_{nm}"] = {"split9_chain": stat(b, ref.sum(0)), "fp32_mfma_layers": stat(zb, ref.sum(0))}
+    out["note"] = (f"{rows} rows of N(0, 1) inputs / N(0, 0.01) gradients through the two networks' layer shapes with 1 / sqrt(fan-in) weights (tests/test_gpu_mlp_chain_split*.py hold "
+                   "the same comparison at 98,304 rows); weight gradients are fp32 MFMA in both loops.  The bf16 MFMA's accumulator does not round to nearest (a positive sum comes out "
+                   "low): odd slabs accumulate the negated sums, which makes the bias sign-symmetric and lets it cancel in sums over rows (DESIGN.md section 5)")
+    return out
+
+
 def _free_port():
     import socket
 
@@ -364,6 +411,12 @@ def main():
     wall = float(tw.item())
 
     log(f"timed region done: {wall:.3f}s for {args.steps} iterations")
+    slow_phase = None
+    if world > 1:  # the largest rollout / update time over the ranks (one line must show a straggler)
+        ph = torch.tensor([sum(a.elapsed_time(b) for a, b, _ in phase_events) / len(phase_events), sum(b.elapsed_time(c) for _, b, c in phase_events) / len(phase_events)],
+                          dtype=torch.float64, device=dev)
+        dist.all_reduce(ph, op=dist.ReduceOp.MAX)
+        slow_phase = {"rollout": float(ph[0].item()), "update": float(ph[1].item())}
     if rank == 0:
         step_ms = sum(a.elapsed_time(b) for a, b in step_events) / max(len(step_events), 1)
         roll_ms = sum(a.elapsed_time(b) for a, b, _ in phase_events) / len(phase_events)
@@ -412,36 +465,47 @@ def main():
         rows_c, rows_a = evc[0][2], eva[0][2]
         fl_c, fl_a = chain_flop(runner._critic_tr, rows_c), chain_flop(runner._actor_tr, rows_a)
         full = rows_c == (T + 1) * 4096
-        tr_c = (pmc_traffic("mlp_chain_fwd_kernel<2>"), pmc_traffic("mlp_chain_fwd_kernel<1>")) if full else (None, None)
+        split_fwd = runner._critic_tr._chain_split() and runner._actor_tr._chain_split()
+        split_bwd = runner._critic_tr._chain_split_bwd() and runner._actor_tr._chain_split_bwd()
+        kc_name, ka_name = ("mlp_chain_split_fwd_kernel<2>", "mlp_chain_split_fwd_kernel<1>") if split_fwd else ("mlp_chain_fwd_kernel<2>", "mlp_chain_fwd_kernel<1>")
+        tr_c = (pmc_traffic(kc_name), pmc_traffic(ka_name)) if full else (None, None)
         tf = (fl_c + fl_a) / (span_us * 1e-6) / 1e12
-        headline = {"kernel": f"mlp_chain_fwd_kernel<2> + mlp_chain_fwd_kernel<1>: the critic's and the actor's three fused Linear+bias+ELU hidden layers, one launch per "
-                              f"network ([{rows_c}x61] -> 256 -> 256 -> 128 and [{rows_a}x47] -> 256 -> 128 -> 128, activations handed on in registers, fp32 MFMA 32x32x2, "
-                              "hand-written HIP, bg_mlp_chain.hip); the two launches of a mini-epoch overlap on two streams",
-                    "bound": "mfma", "achieved": tf, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": tf / MFMA_F32_PEAK_TF,
+        fwd_peak = SPLIT9_PEAK_TF if split_fwd else MFMA_F32_PEAK_TF
+        arith = ("fp32 operands as exact three-way bf16 splits, all 9 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, bg_mlp_chain_split.hip"
+                 if split_fwd else "fp32 MFMA 32x32x2, bg_mlp_chain.hip")
+        headline = {"kernel": f"{kc_name} + {ka_name}: the critic's and the actor's three fused Linear+bias+ELU hidden layers, one launch per "
+                              f"network ([{rows_c}x61] -> 256 -> 256 -> 128 and [{rows_a}x47] -> 256 -> 128 -> 128, activations handed on in registers, {arith}, "
+                              "hand-written HIP); the two launches of a mini-epoch overlap on two streams",
+                    "bound": "mfma", "achieved": tf, "peak": fwd_peak, "unit": "TFLOP/s", "frac": tf / fwd_peak,
+                    "peak_note": (f"peak = {MFMA_BF16_PEAK_TF} TF/s dense bf16 MFMA / 9 products per fp32 x fp32 product = {SPLIT9_PEAK_TF:.1f} TF/s of fp32-exact flops; "
+                                  "`achieved` counts the algorithmic fp32 flops once") if split_fwd else "fp32-input MFMA dense peak",
+                    "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TF, "fp32_mfma_peak": MFMA_F32_PEAK_TF,
                     "traffic": (tr_c[0] + tr_c[1]) if all(tr_c) else None, "traffic_source": PMC_SOURCE,
                     "avg_launch_us": span_us, "algorithmic_flops_per_launch": fl_c + fl_a,
                     "note": "flops of both launches (real input columns) / time from the first start to the last end of the pair, HIP events on the two launch "
                             "streams inside the timed loop; the pair's own durations are in per_kernel_in_the_loop",
-                    "per_kernel_in_the_loop": {"mlp_chain_fwd_kernel<2>": {"avg_launch_us": c_loop_us, "algorithmic_flops": fl_c, "traffic": tr_c[0]},
-                                               "mlp_chain_fwd_kernel<1>": {"avg_launch_us": a_loop_us, "algorithmic_flops": fl_a, "traffic": tr_c[1]}}}
-        layer_fwd = {"kernel": f"mlp_chain_fwd_kernel<2>: the critic's chained forward launch, [{rows_c}x61] -> 256 -> 256 -> 128", "bound": "mfma",
-                     "achieved": fl_c / (c_loop_us * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": fl_c / (c_loop_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+                    "per_kernel_in_the_loop": {kc_name: {"avg_launch_us": c_loop_us, "algorithmic_flops": fl_c, "traffic": tr_c[0]},
+                                               ka_name: {"avg_launch_us": a_loop_us, "algorithmic_flops": fl_a, "traffic": tr_c[1]}}}
+        layer_fwd = {"kernel": f"{kc_name}: the critic's chained forward launch, [{rows_c}x61] -> 256 -> 256 -> 128", "bound": "mfma",
+                     "achieved": fl_c / (c_loop_us * 1e-6) / 1e12, "peak": fwd_peak, "unit": "TFLOP/s", "frac": fl_c / (c_loop_us * 1e-6) / 1e12 / fwd_peak,
+                     "frac_of_fp32_mfma_peak": fl_c / (c_loop_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
                      "traffic": tr_c[0], "traffic_source": PMC_SOURCE, "avg_launch_us": c_loop_us, "algorithmic_flops_per_launch": fl_c,
                      "note": "timed inside the loop, where the actor's launch runs beside it on the second stream"}
         if not args.no_extra:
             # the same launches with nothing beside them (hidden layers only: the critic's value head is left out of the stand-alone launch)
+            from booster_gym_amd.utils.model import MLPTrainer as _MLPT
             alone = {}
-            for name, tr, fl in (("mlp_chain_fwd_kernel<2>", runner._critic_tr, fl_c), ("mlp_chain_fwd_kernel<1>", runner._actor_tr, fl_a)):
+            for name, tr, fl in ((kc_name, runner._critic_tr, fl_c), (ka_name, runner._actor_tr, fl_a)):
                 keep, tr.value_head = tr.value_head, None
                 d = tr._chain_descriptor()
                 tr.value_head = keep
-                us = solo_us(lambda: _lib.check(lib.bg_mlp_chain_forward_group(ctypes.addressof(d), 1, _lib.current_stream_ptr()), "bg_mlp_chain_forward_group"))
-                alone[name] = {"avg_launch_us": us, "achieved": fl / (us * 1e-6) / 1e12, "frac": fl / (us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+                us = solo_us(lambda: _MLPT.launch_chain([d]))
+                alone[name] = {"avg_launch_us": us, "achieved": fl / (us * 1e-6) / 1e12, "frac": fl / (us * 1e-6) / 1e12 / fwd_peak,
                                # the loop's own launch geometry: a persistent grid on this network's share of the CUs (Runner._plan_chain_split), so
                                # "alone" = nothing beside it on the chip, not "on all CUs"
                                "workgroups": int(tr.chain_workgroups) or "one per 128-row slab"}
             headline["alone_on_the_gpu"] = alone
-            layer_fwd["alone_on_the_gpu"] = alone["mlp_chain_fwd_kernel<2>"]
+            layer_fwd["alone_on_the_gpu"] = alone[kc_name]
         wg_ev = wgrad_events
         wgrad = None
         if wg_ev:  # all six hidden-layer weight gradients of both networks: one launch pair per mini-epoch, alone on the GPU
@@ -470,14 +534,20 @@ def main():
                 bspans.append(first.elapsed_time(last))
             bus = sum(bspans) / len(bspans) * 1e3
             bfl = bwc[0][3] + bwa[0][3]
-            backward = {"kernel": "mlp_fwd_kernel<256,2,2> / <128,2,2> / <128,2,1>: the backward-data GEMMs of both networks' hidden layers (dX = G W with ELU' and the "
-                                  "bias-gradient column sums in the epilogue), two chains of two launches on two streams",
-                        "bound": "mfma", "achieved": bfl / (bus * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s", "frac": bfl / (bus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+            bwd_peak = SPLIT9_PEAK_TF if split_bwd else MFMA_F32_PEAK_TF
+            backward = {"kernel": ("mlp_chain_split_bwd_kernel<0> / <1>: the backward-data pass of each network's hidden layers as ONE launch (G2 = (G3 W3) elu'(A2), "
+                                   "G1 = (G2 W2) elu'(A1), bias-gradient column sums; fp32 operands as exact three-way bf16 splits, 9 products, fp32 accumulation, "
+                                   "bg_mlp_chain_split_bwd.hip), two launches on two streams") if split_bwd else
+                                  ("mlp_fwd_kernel<256,2,2> / <128,2,2> / <128,2,1>: the backward-data GEMMs of both networks' hidden layers (dX = G W with ELU' and the "
+                                   "bias-gradient column sums in the epilogue), two chains of two launches on two streams"),
+                        "bound": "mfma", "achieved": bfl / (bus * 1e-6) / 1e12, "peak": bwd_peak, "unit": "TFLOP/s", "frac": bfl / (bus * 1e-6) / 1e12 / bwd_peak,
+                        "frac_of_fp32_mfma_peak": bfl / (bus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
                         "avg_launch_us": bus, "algorithmic_flops_per_launch": bfl,
                         "per_chain_in_the_loop_us": {"critic": sum(a.elapsed_time(b) for a, b, *_ in bwc) / len(bwc) * 1e3,
                                                      "actor": sum(a.elapsed_time(b) for a, b, *_ in bwa) / len(bwa) * 1e3},
                         "note": "flops of both chains / time from the first start to the last end of the pair, HIP events on the two launch streams inside the timed "
-                                "loop; the head kernels (loss + output layers) run at the front of the same span"}
+                                "loop; the head kernels (loss + output layers) run at the front of the same span.  The kernel runs against the CU's vector-memory "
+                                "pipeline, not the matrix pipe (profiles/r06_chain_split_bwd_stamps.txt)"}
         out = {
             "metric": "env-steps/sec (whole node), PPO rollout+update, T1 4096 envs/GPU",
             "value": world * N * T * args.steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -485,8 +555,15 @@ def main():
             "data": "synthetic (random-init policy, seeded domain randomisation)",
             "config": {"workload": f"T1 {args.terrain} terrain, {N} envs/GPU, horizon {T}, {E} mini-epochs, full batch (BASELINE.json configs[1])",
                        "envs_per_gpu": N, "parallelism": f"dp{world}",
-                       "gemm_arithmetic": {0: "fp32 MFMA (v_mfma_f32_32x32x2_f32)", 9: "fp32 operands as exact 3-way bf16 splits, 9 products, fp32 accumulate (BG_GEMM_SPLIT=9)",
-                                           6: "fp32 operands as exact 3-way bf16 splits, 6 largest products, fp32 accumulate (BG_GEMM_SPLIT=6)"}[split_mode]},
+                       "gemm_arithmetic": ({9: "fp32 operands as exact 3-way bf16 splits, 9 products, fp32 accumulate (BG_GEMM_SPLIT=9, per-layer kernels)",
+                                            6: "fp32 operands as exact 3-way bf16 splits, 6 largest products, fp32 accumulate (BG_GEMM_SPLIT=6, per-layer kernels)"}[split_mode]
+                                           if split_mode else
+                                           ("hidden-layer forward" + (" and backward-data" if split_bwd else "") + " GEMMs: every fp32 operand the EXACT sum of three bf16 numbers "
+                                            "(8 + 8 + 8 significant bits), all 9 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- products exact as in an fp32 FMA "
+                                            "chain, measured error against float64 at or below the fp32-MFMA kernels' (gemm_errors_vs_float64)"
+                                            + ("" if split_bwd else "; backward-data") + "; weight gradients, heads, rollout actor: fp32 MFMA (v_mfma_f32_32x32x2_f32 / "
+                                            "16x16x4_f32).  `fp32_mfma_loop`: the same loop with everything on the fp32 matrix pipe") if split_fwd else
+                                           "fp32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms, "all_reduce_ms": ar_ms},
             "kernel_events": {"armed_on_every": KERNEL_EVENTS_EVERY, "iterations_armed": len(armed_ms), "of": args.steps,
@@ -512,17 +589,57 @@ def main():
             out["roofline_wgrad"] = wgrad
         if backward is not None:
             out["roofline_backward"] = backward
+        if world > 1:
+            # what one SCALE record needs to tell a bad queue mapping or a fallback communicator from a slow fabric
+            out["multi_rank"] = {"GPU_MAX_HW_QUEUES": os.environ.get("GPU_MAX_HW_QUEUES"), "own_rccl": runner.dp.comm is not None,
+                                 "backend": runner.dp.backend, "exchange_ms_per_mini_epoch": ex_ms or None, "phase_ms_slowest_rank": slow_phase,
+                                 "note": "exchange times are rank 0's (collective + waiting for the slowest rank); phase_ms_slowest_rank: the largest rollout / update time over the ranks"}
         if world == 1 and not args.no_extra:
+            try:
+                # The same loop, same run, same timing with BOTH chains on the fp32 matrix pipe (last round's headline path: bg_mlp_chain.hip forward,
+                # bg_mlp_layer_backward per layer): what a reader who does not accept the 9-product arithmetic as fp32 falls back on.  NOT part of `value`.
+                from booster_gym_amd.utils.model import MLPTrainer
+
+                runner.rollout, runner.update, runner.env.step_to = orig_rollout, orig_update, orig_step_to
+                runner._critic_tr.timed_layer, runner._actor_tr.timed_layer, runner._wgrad_group.timed_events = None, None, None
+                it0 = args.warmup + args.steps
+
+                def timed_loop(it0):
+                    runner.invalidate()
+                    for _ in range(2):
+                        runner.train_iteration(it0); it0 += 1
+                    torch.cuda.synchronize()
+                    ts = time.perf_counter()
+                    for _ in range(args.steps):
+                        runner.train_iteration(it0); it0 += 1
+                    torch.cuda.synchronize()
+                    dt = time.perf_counter() - ts
+                    return it0, {"value": N * T * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3}
+
+                keep = (MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD)
+                MLPTrainer.CHAIN_SPLIT = MLPTrainer.CHAIN_SPLIT_BWD = False
+                it0, fp32 = timed_loop(it0)
+                MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD = True, False
+                it0, fwd_only = timed_loop(it0)
+                MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD = keep
+                it0, again = timed_loop(it0)
+                runner._flush_log()
+                fp32["gemm_arithmetic"] = "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: BG_CHAIN_SPLIT=0"
+                out["fp32_mfma_loop"] = fp32
+                out["split_forward_only_loop"] = dict(fwd_only, gemm_arithmetic="split forward chain, fp32-MFMA backward layers: BG_CHAIN_SPLIT_BWD=0")
+                out["headline_loop_again"] = dict(again, note="the headline configuration once more behind the two above, uninstrumented (no timing events): what `value` is to be compared with")
+            except Exception as ex:
+                out["fp32_mfma_loop"] = {"error": repr(ex)}
+            try:
+                out["gemm_errors_vs_float64"] = gemm_error_pairs()
+            except Exception as ex:
+                out["gemm_errors_vs_float64"] = {"error": repr(ex)}
             try:
                 # Opt-in form of the layer kernels, measured beside the headline and NOT part of `value`: BG_GEMM_SPLIT (bg_mlp_split.hip) runs the
                 # fp32 x fp32 products of the hidden-layer forward / backward GEMMs on the bf16 matrix pipe, every fp32 operand split EXACTLY into
                 # three bf16 numbers (all 9 cross products: no rounding of the products, fp32 accumulation; 6: the three smallest dropped);
                 # so does the grouped weight-gradient launch (bg_wgrad_split.hip).  Same loop, same workload, same timing as `value`.
-                from booster_gym_amd.utils.model import MLPTrainer
-
-                runner.rollout, runner.update, runner.env.step_to = orig_rollout, orig_update, orig_step_to
-                runner._critic_tr.timed_layer, runner._actor_tr.timed_layer, runner._wgrad_group.timed_events = None, None, None
-                split, it0 = {}, args.warmup + args.steps
+                split = {}
                 for terms in (9, 6):
                     MLPTrainer.SPLIT = terms
                     for _ in range(2):
@@ -536,9 +653,9 @@ def main():
                     split[f"products_{terms}"] = {"value": N * T * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3}
                 MLPTrainer.SPLIT = split_mode
                 runner._flush_log()
-                split["note"] = ("opt-in (BG_GEMM_SPLIT=9|6), not the headline: hidden-layer forward / backward / weight-gradient GEMMs as exact hi/mid/lo "
-                                 "bf16 splits of the fp32 operands on v_mfma_f32_32x32x16_bf16, fp32 accumulate; tests/test_gpu_mlp_split.py holds the error "
-                                 "against float64 beside the fp32-MFMA kernels'")
+                split["note"] = ("opt-in (BG_GEMM_SPLIT=9|6), not the headline and superseded by the chained kernels: one launch per layer (forward / backward / "
+                                 "grouped weight gradients) as exact hi/mid/lo bf16 splits on v_mfma_f32_32x32x16_bf16, fp32 accumulate; products_6 drops the three "
+                                 "smallest cross products and is NOT fp32-exact; tests/test_gpu_mlp_split.py holds the errors against float64")
                 out["opt_in_split_bf16_layers"] = split
             except Exception as ex:
                 out["opt_in_split_bf16_layers"] = {"error": repr(ex)}

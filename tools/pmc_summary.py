@@ -39,7 +39,7 @@ def summarise(passes, keep, command):
     for k, cs in sorted(named.items()):
         e = {c: {"mean": sum(v) / len(v), "launches": len(v)} for c, v in sorted(cs.items())}
         if "FETCH_SIZE" in e and "WRITE_SIZE" in e:
-            wide = any(s in k for s in ("mlp_fwd_kernel", "mlp_chain_fwd_kernel", "mlp_wgrad"))
+            wide = any(s in k for s in ("mlp_fwd_kernel", "mlp_chain", "mlp_wgrad"))
             e["wide16"] = wide
             e["hbm_bytes"] = ((2.0 if wide else 1.0) * e["FETCH_SIZE"]["mean"] + e["WRITE_SIZE"]["mean"]) * 1024.0
         ks[k] = e
