@@ -4,16 +4,25 @@ Same surface: `Runner(test=False)` parses the reference's 8 CLI flags (runner.py
 `envs/<task>.yaml` (:57-68), seeds (:70-80), builds env / model / Adam / buffers (:27-42), `_load` (:82-97),
 `train()` (:99-215) and `play()` (:217-241).  What changed is how an iteration executes:
 
-  rollout   per env-step: ONE fused actor+sample launch (bg_actor_sample) and ONE env launch (bg_env_step_to) that
-            writes obs / privileged obs / reward / done / time-out directly into rows of the experience buffer;
-            no `.to(device)` copies, no per-done-env `.item()` (runner.py:112-121).
-  update    per mini-epoch: critic + actor GEMMs through PyTorch-ROCm (fp32 MFMA) on a hand-scheduled forward/backward
-            (model.MLPTrainer: split-K weight gradients, fused ELU-backward + bias gradient), GAE as one backward scan (bg_gae),
-            the whole loss forward+backward as one pass (bg_ppo_loss), global-norm clip +
-            Adam on one flat buffer (bg_adam_step) and the KL-adaptive learning rate on the device (bg_adapt_lr): no host
-            sync inside the 20 mini-epochs (reference: 4 per mini-epoch, runner.py:175,182-184).
-  multi-GPU one process per GPU (torchrun), environments sharded, three all-reduces per mini-epoch on RCCL: advantage
-            moments (3 doubles), the flat gradient (177,945 floats), loss/KL sums (5 doubles) -- SURVEY section 8e.
+  rollout   per env-step: ONE fused actor+sample launch (bg_actor_sample) and ONE env launch (bg_env_step_to) that writes obs / privileged obs /
+            reward / done / time-out directly into rows of the experience buffer -- no `.to(device)` copies, no per-done-env `.item()`
+            (runner.py:112-121).  Beside them, on the side stream, the FIRST mini-epoch's forward passes of both networks on each step's rows as soon
+            as they exist (same kernels, same weights as the update: bit-identical).
+  update    per mini-epoch, two streams (critic on the side stream, actor on the main one), no host sync inside the 20 mini-epochs (reference: 4
+            per mini-epoch, runner.py:175,182-184):
+              forward        the three hidden layers of a network as ONE launch (utils/model.py MLPTrainer -> bg_mlp_chain_forward_split: fp32 operands
+                             as exact three-way bf16 splits, all 9 products on the bf16 matrix pipe, fp32 accumulation; BG_CHAIN_SPLIT=0: the
+                             fp32-MFMA chain bg_mlp_chain_forward_group), the critic's values from the registers of that launch;
+              GAE            bg_critic_values_gae: time-out bootstrap, GAE scan, returns, advantage moments in one launch;
+              heads + loss   output layers fused with the PPO loss and its backward (bg_critic_head_backward, bg_actor_head);
+              backward-data  the hidden layers of a network as ONE launch (bg_mlp_chain_backward_split: same arithmetic, ELU' and bias-gradient sums
+                             in its epilogues; BG_CHAIN_SPLIT_BWD=0: one fp32-MFMA launch per layer);
+              weight grads   all six hidden layers of both networks in one grouped fp32-MFMA launch (bg_mlp_weight_grad_group_partial);
+              tail           two launches (bg_update_tail): the deferred fixed-order sums + the squared-norm pieces, then clip + Adam + KL learning-rate
+                             rule + statistics bookkeeping + the copies of the weights the layer kernels read (bf16 planes of W, -W, W^T, -W^T).
+  multi-GPU one process per GPU (torchrun), environments sharded; per mini-epoch one float64 moments all-reduce on the side stream and ONE grouped RCCL
+            launch on the main stream (gradient bucket mean, loss / KL sums, log-std gradient mean) through an own communicator (utils/rccl.py) --
+            SURVEY section 8e; the enqueue-order contract of the two communicators is written in utils/parallel.py.
 
 Reference quirks kept on purpose: GAE recomputed from the current critic every mini-epoch (Q5), the
 time-out reward overwrite repeated in place (Q4), KL measured with the pre-step distribution (Q6), entropy_coef < 0 (Q7).

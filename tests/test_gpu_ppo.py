@@ -348,6 +348,9 @@ def test_training_is_reproducible_run_to_run():
 SWITCHES = {
     # name: (runner attributes, MLPTrainer class attributes) -- every branch of Runner.update() / MLPTrainer that a switch or a shape can select
     "default": ({}, {}),
+    # (environment switches and the attributes they set: BG_ONE_LAUNCH_TAIL -> _one_launch_tail, BG_SPLIT_CHAIN_CUS -> _split_chain_cus,
+    #  BG_ROLLOUT_FORWARD -> _rollout_forward, BG_ROLLOUT_FORWARD_GROUP -> _rollout_group, BG_DEFER_FINISH -> _defer_finish / _defer_serial (own test below),
+    #  BG_CHAIN_SPLIT / BG_CHAIN_SPLIT_BWD / BG_CHAIN_ALTERNATE -> MLPTrainer.CHAIN_SPLIT / CHAIN_SPLIT_BWD / CHAIN_ALTERNATE; BG_OWN_RCCL: tests/test_gpu_rccl.py)
     "tail_as_three_launches": ({"_one_launch_tail": False}, {}),                  # reduce_group, weight gradients + finish, optimizer_step (what ranks of a job run)
     "separate_optimizer_tail": ({"_fused_opt": False}, {}),                      # bg_adam_step + bg_adapt_lr + torch adds (first step after a restore)
     "gae_as_three_launches": ({"_fused_gae": False}, {}),                        # bg_critic_head_forward + fill + bg_gae (horizons beyond 32 steps)
@@ -356,7 +359,11 @@ SWITCHES = {
     "hidden_layers_one_launch_each": ({}, {"CHAIN": False}),                     # bg_mlp_layer_forward x 3 per network
     "hidden_layers_as_library_gemms": ({}, {"FUSED": False}),                    # torch.addmm + elu_, torch.mm + bg_elu_backward_colsum, bmm weight gradients
     "weight_gradients_as_library_gemms": ({}, {"FUSED_WGRAD": False}),           # split-K bmm + sum
-    "chain_one_workgroup_per_slab": ({"_split_chain_cus": False}, {}),            # the two forward launches share the chip by slabs instead of by CUs
+    "fp32_mfma_chains": ({}, {"CHAIN_SPLIT": False}),                            # BG_CHAIN_SPLIT=0: forward chain and backward layers on the fp32 matrix pipe (round 5's default)
+    "split_forward_fp32_mfma_backward": ({}, {"CHAIN_SPLIT_BWD": False}),        # BG_CHAIN_SPLIT_BWD=0: the chained split forward, one fp32-MFMA launch per backward layer
+    "plain_accumulation": ({}, {"CHAIN_ALTERNATE": False}),                      # BG_CHAIN_ALTERNATE=0: no slab accumulates the negated sums
+    "chain_one_workgroup_per_slab": ({"_split_chain_cus": False}, {}),            # BG_SPLIT_CHAIN_CUS=0: the two forward launches share the chip by slabs instead of by CUs
+    "backward_chain_one_workgroup_per_slab": ({"_split_bwd_chain_cus": False}, {}),  # BG_SPLIT_BWD_CHAIN_CUS=0: ... and the two backward launches
     "rollout_forward_off": ({"_rollout_forward": False}, {}),
     "rollout_forward_one_step_per_group": ({"_rollout_group": 1}, {}),
     "rollout_forward_five_steps_per_group": ({"_rollout_group": 5}, {}),
@@ -405,7 +412,7 @@ def test_update_through_every_switch_matches_the_default(switch, default_update)
     rate.  The rollout-forward variants run the same kernels on the same numbers: identical bits, also after a second iteration."""
     start, (p0, a0, s0), (q0, b0, act0) = default_update
     _, (p1, a1, s1), (q1, b1, act1) = _update_under(switch)
-    if switch.startswith("rollout_forward") or switch == "chain_one_workgroup_per_slab":
+    if switch.startswith("rollout_forward") or switch in ("chain_one_workgroup_per_slab", "backward_chain_one_workgroup_per_slab"):
         assert torch.equal(p1, p0) and torch.equal(a1, a0) and torch.equal(q1, q0) and torch.equal(b1, b0) and torch.equal(act1, act0)
         return
     _assert_same_adam_steps(switch, p1, p0, start)

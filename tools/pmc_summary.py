@@ -21,7 +21,7 @@ def summarise(passes, keep, command):
             raise SystemExit(f"pmc_summary: pass {p} of tools/profile.sh {tag} left no counter CSV under {root}/{p}")
         for f in files:
             for r in csv.DictReader(open(f)):
-                name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+                name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()
                 if any(k in name for k in keep):
                     acc[(name, int(r.get("Grid_Size", 0) or 0))][r["Counter_Name"]].append(float(r["Counter_Value"]))
     # a kernel launched with several grid sizes (the chained forward: whole-batch launches in the update, 64-slab launches during the rollout) is listed
