@@ -453,7 +453,7 @@ int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stre
  * produces bias_grad2 [N2] and bias_grad1 [N1] when handed to bg_reduce_group / bg_update_tail.  Widths (N1, N2, N3): (256, 128, 128), (256, 256, 128). */
 typedef struct bg_mlp_chain_split_bwd {
     int32_t M, N1, N2, N3;
-    int32_t workgroups, alternate;   /* alternate: as bg_mlp_chain_split (PT3 / PT2 then hold the planes of W^T and of -W^T) */
+    int32_t workgroups, alternate;   /* alternate: as in bg_mlp_chain_split; PT3 / PT2 then hold the planes of W^T and of -W^T */
     const float* G3;
     const uint16_t *PT3, *PT2;
     const float *A2, *A1;
