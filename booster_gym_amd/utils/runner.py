@@ -646,6 +646,9 @@ class Runner:
             return
         cost = lambda tr: sum(l.weight.shape[0] * (tr._kin if i == 0 else l.weight.shape[1]) for i, l in enumerate(tr.layers[:3]))
         ct.chain_workgroups, at.chain_workgroups = plan_chain_split(sc, sa, cost(ct), cost(at), cus)
+        fixed = os.environ.get("BG_FWD_CHAIN_CUS")  # "critic,actor": a fixed split (A/B runs)
+        if fixed:
+            ct.chain_workgroups, at.chain_workgroups = (int(v) for v in fixed.split(","))
         # the chained backward launches likewise (both networks differentiate the same rows_a rows; slab cost ~ flops of the two backward layers)
         ct.chain_bwd_workgroups = at.chain_bwd_workgroups = 0
         if self._split_bwd_chain_cus and ct._chain_split_bwd() and at._chain_split_bwd():
