@@ -468,25 +468,35 @@ def main():
         split_fwd = runner._critic_tr._chain_split() and runner._actor_tr._chain_split()
         split_bwd = runner._critic_tr._chain_split_bwd() and runner._actor_tr._chain_split_bwd()
         kc_name, ka_name = ("mlp_chain_split_fwd_kernel<2>", "mlp_chain_split_fwd_kernel<1>") if split_fwd else ("mlp_chain_fwd_kernel<2>", "mlp_chain_fwd_kernel<1>")
+        one_launch = evc[0][0] is eva[0][0]  # both networks in ONE grid (Runner._one_stream): the trainers noted the same event pair
         tr_c = (pmc_traffic(kc_name), pmc_traffic(ka_name)) if full else (None, None)
+        tr_group = pmc_traffic("mlp_chain_split_fwd_kernel<0>") if full and one_launch else None  # (summarised at its largest grid: the update's launch)
         tf = (fl_c + fl_a) / (span_us * 1e-6) / 1e12
         fwd_peak = SPLIT9_PEAK_TF if split_fwd else MFMA_F32_PEAK_TF
         arith = ("fp32 operands as exact three-way bf16 splits, all 9 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, bg_mlp_chain_split.hip"
                  if split_fwd else "fp32 MFMA 32x32x2, bg_mlp_chain.hip")
-        headline = {"kernel": f"{kc_name} + {ka_name}: the critic's and the actor's three fused Linear+bias+ELU hidden layers, one launch per "
-                              f"network ([{rows_c}x61] -> 256 -> 256 -> 128 and [{rows_a}x47] -> 256 -> 128 -> 128, activations handed on in registers, {arith}, "
-                              "hand-written HIP); the two launches of a mini-epoch overlap on two streams",
+        headline = {"kernel": (f"mlp_chain_split_fwd_kernel<0>: the critic's and the actor's three fused Linear+bias+ELU hidden layers in ONE launch "
+                               f"([{rows_c}x61] -> 256 -> 256 -> 128 on {int(runner._critic_tr.chain_workgroups)} workgroups and [{rows_a}x47] -> 256 -> 128 -> 128 on "
+                               f"{int(runner._actor_tr.chain_workgroups)}, one per CU, persistent over their slabs; activations handed on in registers, {arith}, hand-written HIP)")
+                              if one_launch else
+                              (f"{kc_name} + {ka_name}: the critic's and the actor's three fused Linear+bias+ELU hidden layers, one launch per "
+                               f"network ([{rows_c}x61] -> 256 -> 256 -> 128 and [{rows_a}x47] -> 256 -> 128 -> 128, activations handed on in registers, {arith}, "
+                               "hand-written HIP); the two launches of a mini-epoch overlap on two streams"),
                     "bound": "mfma", "achieved": tf, "peak": fwd_peak, "unit": "TFLOP/s", "frac": tf / fwd_peak,
                     "peak_note": (f"peak = {MFMA_BF16_PEAK_TF} TF/s dense bf16 MFMA / 9 products per fp32 x fp32 product = {SPLIT9_PEAK_TF:.1f} TF/s of fp32-exact flops; "
                                   "`achieved` counts the algorithmic fp32 flops once") if split_fwd else "fp32-input MFMA dense peak",
                     "frac_of_fp32_mfma_peak": tf / MFMA_F32_PEAK_TF, "fp32_mfma_peak": MFMA_F32_PEAK_TF,
-                    "traffic": (tr_c[0] + tr_c[1]) if all(tr_c) else None, "traffic_source": PMC_SOURCE,
+                    "traffic": tr_group if one_launch else ((tr_c[0] + tr_c[1]) if all(tr_c) else None), "traffic_source": PMC_SOURCE,
                     "avg_launch_us": span_us, "algorithmic_flops_per_launch": fl_c + fl_a,
-                    "note": "flops of both launches (real input columns) / time from the first start to the last end of the pair, HIP events on the two launch "
-                            "streams inside the timed loop; the pair's own durations are in per_kernel_in_the_loop",
-                    "per_kernel_in_the_loop": {kc_name: {"avg_launch_us": c_loop_us, "algorithmic_flops": fl_c, "traffic": tr_c[0]},
-                                               ka_name: {"avg_launch_us": a_loop_us, "algorithmic_flops": fl_a, "traffic": tr_c[1]}}}
-        layer_fwd = {"kernel": f"{kc_name}: the critic's chained forward launch, [{rows_c}x61] -> 256 -> 256 -> 128", "bound": "mfma",
+                    "note": ("flops of both networks (real input columns) / duration of the launch, HIP events on the launch stream inside the timed loop"
+                             if one_launch else
+                             "flops of both launches (real input columns) / time from the first start to the last end of the pair, HIP events on the two launch "
+                             "streams inside the timed loop; the pair's own durations are in per_kernel_in_the_loop"),
+                    "per_kernel_in_the_loop": ({"mlp_chain_split_fwd_kernel<0>": {"avg_launch_us": span_us, "algorithmic_flops": fl_c + fl_a, "traffic": tr_group}}
+                                               if one_launch else
+                                               {kc_name: {"avg_launch_us": c_loop_us, "algorithmic_flops": fl_c, "traffic": tr_c[0]},
+                                                ka_name: {"avg_launch_us": a_loop_us, "algorithmic_flops": fl_a, "traffic": tr_c[1]}})}
+        layer_fwd = None if one_launch else {"kernel": f"{kc_name}: the critic's chained forward launch, [{rows_c}x61] -> 256 -> 256 -> 128", "bound": "mfma",
                      "achieved": fl_c / (c_loop_us * 1e-6) / 1e12, "peak": fwd_peak, "unit": "TFLOP/s", "frac": fl_c / (c_loop_us * 1e-6) / 1e12 / fwd_peak,
                      "frac_of_fp32_mfma_peak": fl_c / (c_loop_us * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
                      "traffic": tr_c[0], "traffic_source": PMC_SOURCE, "avg_launch_us": c_loop_us, "algorithmic_flops_per_launch": fl_c,
@@ -505,7 +515,8 @@ def main():
                                # "alone" = nothing beside it on the chip, not "on all CUs"
                                "workgroups": int(tr.chain_workgroups) or "one per 128-row slab"}
             headline["alone_on_the_gpu"] = alone
-            layer_fwd["alone_on_the_gpu"] = alone[kc_name]
+            if layer_fwd is not None:
+                layer_fwd["alone_on_the_gpu"] = alone[kc_name]
         wg_ev = wgrad_events
         wgrad = None
         if wg_ev:  # all six hidden-layer weight gradients of both networks: one launch pair per mini-epoch, alone on the GPU
@@ -537,7 +548,7 @@ def main():
             bwd_peak = SPLIT9_PEAK_TF if split_bwd else MFMA_F32_PEAK_TF
             backward = {"kernel": ("mlp_chain_split_bwd_kernel<0> / <1>: the backward-data pass of each network's hidden layers as ONE launch (G2 = (G3 W3) elu'(A2), "
                                    "G1 = (G2 W2) elu'(A1), bias-gradient column sums; fp32 operands as exact three-way bf16 splits, 9 products, fp32 accumulation, "
-                                   "bg_mlp_chain_split_bwd.hip), two launches on two streams") if split_bwd else
+                                   "bg_mlp_chain_split_bwd.hip), " + ("both networks in ONE launch that shares the chip by CUs" if bwc[0][0] is bwa[0][0] else "two launches on two streams")) if split_bwd else
                                   ("mlp_fwd_kernel<256,2,2> / <128,2,2> / <128,2,1>: the backward-data GEMMs of both networks' hidden layers (dX = G W with ELU' and the "
                                    "bias-gradient column sums in the epilogue), two chains of two launches on two streams"),
                         "bound": "mfma", "achieved": bfl / (bus * 1e-6) / 1e12, "peak": bwd_peak, "unit": "TFLOP/s", "frac": bfl / (bus * 1e-6) / 1e12 / bwd_peak,
@@ -545,9 +556,9 @@ def main():
                         "avg_launch_us": bus, "algorithmic_flops_per_launch": bfl,
                         "per_chain_in_the_loop_us": {"critic": sum(a.elapsed_time(b) for a, b, *_ in bwc) / len(bwc) * 1e3,
                                                      "actor": sum(a.elapsed_time(b) for a, b, *_ in bwa) / len(bwa) * 1e3},
-                        "note": "flops of both chains / time from the first start to the last end of the pair, HIP events on the two launch streams inside the timed "
-                                "loop; the head kernels (loss + output layers) run at the front of the same span.  The kernel runs against the CU's vector-memory "
-                                "pipeline, not the matrix pipe (profiles/r06_chain_split_bwd_stamps.txt)"}
+                        "note": "flops of both chains / time from the first start to the last end of the pair (one launch: its duration), HIP events on the launch "
+                                "stream(s) inside the timed loop.  The kernel runs against the CU's vector-memory pipeline, not the matrix pipe "
+                                "(profiles/r06_chain_split_bwd_stamps_and_ablations.txt)"}
         out = {
             "metric": "env-steps/sec (whole node), PPO rollout+update, T1 4096 envs/GPU",
             "value": world * N * T * args.steps / wall, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -622,7 +633,12 @@ def main():
                 MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD = True, False
                 it0, fwd_only = timed_loop(it0)
                 MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD = keep
+                one_stream, runner._one_stream = runner._one_stream, False
+                it0, two_streams = timed_loop(it0)
+                runner._one_stream = one_stream
                 it0, again = timed_loop(it0)
+                out["two_launches_on_two_streams_loop"] = dict(two_streams, note="the headline arithmetic with the critic's and the actor's chains as separate launches on "
+                                                                                 "two streams (BG_ONE_STREAM=0: the form until mid round 6)")
                 runner._flush_log()
                 fp32["gemm_arithmetic"] = "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: BG_CHAIN_SPLIT=0"
                 out["fp32_mfma_loop"] = fp32

@@ -264,6 +264,49 @@ class MLPTrainer:
         MLPTrainer.launch_chain(descs)
 
     @staticmethod
+    def forward_hidden_group(jobs):
+        """jobs = [(trainer, x, train_rows), ...] (at most 4, all on the chained split kernel): `forward_hidden` of every job in ONE launch -- the
+        networks share the chip by their `chain_workgroups` inside one grid instead of as launches on several streams.  Same kernel code per network,
+        same slabs, same order of the sums: bit-identical to the separate launches.  Returns the last hidden activations of every job."""
+        descs = []
+        for tr, x, train_rows in jobs:
+            tr.prepare(x, train_rows)
+            if not tr._chain_split():
+                raise ValueError("forward_hidden_group: every network must run the chained split kernel")
+            descs.append(tr._chain_descriptor())
+        timed = any(tr.timed_layer is not None for tr, _, _ in jobs)
+        if timed:  # bench.py: HIP events on the launch stream around this one kernel (the same pair is noted for every network of the launch)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        MLPTrainer.launch_chain(descs)
+        if timed:
+            e1.record()
+            for tr, x, _ in jobs:
+                tr.timed_events.append((e0, e1, x.shape[0], tr._kin, tuple(l.weight.shape[0] for l in tr.layers[:3]), "chain_split"))
+        return [tr.acts[2] for tr, _, _ in jobs]
+
+    @staticmethod
+    def backward_hidden_group(trainers, finishes):
+        """`backward_hidden(finishes=finishes)` of every trainer (at most 4, all on the chained split backward kernel) in ONE launch; appends one
+        reduction descriptor per trainer, in the order given."""
+        if not all(tr._chain_split_bwd() for tr in trainers):
+            raise ValueError("backward_hidden_group: every network must run the chained split backward kernel")
+        timed = any(tr.timed_layer is not None for tr in trainers)
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        ds = [tr.chain_backward_descriptor() for tr in trainers]
+        arr = (_lib.MlpChainSplitBwd * len(ds))(*ds)
+        fins = (_lib.ReduceProblem * len(ds))()
+        _lib.check(_lib.load().bg_mlp_chain_backward_split(ctypes.addressof(arr), len(ds), fins, _lib.current_stream_ptr()), "bg_mlp_chain_backward_split")
+        finishes.extend(fins[k] for k in range(len(ds)))
+        if timed:
+            e1.record()
+            for tr in trainers:
+                fl = 2.0 * tr._B * sum(l.weight.shape[0] * l.weight.shape[1] for l in tr.layers[1:-1])
+                tr.timed_events.append((e0, e1, tr._B, fl, None, "backward"))
+
+    @staticmethod
     def launch_chain(descs):
         """One launch for a list of chain descriptors of one kind (all bg_mlp_chain or all bg_mlp_chain_split); a mixed list runs as two launches."""
         lib, st = _lib.load(), _lib.current_stream_ptr()

@@ -259,6 +259,10 @@ class Runner:
         # False: one workgroup per slab, dispatched as CUs fall free
         self._split_chain_cus = os.environ.get("BG_SPLIT_CHAIN_CUS", "1") == "1"
         self._split_bwd_chain_cus = os.environ.get("BG_SPLIT_BWD_CHAIN_CUS", "1") == "1"  # ... and the two chained backward launches
+        # Both networks' forward chains as ONE launch and both backward chains as ONE launch, the whole mini-epoch on the main stream (round 6): the
+        # networks share the chip by CUs inside one grid exactly as the two launches did, and no kernel of the mini-epoch waits for an event of another
+        # stream any more (three hand-overs on its critical path, 7-20 us each in a kernel trace).  0: two launches on two streams
+        self._one_stream = os.environ.get("BG_ONE_STREAM", "1") == "1"
         self._gae_scratch = torch.zeros(3 * ((self.env.num_envs + 15) // 16) + 1, dtype=torch.float64, device=self.device)
 
         # fused output layers + loss (bg_head.hip): both networks end in a 128-wide ELU layer, 12 actions / 1 value (utils/model.py); a model of
@@ -437,8 +441,11 @@ class Runner:
             for epoch in range(self.cfg["runner"]["mini_epochs"]):
                 # this mini-epoch's hidden activations and values may be the rollout's: same kernels, same weights
                 have_fwd = u.ahead and epoch == 0
-                self._epoch_critic_forward_and_gae(u, have_fwd)
-                self._epoch_losses_and_backward(u, have_fwd)
+                if u.one_stream:
+                    self._epoch_on_one_stream(u, have_fwd)
+                else:
+                    self._epoch_critic_forward_and_gae(u, have_fwd)
+                    self._epoch_losses_and_backward(u, have_fwd)
                 self._epoch_gradients_and_step(u)
         return self._stats_acc
 
@@ -483,9 +490,12 @@ class Runner:
         # the MFMA-bound GEMMs of the other.  side stream = critic forward -> GAE ... critic backward; main stream = actor.
         main = torch.cuda.current_stream()
         side = self._side_stream
+        ct, at = self._critic_tr, self._actor_tr
+        one_stream = (self._one_stream and fused_head and self._fused_gae and self._chain_values and self._defer_finish and self._defer_serial
+                      and not MLPTrainer.SPLIT and ct.chainable_for(critic_all, B) and at.chainable_for(obs_flat) and ct._chain_split_bwd() and at._chain_split_bwd())
         return types.SimpleNamespace(cfg=cfg, buf=buf, T=T, N=N, B=B, A=A, alg=alg, act_flat=act_flat, ahead=ahead, obs_flat=obs_flat, critic_all=critic_all,
                                      fused_head=fused_head, logstd_flat=logstd_flat, a_out=a_out, c_out=c_out, old_mu=old_mu, old_logstd=old_logstd, main=main, side=side,
-                                     mirrors=None)
+                                     mirrors=None, one_stream=one_stream)
 
     def _epoch_critic_forward_and_gae(self, u, have_fwd):
         """Side stream: the critic's forward pass (unless the rollout ran it), values, time-out bootstrap, GAE, returns, advantage moments and their
@@ -564,6 +574,33 @@ class Runner:
             self._actor_tr.backward(self._grad_mu)
         u.defer, u.fins, u.fin_c, u.fin_a = defer, fins, fin_c, fin_a
 
+    def _epoch_on_one_stream(self, u, have_fwd):
+        """What _epoch_critic_forward_and_gae + _epoch_losses_and_backward do, as one sequence of launches on the main stream: both forward chains in
+        one launch (unless the rollout ran them), values + GAE + moments (+ their exchange), the two output layers fused with the loss, both
+        backward-data chains in one launch (runner.py:132-163).  Same kernels on the same slabs with the same reduction order as the two-stream form:
+        bit-identical results (tests/test_gpu_ppo.py).  Leaves defer / fins / fin_c / fin_a in u."""
+        buf, B, alg, act_flat, obs_flat, critic_all, logstd_flat, a_out, c_out, old_mu, old_logstd = u.buf, u.B, u.alg, u.act_flat, u.obs_flat, u.critic_all, u.logstd_flat, u.a_out, u.c_out, u.old_mu, u.old_logstd
+        ct, at = self._critic_tr, self._actor_tr
+        ct.value_head = (c_out.weight.reshape(-1), c_out.bias, self._values_all)
+        if have_fwd:
+            u.main.wait_stream(u.side)  # the rollout ran the forward passes on the side stream
+            hc, ha = ct.acts[2], at.acts[2]
+        else:
+            hc, ha = MLPTrainer.forward_hidden_group([(ct, critic_all, B), (at, obs_flat, None)])
+        v_all = critic_values_gae(None, c_out.weight, c_out.bias, buf["rewards"], buf["dones"], buf["time_outs"], alg["gamma"], alg["lam"], self._values_all,
+                                  self._adv, self._ret, self._adv_sums, self._gae_scratch)
+        values = v_all[:B]
+        self.dp.sum_(self._adv_sums, tag="moments")  # exchange (1)
+        fins, fin_c, fin_a = [], _lib.ReduceProblem(), _lib.ReduceProblem()
+        critic_head_backward(hc[:B], c_out.weight, values, self._ret.view(B), ct.hidden_grad, c_out.weight.grad, c_out.bias.grad, ct.layers[-2].bias.grad,
+                             self._stats, self._head_scratch_c, finish=fin_c)
+        actor_head_loss_backward(ha, a_out.weight, a_out.bias, logstd_flat, act_flat, old_mu, old_logstd, self._old_logp, self._adv.view(B), self._adv_sums, 0.2,
+                                 alg["bound_coef"], alg["entropy_coef"], at.hidden_grad, a_out.weight.grad, a_out.bias.grad, at.layers[-2].bias.grad,
+                                 self._grad_logstd, self._stats, self._head_scratch_a, finish=fin_a)
+        MLPTrainer.backward_hidden_group([ct, at], fins)
+        u.hc, u.values, u.gae_done = hc, values, None
+        u.defer, u.fins, u.fin_c, u.fin_a = True, fins, fin_c, fin_a
+
     def _epoch_gradients_and_step(self, u):
         """Deferred reductions, all weight gradients, the exchange of the gradient over the ranks, clip + Adam + KL rule (runner.py:162-180)."""
         cfg, B, alg, main, side = u.cfg, u.B, u.alg, u.main, u.side
@@ -577,7 +614,8 @@ class Runner:
         one_tail = (fused_tail and self._one_launch_tail and defer and self._defer_serial and len(fins) + 2 <= 8
                     and all(all(tr.wg_slices[:-1]) for tr in (self._critic_tr, self._actor_tr))
                     and len(fins) == sum(1 if tr._chain_split_bwd() else len(tr.layers) - 2 for tr in (self._critic_tr, self._actor_tr)))
-        main.wait_stream(side)
+        if not u.one_stream:
+            main.wait_stream(side)
         if one_tail:
             pass  # the deferred reductions run inside bg_update_tail
         elif defer and self._defer_serial:  # the deferred reductions as one launch in FRONT of the weight gradients (the default)

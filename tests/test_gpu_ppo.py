@@ -349,7 +349,7 @@ SWITCHES = {
     # name: (runner attributes, MLPTrainer class attributes) -- every branch of Runner.update() / MLPTrainer that a switch or a shape can select
     "default": ({}, {}),
     # (environment switches and the attributes they set: BG_ONE_LAUNCH_TAIL -> _one_launch_tail, BG_SPLIT_CHAIN_CUS -> _split_chain_cus,
-    #  BG_ROLLOUT_FORWARD -> _rollout_forward, BG_ROLLOUT_FORWARD_GROUP -> _rollout_group, BG_DEFER_FINISH -> _defer_finish / _defer_serial (own test below),
+    #  BG_ONE_STREAM -> _one_stream, BG_ROLLOUT_FORWARD -> _rollout_forward, BG_ROLLOUT_FORWARD_GROUP -> _rollout_group, BG_DEFER_FINISH -> _defer_finish / _defer_serial (own test below),
     #  BG_CHAIN_SPLIT / BG_CHAIN_SPLIT_BWD / BG_CHAIN_ALTERNATE -> MLPTrainer.CHAIN_SPLIT / CHAIN_SPLIT_BWD / CHAIN_ALTERNATE; BG_OWN_RCCL: tests/test_gpu_rccl.py)
     "tail_as_three_launches": ({"_one_launch_tail": False}, {}),                  # reduce_group, weight gradients + finish, optimizer_step (what ranks of a job run)
     "separate_optimizer_tail": ({"_fused_opt": False}, {}),                      # bg_adam_step + bg_adapt_lr + torch adds (first step after a restore)
@@ -364,6 +364,7 @@ SWITCHES = {
     "plain_accumulation": ({}, {"CHAIN_ALTERNATE": False}),                      # BG_CHAIN_ALTERNATE=0: no slab accumulates the negated sums
     "chain_one_workgroup_per_slab": ({"_split_chain_cus": False}, {}),            # BG_SPLIT_CHAIN_CUS=0: the two forward launches share the chip by slabs instead of by CUs
     "backward_chain_one_workgroup_per_slab": ({"_split_bwd_chain_cus": False}, {}),  # BG_SPLIT_BWD_CHAIN_CUS=0: ... and the two backward launches
+    "two_launches_on_two_streams": ({"_one_stream": False}, {}),                 # BG_ONE_STREAM=0: critic and actor chains as separate launches on two streams (until mid round 6)
     "rollout_forward_off": ({"_rollout_forward": False}, {}),
     "rollout_forward_one_step_per_group": ({"_rollout_group": 1}, {}),
     "rollout_forward_five_steps_per_group": ({"_rollout_group": 5}, {}),
@@ -412,7 +413,7 @@ def test_update_through_every_switch_matches_the_default(switch, default_update)
     rate.  The rollout-forward variants run the same kernels on the same numbers: identical bits, also after a second iteration."""
     start, (p0, a0, s0), (q0, b0, act0) = default_update
     _, (p1, a1, s1), (q1, b1, act1) = _update_under(switch)
-    if switch.startswith("rollout_forward") or switch in ("chain_one_workgroup_per_slab", "backward_chain_one_workgroup_per_slab"):
+    if switch.startswith("rollout_forward") or switch in ("chain_one_workgroup_per_slab", "backward_chain_one_workgroup_per_slab", "two_launches_on_two_streams"):
         assert torch.equal(p1, p0) and torch.equal(a1, a0) and torch.equal(q1, q0) and torch.equal(b1, b0) and torch.equal(act1, act0)
         return
     _assert_same_adam_steps(switch, p1, p0, start)
