@@ -8,15 +8,16 @@ Same surface: `Runner(test=False)` parses the reference's 8 CLI flags (runner.py
             reward / done / time-out directly into rows of the experience buffer -- no `.to(device)` copies, no per-done-env `.item()`
             (runner.py:112-121).  Beside them, on the side stream, the FIRST mini-epoch's forward passes of both networks on each step's rows as soon
             as they exist (same kernels, same weights as the update: bit-identical).
-  update    per mini-epoch, two streams (critic on the side stream, actor on the main one), no host sync inside the 20 mini-epochs (reference: 4
-            per mini-epoch, runner.py:175,182-184):
-              forward        the three hidden layers of a network as ONE launch (utils/model.py MLPTrainer -> bg_mlp_chain_forward_split: fp32 operands
-                             as exact three-way bf16 splits, all 9 products on the bf16 matrix pipe, fp32 accumulation; BG_CHAIN_SPLIT=0: the
-                             fp32-MFMA chain bg_mlp_chain_forward_group), the critic's values from the registers of that launch;
+  update    per mini-epoch EIGHT launches on one stream (BG_ONE_STREAM=0: the two networks' chains as separate launches on two streams), no host sync
+            inside the 20 mini-epochs (reference: 4 per mini-epoch, runner.py:175,182-184):
+              forward        the three hidden layers of BOTH networks as ONE launch that shares the chip by CUs (utils/model.py MLPTrainer ->
+                             bg_mlp_chain_forward_split: fp32 operands as exact three-way bf16 splits, all 9 products on the bf16 matrix pipe, fp32
+                             accumulation; BG_CHAIN_SPLIT=0: the fp32-MFMA chain bg_mlp_chain_forward_group), the critic's values from the registers
+                             of that launch;
               GAE            bg_critic_values_gae: time-out bootstrap, GAE scan, returns, advantage moments in one launch;
               heads + loss   output layers fused with the PPO loss and its backward (bg_critic_head_backward, bg_actor_head);
-              backward-data  the hidden layers of a network as ONE launch (bg_mlp_chain_backward_split: same arithmetic, ELU' and bias-gradient sums
-                             in its epilogues; BG_CHAIN_SPLIT_BWD=0: one fp32-MFMA launch per layer);
+              backward-data  the hidden layers of both networks as ONE launch (bg_mlp_chain_backward_split: same arithmetic, ELU' and bias-gradient
+                             sums in its epilogues; BG_CHAIN_SPLIT_BWD=0: one fp32-MFMA launch per layer);
               weight grads   all six hidden layers of both networks in one grouped fp32-MFMA launch (bg_mlp_weight_grad_group_partial);
               tail           two launches (bg_update_tail): the deferred fixed-order sums + the squared-norm pieces, then clip + Adam + KL learning-rate
                              rule + statistics bookkeeping + the copies of the weights the layer kernels read (bf16 planes of W, -W, W^T, -W^T).
