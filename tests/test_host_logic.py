@@ -34,17 +34,19 @@ def test_ctypes_structs_match_the_c_header(tmp_path):
     from booster_gym_amd import _lib
 
     src = tmp_path / "sz.c"
-    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "booster_gym_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bg_env_cfg), '
+    src.write_text('#include <stdio.h>\n#include <stddef.h>\n#include "booster_gym_amd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(bg_env_cfg), '
                    "sizeof(bg_model_desc), offsetof(bg_env_cfg, reward_scale), offsetof(bg_env_cfg, terrain_type), offsetof(bg_env_cfg, noise_gravity), "
                    "offsetof(bg_model_desc, feet_edge_pos), sizeof(bg_param_mirror), offsetof(bg_param_mirror, dst), sizeof(bg_mlp_chain), offsetof(bg_mlp_chain, Y1), "
-                   "sizeof(bg_reduce_problem));return 0;}\n")
+                   "sizeof(bg_reduce_problem), sizeof(bg_mlp_chain_split), offsetof(bg_mlp_chain_split, X), offsetof(bg_mlp_chain_split, v_out), "
+                   "sizeof(bg_mlp_chain_split_bwd), offsetof(bg_mlp_chain_split_bwd, G3), offsetof(bg_mlp_chain_split_bwd, bias_grad1));return 0;}\n")
     exe = tmp_path / "sz"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)]).split()]
     E, M = _lib.EnvCfg, _lib.ModelDesc
-    P, Q, R = _lib.ParamMirror, _lib.MlpChain, _lib.ReduceProblem
+    P, Q, R, S, B = _lib.ParamMirror, _lib.MlpChain, _lib.ReduceProblem, _lib.MlpChainSplit, _lib.MlpChainSplitBwd
     assert got == [C.sizeof(E), C.sizeof(M), E.reward_scale.offset, E.terrain_type.offset, E.noise_gravity.offset, M.feet_edge_pos.offset,
-                   C.sizeof(P), P.dst.offset, C.sizeof(Q), Q.Y1.offset, C.sizeof(R)]
+                   C.sizeof(P), P.dst.offset, C.sizeof(Q), Q.Y1.offset, C.sizeof(R), C.sizeof(S), S.X.offset, S.v_out.offset, C.sizeof(B), B.G3.offset,
+                   B.bias_grad1.offset]
 
 
 def test_abi_argument_errors_without_gpu():
