@@ -156,6 +156,10 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
         constexpr int e = decltype(e_)::value;
         fb(f, a3, IC<e / 16>{}, IC<e % 16>{});
         part = fmaf(a3[e / 16][e % 16], wv[(e / 4) % 3][e % 4], part);
+        // ONE chain of 64 fused multiply-adds in element order, wherever this runs: in the stream the pieces are pinned between MFMAs anyway; in the tail
+        // (straight-line code) -fassociative-math would re-associate the chain into several partial sums, and a slab's value would depend on whether it
+        // is a workgroup's last one -- that is on how the slabs are dealt to workgroups (tests: "...however the slabs are dealt...")
+        asm volatile("" : "+v"(part));
         if constexpr (e % 4 == 3) store4(a3, a.Y3, rowp, IC<N3>{}, IC<e / 16>{}, IC<(e / 4) % 4>{});
     };
     auto split_pair_at = [&](auto ph_, float v0, float v1, SplitTmp& st, auto p_) {

@@ -672,9 +672,10 @@ class Runner:
         u.mirrors = mirrors
 
     def _plan_chain_split(self, rows_c, rows_a):
-        """The two networks' chained forward launches of a mini-epoch run side by side on two streams, one workgroup per CU (128 KB of LDS).  Left to the
-        dispatcher, equal-sized slabs of unequal cost run in lockstep rounds and the last 32 slabs run alone (370 us for 325 us of work per CU); here each
-        launch gets a share of the CUs and walks its slabs (bg_mlp_chain::workgroups): the split that minimises the longer of the two, slab cost ~ flops."""
+        """The two networks' chains of a mini-epoch run side by side -- inside one grid (the default) or as two launches on two streams -- one workgroup
+        per CU (all of its LDS).  Left to the dispatcher, equal-sized slabs of unequal cost run in lockstep rounds and the last 32 slabs run alone (370 us
+        for 325 us of work per CU); here each network gets a share of the CUs whose workgroups walk its slabs (bg_mlp_chain_split::workgroups): the
+        split that minimises the longer of the two, slab cost ~ flops.  Which workgroup walks which slab changes no bit of the results."""
         ct, at = self._critic_tr, self._actor_tr
         ct.chain_workgroups = at.chain_workgroups = 0
         if not (self._split_chain_cus and ct._chainable() and at._chainable()):

@@ -118,6 +118,30 @@ def test_alternating_the_sign_of_the_accumulation_removes_the_bias():
     assert bias1 <= 0.6 * bias0 and bias0 > 5.0 * bias32
 
 
+@pytest.mark.parametrize("dims,k_real", [((64, 256, 256, 128), 61), ((64, 256, 128, 128), 47)])
+def test_split_chain_forward_gives_the_same_bits_however_the_slabs_are_dealt_to_workgroups(dims, k_real):
+    """Which workgroup walks which slab -- one slab each, the planner's shares, a count that gives some workgroups ONE slab and others two (first slab =
+    last slab: prologue and tail with nothing between), an odd count -- changes no bit of the three activations or of the value head's output."""
+    from booster_gym_amd import _lib
+
+    lib, st, p = _lib.load(), _lib.current_stream_ptr(), _lib.ptr
+    M = 400 * 128 - 57
+    g = torch.Generator(device="cpu").manual_seed(9)
+    vw, vb = (torch.randn(128, generator=g) * 0.1).to(DEV), torch.randn(1, generator=g).to(DEV)
+    ref = None
+    for wgs in (0, 160, 256, 33, 399):
+        d, x, Ws, bs, ys, Ps = _case(M, dims, seed=21, k_real=k_real, wgs=wgs)
+        vo = torch.full((M,), float("nan"), device=DEV)
+        d.v_w, d.v_b, d.v_out = p(vw), p(vb), p(vo)
+        _lib.check(lib.bg_mlp_chain_forward_split(ctypes.addressof(d), 1, st), "bg_mlp_chain_forward_split")
+        got = [y[:M].clone() for y in ys] + [vo.clone()]
+        assert all(torch.isfinite(t).all() for t in got)
+        if ref is None:
+            ref = got
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (wgs, k, (a - b).abs().max().item(), int((a != b).sum()))
+
+
 def test_split_chain_value_head_group_and_bad_arguments():
     """The scalar output layer taken from the registers (the critic's values) on every row of a ragged batch; two networks in one launch; the same
     slabs give the same bits whether they run in one launch or in pieces (the rollout evaluates each step's rows as soon as they exist); refusals."""

@@ -99,6 +99,28 @@ def _run_and_check(M, dims, wgs, seed, alternate=1):
     return t, stats
 
 
+@pytest.mark.parametrize("dims", [(256, 256, 128), (256, 128, 128)])
+def test_split_chain_backward_gives_the_same_bits_however_the_slabs_are_dealt_to_workgroups(dims):
+    """One slab per workgroup, the planner's shares, a count that gives some workgroups one slab and others two, an odd count: the same bits in G2, G1
+    and (one record per (slab, wave), summed in a fixed order) in the bias gradients."""
+    from booster_gym_amd import _lib
+    from booster_gym_amd.utils.utils import reduce_group
+
+    lib, st = _lib.load(), _lib.current_stream_ptr()
+    M, ref = 384 * 128 - 57, None
+    for wgs in (0, 168, 256, 37, 383):
+        d, t = _case(M, dims, 31, wgs)
+        fin = _lib.ReduceProblem()
+        _lib.check(lib.bg_mlp_chain_backward_split(ctypes.addressof(d), 1, fin, st), "bg_mlp_chain_backward_split")
+        reduce_group([fin])
+        got = [t[k].clone() for k in ("G2", "G1", "b2", "b1")]
+        assert all(torch.isfinite(x).all() for x in got)
+        if ref is None:
+            ref = got
+        for k, (a, b) in enumerate(zip(ref, got)):
+            assert torch.equal(a, b), (wgs, k, (a - b).abs().max().item(), int((a != b).sum()))
+
+
 @pytest.mark.parametrize("M,dims,wgs", [(98304, (256, 128, 128), 0), (98304, (256, 256, 128), 0), (1000, (256, 256, 128), 0), (77, (256, 128, 128), 0),
                                         # persistent workgroups walking the slabs (the update's split of the CUs), a count that does not divide the slabs,
                                         # more workgroups than slabs

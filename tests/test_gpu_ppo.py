@@ -422,6 +422,41 @@ def test_update_through_every_switch_matches_the_default(switch, default_update)
     assert abs(s1["lr"] - s0["lr"]) < 1e-9
 
 
+def test_cu_shares_of_the_chains_change_no_bit(monkeypatch):
+    """The CU shares of the two networks inside the chained launches (Runner._plan_chain_split; BG_FWD_CHAIN_CUS / BG_BWD_CHAIN_CUS fix them for A/B
+    runs, BG_SPLIT_CHAIN_CUS / BG_SPLIT_BWD_CHAIN_CUS = 0 give every slab its own workgroup) decide which workgroup walks which slab, nothing else:
+    at a size where the planner splits the chip (2,048 envs: 400 + 384 slabs on 256 CUs), the planner's shares, other shares and no shares give the same
+    bits -- in the one-launch form and as two launches on two streams."""
+    from booster_gym_amd.utils.config import load_cfg
+    from booster_gym_amd.utils.runner import Runner
+
+    def run(env, one_stream=True, split=True):
+        for k in ("BG_FWD_CHAIN_CUS", "BG_BWD_CHAIN_CUS"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        r = Runner(cfg=load_cfg("T1", {"env.num_envs": 2048, "terrain.type": "plane", "runner.mini_epochs": 2, "basic.seed": 5}))
+        r._one_stream = one_stream
+        r._split_chain_cus = r._split_bwd_chain_cus = split
+        obs, infos = r.env.reset()
+        r.buffer["obses"][0].copy_(obs); r.buffer["privileged_obses"][0].copy_(infos["privileged_obs"])
+        acc = r.iteration().clone()
+        torch.cuda.synchronize()
+        shares = (r._critic_tr.chain_workgroups, r._actor_tr.chain_workgroups, r._critic_tr.chain_bwd_workgroups, r._actor_tr.chain_bwd_workgroups)
+        return r.optimizer.flat.clone(), acc, shares
+
+    p0, a0, s0 = run({})
+    assert s0[0] > 0 and s0[0] + s0[1] == s0[2] + s0[3] and s0[0] % 8 == 0 and s0[2] % 8 == 0, s0  # the planner split the chip, in multiples of the XCDs
+    for env, one_stream, split in (({"BG_FWD_CHAIN_CUS": "168,88", "BG_BWD_CHAIN_CUS": "176,80"}, True, True), ({"BG_FWD_CHAIN_CUS": "256,256"}, True, True),
+                                   ({}, False, True), ({"BG_BWD_CHAIN_CUS": "96,160"}, False, True), ({}, True, False)):
+        p1, a1, s1 = run(env, one_stream, split)
+        assert torch.equal(p1, p0) and torch.equal(a1, a0), (env, one_stream, split, s1, (p1 - p0).abs().max().item())
+        if "BG_BWD_CHAIN_CUS" in env:
+            assert list(s1[2:]) == [int(v) for v in env["BG_BWD_CHAIN_CUS"].split(",")]
+        if not split:
+            assert s1 == (0, 0, 0, 0)
+
+
 def test_update_with_deferred_reductions_equals_update_with_immediate_ones():
     """Runner.update() with the small reductions deferred to one launch in front of the weight gradients (the default), to one launch on the side
     stream beside them (BG_DEFER_FINISH=2) and with every finish inside its chain (=0), from identical weights and rollout data: same parameters
