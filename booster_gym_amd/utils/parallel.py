@@ -13,9 +13,10 @@ calls of this file (tests/test_gpu_rccl.py).
 
 Enqueue-order contract (two communicators, two streams).  A communicator executes its collectives in the order they were ENQUEUED, per rank; ranks
 that enqueue the same communicator's collectives in different orders dead-lock or mix up buffers.  This build drives
-  * the OWN communicator (utils/rccl.py) from two streams of a rank: the side stream (tag "moments": the advantage moments, once per mini-epoch, inside
-    Runner._epoch_critic_forward_and_gae) and the main stream (tag "bucket": the grouped gradient / statistics / log-std exchange, once per mini-epoch,
-    inside Runner._epoch_gradients_and_step);
+  * the OWN communicator (utils/rccl.py): tag "moments" (the advantage moments, once per mini-epoch) and tag "bucket" (the grouped gradient /
+    statistics / log-std exchange, once per mini-epoch, inside Runner._epoch_gradients_and_step).  In the default one-stream mini-epoch
+    (Runner._epoch_on_one_stream) both are enqueued on the MAIN stream: one communicator, one stream.  With BG_ONE_STREAM=0 "moments" is enqueued on
+    the side stream (Runner._epoch_critic_forward_and_gae) and "bucket" on the main stream: one communicator driven from two streams of a rank;
   * the PROCESS GROUP's communicator for everything outside the mini-epochs (seed, initial weights, curriculum grid, barriers).
 The host enqueues strictly in program order -- moments(e), bucket(e), moments(e + 1), ... -- on every rank, whatever the streams do on the device, and
 nothing else touches the own communicator; the process group's collectives are issued only between iterations.  Any change that makes the ORDER OF
