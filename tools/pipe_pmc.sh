@@ -14,7 +14,7 @@ R = os.environ.get("GRAFT_REPO_ROOT", "/root/repo")
 f = sorted(glob.glob(f"{R}/gpurun_out/prof_{tag}_pipe/**/*counter_collection.csv", recursive=True), key=os.path.getmtime)[-1]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for r in csv.DictReader(open(f)):
-    name = r["Kernel_Name"].split("(")[0].replace("void ", "").strip()[:70]
+    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").split("(")[0].replace("void ", "").strip()[:70]
     acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, cs in acc.items():
