@@ -38,7 +38,9 @@ with torch.cuda.stream(side):                  # collectives issued on the side 
 main.wait_stream(side)
 dep = g32 * 2.0 + a64.sum().float()            # a dependent kernel on the main stream
 torch.cuda.synchronize()
-assert dp.comm is not None, "the per-mini-epoch exchanges must go through the own communicator (utils/rccl.py)"
+own = os.environ.get("BG_OWN_RCCL", "1") != "0"
+assert (dp.comm is not None) == own, "the per-mini-epoch exchanges go through the own communicator (utils/rccl.py) unless BG_OWN_RCCL=0"
+out["own_rccl"] = dp.comm is not None
 s64, l64 = torch.arange(5, dtype=torch.float64, device=dev) + 0.5, torch.arange(12, dtype=torch.float64, device=dev) - 3.0
 dp.exchange_tail_(g32, s64, l64)               # bucket (mean) + loss sums (sum) + log-std gradient (mean): one grouped launch on the current stream
 torch.cuda.synchronize()

@@ -350,7 +350,7 @@ SWITCHES = {
     "default": ({}, {}),
     # (environment switches and the attributes they set: BG_ONE_LAUNCH_TAIL -> _one_launch_tail, BG_SPLIT_CHAIN_CUS -> _split_chain_cus,
     #  BG_ONE_STREAM -> _one_stream, BG_ROLLOUT_FORWARD -> _rollout_forward, BG_ROLLOUT_FORWARD_GROUP -> _rollout_group, BG_DEFER_FINISH -> _defer_finish / _defer_serial (own test below),
-    #  BG_CHAIN_SPLIT / BG_CHAIN_SPLIT_BWD / BG_CHAIN_ALTERNATE -> MLPTrainer.CHAIN_SPLIT / CHAIN_SPLIT_BWD / CHAIN_ALTERNATE; BG_OWN_RCCL: tests/test_gpu_rccl.py)
+    #  BG_CHAIN_SPLIT / BG_CHAIN_SPLIT_BWD / BG_CHAIN_ALTERNATE -> MLPTrainer.CHAIN_SPLIT / CHAIN_SPLIT_BWD / CHAIN_ALTERNATE; BG_OWN_RCCL = 0 and 1: tests/test_gpu_rccl.py; BG_FWD_CHAIN_CUS / BG_BWD_CHAIN_CUS: test_cu_shares_of_the_chains_change_no_bit below)
     "tail_as_three_launches": ({"_one_launch_tail": False}, {}),                  # reduce_group, weight gradients + finish, optimizer_step (what ranks of a job run)
     "separate_optimizer_tail": ({"_fused_opt": False}, {}),                      # bg_adam_step + bg_adapt_lr + torch adds (first step after a restore)
     "gae_as_three_launches": ({"_fused_gae": False}, {}),                        # bg_critic_head_forward + fill + bg_gae (horizons beyond 32 steps)
