@@ -347,7 +347,9 @@ int bg_mlp_layer_backward_split(int32_t M, int32_t K, int32_t N, const float* G,
  * formed exactly from the 9 cross products of the operands' three bf16 planes (see bg_mlp_layer_forward_split; terms = 9 only).  P1 / P2 / P3: the
  * layers' weight planes as bg_mlp_split_weights writes them (transpose = 0; P1 with k_out = K0 = 64, the zero-padded input width).  Same shapes, slab
  * padding of Y1 / Y2 / Y3, `workgroups` and value head as bg_mlp_chain.  Not bit-identical to the fp32-MFMA chain (another summation order; the bias is
- * the accumulators' initial value): both are exact-product fp32 sums.  1 to 4 networks per launch. */
+ * the accumulators' initial value): both are exact-product fp32 sums.  1 to 4 networks per launch (each on its own `workgroups` persistent
+ * workgroups inside one grid: how the update shares the chip between the critic and the actor); which workgroup walks which slab changes no bit of
+ * any output (tests/test_gpu_mlp_chain_split.py). */
 typedef struct bg_mlp_chain_split {
     int32_t M, K0, N1, N2, N3;
     int32_t workgroups;
@@ -449,8 +451,10 @@ int bg_reduce_group(const bg_reduce_problem* problems, int32_t count, void* stre
  * PT3 / PT2: the planes of W3^T / W2^T as bg_mlp_split_weights(transpose = 1) writes them ([N2][N3 / 32][3][32], [N1][N2 / 32][3][32]); A2 / A1: the
  * layers' stored outputs, holding ceil(M / 128) * 128 rows of finite values as bg_mlp_chain_forward_split leaves them (whole 128-byte rows of a
  * slab are copied; rows >= M do not enter the results).  G2 / G1 must hold ceil(M / 128) * 128 rows (rows >= M are written with zeros).  Every wave
- * leaves one record of column sums per slab in colsum_partial ([ceil(M / 128) * 4][N2 + N1] floats); `finishes[k]` receives the descriptor of the fixed-order reduction that
- * produces bias_grad2 [N2] and bias_grad1 [N1] when handed to bg_reduce_group / bg_update_tail.  Widths (N1, N2, N3): (256, 128, 128), (256, 256, 128). */
+ * leaves one record of column sums per slab in colsum_partial ([ceil(M / 128) * 4][N2 + N1] floats); `finishes[k]` receives the descriptor of the
+ * fixed-order reduction that produces bias_grad2 [N2] and bias_grad1 [N1] when handed to bg_reduce_group / bg_update_tail.  Widths (N1, N2, N3):
+ * (256, 128, 128), (256, 256, 128).  1 to 4 networks per launch; `workgroups` as in bg_mlp_chain_split: which workgroup walks which slab changes no
+ * bit of any output. */
 typedef struct bg_mlp_chain_split_bwd {
     int32_t M, N1, N2, N3;
     int32_t workgroups, alternate;   /* alternate: as in bg_mlp_chain_split; PT3 / PT2 then hold the planes of W^T and of -W^T */
