@@ -12,7 +12,7 @@
 //   * One wave per SIMD, one workgroup per CU, persistent; weight planes through three 48 KB LDS buffers by global_load_lds_dwordx4 two chunks ahead,
 //     one barrier per chunk (in front of the last k-step of the chunk before), copies / loads / stores counted by hand.
 //   * The CU's vector-memory pipeline is what this kernel runs against (tools/chain_split_bwd_stamps.py: without its loads and stores a slab takes
-//     1.16 x its MFMA time, with them 2.3 x): a 16-byte-per-lane access in the accumulator layout touches 32 lines a quarter each.  So the activations
+//     1.14-1.16 x its MFMA time, with them 2.3 x in the first version and 1.4-1.7 x now): a 16-byte-per-lane access in the accumulator layout touches 32 lines a quarter each.  So the activations
 //     under a tile come in as FOUR coalesced LDS-DMA pieces (8 rows x 128 bytes each, full lines, no register stop, swizzled at the source) into a
 //     4 KB corner of LDS per wave and are read from there in the accumulator layout a chunk later; the input rows of the next slab are counted asm
 //     loads; nothing the compiler would wait for by draining the copies is left in the stream.

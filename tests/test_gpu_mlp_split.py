@@ -175,10 +175,16 @@ def test_split_weight_grad_group_matches_float64_as_well_as_the_fp32_kernel(M, t
         ref64 = G.double().t() @ A.double()[:, :cr]
         rms, rms32 = (dW.double() - ref64).pow(2).mean().sqrt().item(), (d32.double() - ref64).pow(2).mean().sqrt().item()
         err, err32 = (dW.double() - ref64).abs().max().item(), (d32.double() - ref64).abs().max().item()
-        # sums over 98,304 rows: the rounding of the ACCUMULATOR dominates here (9 or 6 accumulator updates per 16 rows against the fp32 kernel's 8),
-        # not the products: the bound is a band around the fp32 kernel's error, not "at least as good"
-        slack = 1.5 if terms == 9 else 2.5
+        # sums over 98,304 rows: the rounding of the ACCUMULATOR dominates here, not the products.  The bf16 MFMA's accumulator truncates, which left one
+        # negative offset on every element (0.7 of the rms error, round 6: profiles/r06_wgrad_split_error_parts.jsonl) until the sub-ranges of the batch
+        # took turns accumulating the negated sums: with 9 products the split launch is now at or below the fp32 kernel's rms error (it was 1.2 x), and
+        # its mean signed error is a small fraction of its rms error; 6 products drop terms of 2^-24 of a product and stay in a band
+        slack = 1.05 if terms == 9 else 2.5
+        bias = (dW.double() - ref64).mean().abs().item()
+        print(f"split weight gradients {co}x{ci}, {terms} products: rms {rms:.3e} (fp32 MFMA {rms32:.3e}), |mean signed error| {bias:.2e}, max {err:.2e} ({err32:.2e})")
         assert torch.isfinite(dW).all() and rms <= slack * rms32 + 1e-7 and err <= 2.5 * err32 + 1e-6, (co, ci, rms, rms32, err, err32)
+        if terms == 9 and M >= 98304:
+            assert bias <= 0.2 * rms, (co, ci, bias, rms)
     first = [dW.clone() for _, _, dW, _ in keep]
     _lib.check(lib.bg_mlp_weight_grad_group_split(arr, len(shapes), terms, st), "bg_mlp_weight_grad_group_split")
     assert all(torch.equal(a, dW) for a, (_, _, dW, _) in zip(first, keep))  # deterministic
