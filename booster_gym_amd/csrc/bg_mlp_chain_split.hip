@@ -384,13 +384,14 @@ __device__ __forceinline__ void split_net(const bg_mlp_chain_split& a, int first
 }
 
 // TAG: 1 / 2 = one network with N2 = 128 / 256 (one kernel symbol per shape: a profiler's per-kernel average is the average of ONE shape),
-// 0 = a group, shapes looked up per workgroup.
+// 0 = a group, shapes looked up per workgroup; 3 = the same code as 0 under another symbol, for groups WITHOUT persistent workgroups (the few slabs per
+// network the rollout evaluates as they appear: 40-60 us launches that would otherwise be averaged with the update's 260 us launches).
 template <int TAG>
 __global__ __launch_bounds__(256) void mlp_chain_split_fwd_kernel(SplitGroup grp) {
     __shared__ __attribute__((aligned(16))) unsigned sW[NBUF * BUFDW];
     __shared__ __attribute__((aligned(16))) float sB[2 * SBNEG];   // biases [N1 | N2 | N3], value-head weights [N3]; SBNEG further: the negated biases
     int k = 0;
-    if constexpr (TAG == 0) {
+    if constexpr (TAG == 0 || TAG == 3) {
 #pragma unroll
         for (int j = 1; j < CHAIN_MAX; j++)
             if (j < grp.n && (int)blockIdx.x >= grp.begin[j]) k = j;
@@ -407,7 +408,7 @@ __global__ __launch_bounds__(256) void mlp_chain_split_fwd_kernel(SplitGroup grp
     // share the chip by CUs; counts that are multiples of the 8 XCDs)
     const int nslabs = (a.M + 127) / 128, stride = grp.begin[k + 1] - grp.begin[k], first = blockIdx.x - grp.begin[k];
     if (first >= nslabs) return;
-    if (TAG == 2 || (TAG == 0 && a.N2 == 256)) split_net<64, 256, 256, 128>(a, first, stride, nslabs, sW, sB);
+    if (TAG == 2 || ((TAG == 0 || TAG == 3) && a.N2 == 256)) split_net<64, 256, 256, 128>(a, first, stride, nslabs, sW, sB);
     else split_net<64, 256, 128, 128>(a, first, stride, nslabs, sW, sB);
 }
 
@@ -431,16 +432,19 @@ extern "C" int bg_mlp_chain_forward_split(const bg_mlp_chain_split* nets, int32_
     SplitGroup grp;
     grp.n = count;
     int blocks = 0;
+    bool persistent = false;
     for (int k = 0; k < count; k++) {
         const int rc = split_check(nets[k]);
         if (rc) return rc;
         grp.begin[k] = blocks;
         grp.net[k] = nets[k];
         const int slabs = (nets[k].M + 127) / 128;
+        persistent = persistent || (nets[k].workgroups > 0 && nets[k].workgroups < slabs);
         blocks += nets[k].workgroups > 0 && nets[k].workgroups < slabs ? nets[k].workgroups : slabs;
     }
     grp.begin[count] = blocks;
-    if (count > 1) hipLaunchKernelGGL(mlp_chain_split_fwd_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    if (count > 1 && persistent) hipLaunchKernelGGL(mlp_chain_split_fwd_kernel<0>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
+    else if (count > 1) hipLaunchKernelGGL(mlp_chain_split_fwd_kernel<3>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
     else if (nets[0].N2 == 256) hipLaunchKernelGGL(mlp_chain_split_fwd_kernel<2>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
     else hipLaunchKernelGGL(mlp_chain_split_fwd_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, grp);
     if (hipGetLastError() != hipSuccess) return bg_set_error(-2, "bg_mlp_chain_forward_split: launch failed");
