@@ -7,12 +7,12 @@ A "step" is one PPO iteration on synthetic (randomly initialised) policy weights
 HIP simulator + 20 full-batch optimiser steps (BASELINE.json configs[1], flat terrain).  Rank 0 prints
 ONE JSON line.  `value` = world * N * T * K / wall (max over ranks).
 
-`roofline` = the two networks' chained forward launches (bg_mlp_chain_split.hip: fp32 operands as exact three-way bf16 splits, all 9 products on the
-bf16 matrix pipe, fp32 accumulation), priced over the span of each mini-epoch's pair, against the 9-product equivalent of the bf16 pipe's peak AND
-against the fp32 matrix pipe's; `roofline_backward` = both backward-data chains (bg_mlp_chain_split_bwd.hip) over their span; `roofline_wgrad` = the
-grouped weight gradients (fp32 MFMA: the largest single launch of the iteration, profiles/r06_bench_kernel_stats.csv); `fp32_mfma_loop` = the SAME loop in
-the same run with both chains on the fp32 matrix pipe (last round's headline path); `gemm_errors_vs_float64` = the measured error pair (split chain,
-fp32-MFMA kernels) of each GEMM family; `roofline_env_step`, `roofline_aba` = the simulator kernels against the HBM roof; `other_configs` = BASELINE
+`roofline` = both networks' chained forward pass, one launch (bg_mlp_chain_split.hip: fp32 operands as exact three-way bf16 splits, all 9 products on the
+bf16 matrix pipe, fp32 accumulation), priced against the 9-product equivalent of the bf16 pipe's peak AND against the fp32 matrix pipe's;
+`roofline_backward` = both backward-data chains, one launch (bg_mlp_chain_split_bwd.hip); `roofline_wgrad` = the grouped weight gradients (bg_wgrad_split.hip:
+the same arithmetic; the largest single launch of the iteration, profiles/r06_bench_kernel_stats.csv); `fp32_mfma_loop` = the SAME loop in the same run
+with every GEMM on the fp32 matrix pipe (last round's headline path), `fp32_mfma_weight_gradients_loop` / `split_forward_only_loop` = the steps between;
+`gemm_errors_vs_float64` = the measured error pair (split kernel, fp32-MFMA kernel) of each GEMM family; `roofline_env_step`, `roofline_aba` = the simulator kernels against the HBM roof; `other_configs` = BASELINE
 configs[2] and [4] through the same loop; `cpu_baseline` = the oracle's CPU restatement of the same workload on the host cores.
 """
 import argparse
@@ -273,9 +273,37 @@ def gemm_error_pairs(rows=16384):
         for nm, y, ref, (z, zb), b in (("G2", t["G2"], r2, f32[0], t["b2"]), ("G1", t["G1"], r1, f32[1], t["b1"])):
             out[f"backward_{name}_{nm}"] = {"split9_chain": stat(y[:rows], ref), "fp32_mfma_layers": stat(z, ref)}
             out[f"backward_{name}_bias_gradient_of_{nm}"] = {"split9_chain": stat(b, ref.sum(0)), "fp32_mfma_layers": stat(zb, ref.sum(0))}
+    # weight gradients: the six layers at the update's full batch (the error of a sum over the batch grows with it), ELU outputs x N(0, 0.01) gradients
+    from booster_gym_amd.utils.model import plan_wgrad_slices
+    M = 98304
+    six = [(128, 256, 256), (256, 256, 256), (256, 64, 61), (128, 128, 128), (128, 256, 256), (256, 64, 47)]
+    g = torch.Generator(device="cpu").manual_seed(3)
+    data = []
+    for co, ci, cr in six:
+        G = (torch.randn(M, co, generator=g) * 0.01).to("cuda")
+        A = torch.zeros(M, ci); A[:, :cr] = torch.nn.functional.elu(torch.randn(M, cr, generator=g)); A = A.to("cuda")
+        data.append((G, A))
+    res = {}
+    for kind, share in (("fp32_mfma", False), ("split9", True)):
+        slices, tw = plan_wgrad_slices([(co, ci) for co, ci, _ in six], M, 256, share_rows=share)
+        arr, keep = (_lib.WgradProblem * len(six))(), []
+        for k, ((co, ci, cr), (G, A), sl) in enumerate(zip(six, data, slices)):
+            dW, sc = torch.empty(co, cr, device="cuda"), torch.empty(sl * co * ci, device="cuda")
+            keep.append((dW, sc))
+            arr[k].G, arr[k].A, arr[k].dW, arr[k].scratch = G.data_ptr(), A.data_ptr(), dW.data_ptr(), sc.data_ptr()
+            arr[k].M, arr[k].C_out, arr[k].C_in, arr[k].C_in_real, arr[k].slices, arr[k].tiles_per_workgroup = M, co, ci, cr, sl, tw[k]
+        if share:
+            _lib.check(lib.bg_mlp_weight_grad_group_split(arr, len(six), 9, st), "bg_mlp_weight_grad_group_split")
+        else:
+            _lib.check(lib.bg_mlp_weight_grad_group(arr, len(six), st), "bg_mlp_weight_grad_group")
+        res[kind] = [dW for dW, _ in keep]
+    for k, ((co, ci, cr), (G, A)) in enumerate(zip(six, data)):
+        ref = G.double().t() @ A.double()[:, :cr]
+        out[f"weight_gradient_{k}_{co}x{cr}"] = {"split9": stat(res["split9"][k], ref), "fp32_mfma": stat(res["fp32_mfma"][k], ref)}
     out["note"] = (f"{rows} rows of N(0, 1) inputs / N(0, 0.01) gradients through the two networks' layer shapes with 1 / sqrt(fan-in) weights (tests/test_gpu_mlp_chain_split*.py hold "
-                   "the same comparison at 98,304 rows); weight gradients are fp32 MFMA in both loops.  The bf16 MFMA's accumulator does not round to nearest (a positive sum comes out "
-                   "low): odd slabs accumulate the negated sums, which makes the bias sign-symmetric and lets it cancel in sums over rows (DESIGN.md section 5)")
+                   "the same comparison at 98,304 rows); weight gradients: 98,304 rows of ELU outputs x N(0, 0.01) gradients.  The bf16 MFMA's accumulator does not round to nearest "
+                   "(it truncates: a sum comes out low): odd slabs of the chains and odd sub-ranges of the batch in the weight gradients accumulate the negated sums, which makes "
+                   "the offset cancel in every sum over rows (DESIGN.md section 6.2)")
     return out
 
 
@@ -522,12 +550,18 @@ def main():
         if wg_ev:  # all six hidden-layer weight gradients of both networks: one launch pair per mini-epoch, alone on the GPU
             wus = sum(a.elapsed_time(b) for a, b, *_ in wg_ev) / len(wg_ev) * 1e3
             wfl = wg_ev[0][2]
-            wgrad = {"kernel": "mlp_wgrad_group_kernel (+ its fixed-order finish): dW = G^T A of all six hidden layers of both networks in one launch pair, " +
-                               " + ".join(f"[{co}x{m}]x[{m}x{ci}]" for m, co, ci in wg_ev[0][3]) + ", fp32 MFMA 32x32x2 (hand-written HIP, bg_wgrad.hip)",
-                     "bound": "mfma", "achieved": wfl / (wus * 1e-6) / 1e12, "peak": MFMA_F32_PEAK_TF, "unit": "TFLOP/s",
-                     "frac": wfl / (wus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF, "traffic": pmc_traffic("mlp_wgrad_group_kernel") if N == 4096 else None,
+            split_wg = bool(getattr(runner._wgrad_group, "split", 0))
+            wg_peak = SPLIT9_PEAK_TF if split_wg else MFMA_F32_PEAK_TF
+            wg_kernel = "mlp_wgrad_group_split_kernel<9>" if split_wg else "mlp_wgrad_group_kernel"
+            wgrad = {"kernel": f"{wg_kernel}: dW = G^T A of all six hidden layers of both networks in one launch (its fixed-order finish runs inside the tail's first "
+                               "launch), " + " + ".join(f"[{co}x{m}]x[{m}x{ci}]" for m, co, ci in wg_ev[0][3]) +
+                               (", fp32 operands as exact three-way bf16 splits, all 9 products on v_mfma_f32_32x32x16_bf16, fp32 accumulation, the sub-ranges of the batch "
+                                "alternating the sign of the accumulation (hand-written HIP, bg_wgrad_split.hip)" if split_wg else ", fp32 MFMA 32x32x2 (hand-written HIP, bg_wgrad.hip)"),
+                     "bound": "mfma", "achieved": wfl / (wus * 1e-6) / 1e12, "peak": wg_peak, "unit": "TFLOP/s",
+                     "frac": wfl / (wus * 1e-6) / 1e12 / wg_peak, "frac_of_fp32_mfma_peak": wfl / (wus * 1e-6) / 1e12 / MFMA_F32_PEAK_TF,
+                     "traffic": pmc_traffic(wg_kernel) if N == 4096 else None,
                      "traffic_source": PMC_SOURCE, "avg_launch_us": wus, "algorithmic_flops_per_launch": wfl,
-                     "note": "launch pair (main kernel + finish) timed inside the loop with HIP events on its stream; it runs after both backward chains, alone on the GPU"}
+                     "note": "timed inside the loop with HIP events on its stream; it runs after both backward chains, alone on the GPU"}
         # HBM traffic per launch comes from PMC counters, which rocprofv3 collects in separate passes of the same command (tools/profile.sh
         # -> profiles/<PMC_TAG>_*_pmc.json, FETCH_SIZE corrected as MI355X_MICROARCH.md prescribes); the JSON line names the file it cites
         traffic = pmc_traffic("env_step_kernel", which="env") if N == 4096 else None
@@ -569,11 +603,13 @@ def main():
                        "gemm_arithmetic": ({9: "fp32 operands as exact 3-way bf16 splits, 9 products, fp32 accumulate (BG_GEMM_SPLIT=9, per-layer kernels)",
                                             6: "fp32 operands as exact 3-way bf16 splits, 6 largest products, fp32 accumulate (BG_GEMM_SPLIT=6, per-layer kernels)"}[split_mode]
                                            if split_mode else
-                                           ("hidden-layer forward" + (" and backward-data" if split_bwd else "") + " GEMMs: every fp32 operand the EXACT sum of three bf16 numbers "
+                                           ("hidden-layer forward" + (", backward-data" if split_bwd else "") +
+                                            (" and weight-gradient" if getattr(runner._wgrad_group, "split", 0) else "") + " GEMMs: every fp32 operand the EXACT sum of three bf16 numbers "
                                             "(8 + 8 + 8 significant bits), all 9 cross products on v_mfma_f32_32x32x16_bf16, fp32 accumulation -- products exact as in an fp32 FMA "
                                             "chain, measured error against float64 at or below the fp32-MFMA kernels' (gemm_errors_vs_float64)"
-                                            + ("" if split_bwd else "; backward-data") + "; weight gradients, heads, rollout actor: fp32 MFMA (v_mfma_f32_32x32x2_f32 / "
-                                            "16x16x4_f32).  `fp32_mfma_loop`: the same loop with everything on the fp32 matrix pipe") if split_fwd else
+                                            + ("" if split_bwd else "; backward-data: fp32 MFMA") + ("" if getattr(runner._wgrad_group, "split", 0) else "; weight gradients: fp32 MFMA")
+                                            + "; heads, rollout actor: fp32 VALU / fp32 MFMA (v_mfma_f32_16x16x4_f32).  `fp32_mfma_loop`: the same loop with everything on the fp32 "
+                                            "matrix pipe") if split_fwd else
                                            "fp32 MFMA (v_mfma_f32_32x32x2_f32)")},
             "ppo_iters_per_s": args.steps / wall,
             "phase_ms": {"rollout": roll_ms, "update": upd_ms, "all_reduce_ms": ar_ms},
@@ -627,12 +663,16 @@ def main():
                     dt = time.perf_counter() - ts
                     return it0, {"value": N * T * args.steps / dt, "unit": "env-steps/s", "ms_per_step": dt / args.steps * 1e3}
 
-                keep = (MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD)
+                keep = (MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD, MLPTrainer.WGRAD_SPLIT)
                 MLPTrainer.CHAIN_SPLIT = MLPTrainer.CHAIN_SPLIT_BWD = False
                 it0, fp32 = timed_loop(it0)
                 MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD = True, False
                 it0, fwd_only = timed_loop(it0)
-                MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD = keep
+                MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD, MLPTrainer.WGRAD_SPLIT = keep[0], keep[1], 0
+                it0, fp32_wg = timed_loop(it0)
+                out["fp32_mfma_weight_gradients_loop"] = dict(fp32_wg, gemm_arithmetic="split forward and backward chains, fp32-MFMA weight gradients: BG_WGRAD_SPLIT=0 "
+                                                                                       "(the headline path until late round 6)")
+                MLPTrainer.CHAIN_SPLIT, MLPTrainer.CHAIN_SPLIT_BWD, MLPTrainer.WGRAD_SPLIT = keep
                 one_stream, runner._one_stream = runner._one_stream, False
                 it0, two_streams = timed_loop(it0)
                 runner._one_stream = one_stream
@@ -640,7 +680,7 @@ def main():
                 out["two_launches_on_two_streams_loop"] = dict(two_streams, note="the headline arithmetic with the critic's and the actor's chains as separate launches on "
                                                                                  "two streams (BG_ONE_STREAM=0: the form until mid round 6)")
                 runner._flush_log()
-                fp32["gemm_arithmetic"] = "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: BG_CHAIN_SPLIT=0"
+                fp32["gemm_arithmetic"] = "fp32 MFMA (v_mfma_f32_32x32x2_f32) everywhere: BG_CHAIN_SPLIT=0 (with it the weight gradients take the fp32 launch too)"
                 out["fp32_mfma_loop"] = fp32
                 out["split_forward_only_loop"] = dict(fwd_only, gemm_arithmetic="split forward chain, fp32-MFMA backward layers: BG_CHAIN_SPLIT_BWD=0")
                 out["headline_loop_again"] = dict(again, note="the headline configuration once more behind the two above, uninstrumented (no timing events): what `value` is to be compared with")

@@ -124,7 +124,7 @@ SYMBOLS = [
     "bg_env_set_params", "bg_env_bind_outputs", "bg_env_reset", "bg_env_step", "bg_env_step_to", "bg_env_get_state",
     "bg_env_set_state", "bg_env_get_field", "bg_env_set_field", "bg_env_field_info", "bg_env_get_curriculum", "bg_env_set_curriculum", "bg_env_step_count", "bg_env_set_step_count",
     "bg_env_forward_dynamics", "bg_env_forward_dynamics_packed", "bg_sim_bind_state", "bg_sim_set_actuation", "bg_sim_apply_body_wrench_local", "bg_sim_simulate",
-    "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_optimizer_step", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_chain_forward", "bg_critic_values_gae", "bg_mlp_chain_forward_group", "bg_mlp_chain_forward_split", "bg_mlp_chain_backward_split", "bg_mlp_split_weights_pm", "bg_mlp_layer_backward", "bg_mlp_split_weights", "bg_mlp_layer_forward_split", "bg_mlp_layer_backward_split", "bg_mlp_weight_grad", "bg_mlp_weight_grad_group", "bg_mlp_weight_grad_group_partial", "bg_update_tail", "bg_update_tail_sums", "bg_mlp_weight_grad_group_split",
+    "bg_sim_refresh_body_state", "bg_sim_write_root_state", "bg_sim_write_dof_state", "bg_gae", "bg_ppo_loss", "bg_gaussian_logp", "bg_actor_sample", "bg_adam_step", "bg_adapt_lr", "bg_optimizer_step", "bg_elu_backward_colsum", "bg_mlp_layer_forward", "bg_mlp_chain_forward", "bg_critic_values_gae", "bg_mlp_chain_forward_group", "bg_mlp_chain_forward_split", "bg_mlp_chain_backward_split", "bg_mlp_split_weights_pm", "bg_mlp_layer_backward", "bg_mlp_split_weights", "bg_mlp_layer_forward_split", "bg_mlp_layer_backward_split", "bg_mlp_weight_grad", "bg_mlp_weight_grad_group", "bg_mlp_weight_grad_group_partial", "bg_update_tail", "bg_update_tail_sums", "bg_mlp_weight_grad_group_split", "bg_mlp_weight_grad_group_split_partial",
     "bg_critic_head_forward", "bg_actor_head", "bg_critic_head_backward",
     "bg_reduce_group", "bg_actor_head_partial", "bg_critic_head_backward_partial", "bg_mlp_layer_backward_partial",
     "bg_last_error", "bg_version",
@@ -205,6 +205,7 @@ def load():
         "bg_update_tail": (i32, [C.POINTER(WgradProblem), i32, C.POINTER(ReduceProblem), i32, i32, vp, vp, vp, vp, vp, i32, f32, f32, f32, f32, vp, i32, i32, vp, vp,
                                  vp, i32, i32, f32, f32, f32, f32, vp, vp, vp, i32, vp]),
         "bg_mlp_weight_grad_group_split": (i32, [C.POINTER(WgradProblem), i32, i32, vp]),
+        "bg_mlp_weight_grad_group_split_partial": (i32, [C.POINTER(WgradProblem), i32, i32, vp]),
         "bg_critic_head_forward": (i32, [i32, vp, vp, vp, vp, vp]),
         "bg_actor_head": (i32, [i32, i32] + [vp] * 10 + [f32, f32, f32] + [vp] * 9),
         "bg_critic_head_backward": (i32, [i32] + [vp] * 11),

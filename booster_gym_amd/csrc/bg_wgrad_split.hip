@@ -128,7 +128,7 @@ __device__ __forceinline__ void wgrad_split_tile(float* lds, int M, const float*
     const int buf_fl = ks * grp_fl;
     float* my0 = lds + ksub * grp_fl;  // this group's block in buffer 0 (buffer n: + n * buf_fl)
     // NBUF buffers: the copy of block c + NBUF is started at the top of block c, NBUF - 1 blocks before its first use
-    constexpr int NT = (Cout / 128) * (Cin >= 128 ? Cin / 128 : 1), KS = 4 / NT, NBUF = 3 * KS * grp_fl <= WS_LDS_FLOATS ? 3 : 2;
+    constexpr int NT = (Cout / 128) * (Cin >= 128 ? Cin / 128 : 1), KS = 4 / NT, NBUF = 3 * KS * grp_fl <= WS_LDS_FLOATS ? 3 : 2;  // (four and five buffers in 160 KB: measured no faster, round 6)
     // this wave's share of the group's copy: wave-instructions (1 KB each) q = tl, tl + tw, ... of the block's (gfl + afl) / 256
     constexpr int n_inst = grp_fl / 256, N_MINE = n_inst / NT;
     static_assert(n_inst % NT == 0, "every wave of a group issues the same number of copies");
@@ -178,11 +178,20 @@ __device__ __forceinline__ void wgrad_split_tile(float* lds, int M, const float*
     // four times as many), and are consumed within the row.
     auto block = [&](auto cur_c, const float* src) {
         constexpr int CUR = decltype(cur_c)::value, NXT = 1 - CUR;
+        // the lane's four G floats and TCI A floats of a row pair, read ONE ROW PAIR AHEAD of their use (round 2 had no registers for this -- 16 more and
+        // the kernel spilled; it fits since the split's first step carries its values in the unit's own registers: 232 of 256): 320 -> 308 us
+        f32x4 gq[2][2]; avec aq[2][2];
+        auto rd = [&](int t, int w) {
+            gq[w][0] = *reinterpret_cast<const f32x4*>(src + gofs + (2 * t) * Cout); gq[w][1] = *reinterpret_cast<const f32x4*>(src + gofs + (2 * t + 1) * Cout);
+            aq[w][0] = *reinterpret_cast<const avec*>(src + aofs + (2 * t) * Cin); aq[w][1] = *reinterpret_cast<const avec*>(src + aofs + (2 * t + 1) * Cin);
+        };
+        rd(0, 0);
 #pragma unroll
         for (int t = 0; t < 4; t++) {
-            // (reading a row ahead was tried: 16 more registers and the kernel spills)
-            const f32x4 g0 = *reinterpret_cast<const f32x4*>(src + gofs + (2 * t) * Cout), g1 = *reinterpret_cast<const f32x4*>(src + gofs + (2 * t + 1) * Cout);
-            const avec a0 = *reinterpret_cast<const avec*>(src + aofs + (2 * t) * Cin), a1 = *reinterpret_cast<const avec*>(src + aofs + (2 * t + 1) * Cin);
+            if (t < 3) rd(t + 1, (t + 1) & 1);  // the next row pair's four reads are in flight under this row's MFMAs
+            BG_PIN();
+            const f32x4 g0 = gq[t & 1][0], g1 = gq[t & 1][1];
+            const avec a0 = aq[t & 1][0], a1 = aq[t & 1][1];
 #pragma unroll
             for (int u = 0; u < TCI; u++) {
                 float x[4], y[4];
@@ -277,7 +286,7 @@ __global__ __launch_bounds__(256, 1) void mlp_wgrad_group_split_kernel(WgradGrou
     else wgrad_split_tile<256, 64, TERMS>(lds, pr.M, pr.G, pr.A, pr.P, pr.ntile_ci, tile0, pr.tw, slice, pr.slices);
 }
 
-extern "C" int bg_mlp_weight_grad_group_split(const bg_wgrad_problem* problems, int32_t count, int32_t terms, void* stream) {
+static int split_launch(const bg_wgrad_problem* problems, int32_t count, int32_t terms, void* stream, bool finish) {
     if (terms != 9 && terms != 6) return bg_set_error(-4, "bg_mlp_weight_grad_group_split: terms must be 9 or 6");
     WgradGroup grp;
     int wg = 0, fin = 0;
@@ -296,7 +305,15 @@ extern "C" int bg_mlp_weight_grad_group_split(const bg_wgrad_problem* problems, 
     hipStream_t st = (hipStream_t)stream;
     if (terms == 9) hipLaunchKernelGGL(mlp_wgrad_group_split_kernel<9>, dim3(wg), dim3(256), 0, st, grp);
     else hipLaunchKernelGGL(mlp_wgrad_group_split_kernel<6>, dim3(wg), dim3(256), 0, st, grp);
-    if (bg_wgrad_group_finish_launch(grp, fin, st)) return bg_set_error(-2, "bg_mlp_weight_grad_group_split: launch failed");
+    if (finish && bg_wgrad_group_finish_launch(grp, fin, st)) return bg_set_error(-2, "bg_mlp_weight_grad_group_split: launch failed");
     HIP_OK(hipGetLastError());
     return 0;
+}
+
+extern "C" int bg_mlp_weight_grad_group_split(const bg_wgrad_problem* problems, int32_t count, int32_t terms, void* stream) {
+    return split_launch(problems, count, terms, stream, true);
+}
+// ... without its finish: the partial tiles stay in `scratch` for bg_update_tail (as bg_mlp_weight_grad_group_partial; same scratch layout)
+extern "C" int bg_mlp_weight_grad_group_split_partial(const bg_wgrad_problem* problems, int32_t count, int32_t terms, void* stream) {
+    return split_launch(problems, count, terms, stream, false);
 }

@@ -68,11 +68,13 @@ class GroupedWeightGrad:
         probs = [p for tr in trainers for p in tr.pending_wgrad_problems()]
         if not probs:
             return None
-        key = (MLPTrainer.SPLIT,) + tuple((g.data_ptr(), a.data_ptr(), dw.data_ptr(), g.shape[0], co, ci, cr) for g, a, dw, co, ci, cr in probs)
+        key = (MLPTrainer.SPLIT, MLPTrainer.WGRAD_SPLIT) + tuple((g.data_ptr(), a.data_ptr(), dw.data_ptr(), g.shape[0], co, ci, cr) for g, a, dw, co, ci, cr in probs)
         if key != self._key:  # buffers are static: built once
             rows = probs[0][0].shape[0]
             # split mode (bg_mlp_weight_grad_group_split): the waves of a workgroup share their rows through LDS, all tiles of a layer in one workgroup
-            self.split = MLPTrainer.SPLIT if rows % 32 == 0 and rows >= 128 and all((co, ci) in ((256, 256), (128, 256), (128, 128), (256, 64)) for _, _, _, co, ci, _ in probs) else 0
+            # (MLPTrainer.WGRAD_SPLIT: the split launch behind the chained kernels, its finish inside bg_update_tail like the fp32 launch's)
+            chained = all(tr._chain_split_bwd() for tr in trainers)
+            self.split = (MLPTrainer.SPLIT or (MLPTrainer.WGRAD_SPLIT if chained else 0)) if rows % 32 == 0 and rows >= 128 and all((co, ci) in ((256, 256), (128, 256), (128, 128), (256, 64)) for _, _, _, co, ci, _ in probs) else 0
             slices, tw = plan_wgrad_slices([(co, ci) for _, _, _, co, ci, _ in probs], rows, self.workgroups, share_rows=self.share_rows or bool(self.split))
             self._scratch = [torch.empty(sl * co * ci, dtype=torch.float32, device=probs[0][0].device) for sl, (_, _, _, co, ci, _) in zip(slices, probs)]
             arr = (_lib.WgradProblem * len(probs))()
@@ -84,8 +86,10 @@ class GroupedWeightGrad:
         if ev is not None:  # bench.py: HIP events on the launch stream around the launch pair
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
-        partial = not finish and not self.split
-        if self.split:
+        partial = not finish and (not self.split or not MLPTrainer.SPLIT)
+        if self.split and partial:
+            _lib.check(_lib.load().bg_mlp_weight_grad_group_split_partial(self._arr, len(probs), self.split, _lib.current_stream_ptr()), "bg_mlp_weight_grad_group_split_partial")
+        elif self.split:
             _lib.check(_lib.load().bg_mlp_weight_grad_group_split(self._arr, len(probs), self.split, _lib.current_stream_ptr()), "bg_mlp_weight_grad_group_split")
         elif partial:
             _lib.check(_lib.load().bg_mlp_weight_grad_group_partial(self._arr, len(probs), _lib.current_stream_ptr()), "bg_mlp_weight_grad_group_partial")
@@ -117,6 +121,11 @@ class MLPTrainer:
     # Opt-in (BG_GEMM_SPLIT=9 or 6): the same layers on the bf16 matrix pipe, every fp32 operand split exactly into three bf16 numbers and all 9
     # (or the 6 largest) cross products accumulated in fp32 (bg_mlp_split.hip).  0 = the fp32 MFMA kernels.
     SPLIT = int(__import__("os").environ.get("BG_GEMM_SPLIT", "0"))
+    # The grouped weight-gradient launch on the bf16 matrix pipe as well (bg_wgrad_split.hip: exact 3-way splits, all 9 products, the sub-ranges of the
+    # batch alternating the sign of the accumulation; its error against float64 is 0.84-0.89 of the fp32-MFMA launch's and it is 0.4 ms per iteration
+    # faster in the loop: profiles/r06_wgrad_split_*).  BG_WGRAD_SPLIT=0: the fp32-MFMA launch (bg_wgrad.hip).  Applies behind the chained split kernels
+    # only (GroupedWeightGrad.run); shapes outside the split kernel's four take the fp32 launch.
+    WGRAD_SPLIT = int(__import__("os").environ.get("BG_WGRAD_SPLIT", "9"))
 
     @classmethod
     def _fusable(cls, k_in, n_out):

@@ -398,6 +398,8 @@ int bg_mlp_weight_grad_group_partial(const bg_wgrad_problem* problems, int32_t c
  * tiles_per_workgroup must equal the layer's tile count (1, 2 or 4).  Shapes: 256 x 256, 128 x 256, 128 x 128, 256 x 64 (C_out x C_in padded), M a
  * multiple of 32; anything else returns -4 and the caller uses bg_mlp_weight_grad_group.  Same scratch layout and fixed-order finish. */
 int bg_mlp_weight_grad_group_split(const bg_wgrad_problem* problems, int32_t count, int32_t terms, void* stream);
+/* ... without its finish, for bg_update_tail (as bg_mlp_weight_grad_group_partial: the same scratch layout, the same finish). */
+int bg_mlp_weight_grad_group_split_partial(const bg_wgrad_problem* problems, int32_t count, int32_t terms, void* stream);
 
 /* ---- output ("head") layers fused with the loss: the 128 -> 12 / 128 -> 1 Linear layers of utils/model.py:13,21 together with
  * runner.py:145-174.  h [rows][128] = activations of the last hidden (ELU) layer, 16-byte aligned.  One launch reads h once instead of

@@ -350,7 +350,7 @@ SWITCHES = {
     "default": ({}, {}),
     # (environment switches and the attributes they set: BG_ONE_LAUNCH_TAIL -> _one_launch_tail, BG_SPLIT_CHAIN_CUS -> _split_chain_cus,
     #  BG_ONE_STREAM -> _one_stream, BG_ROLLOUT_FORWARD -> _rollout_forward, BG_ROLLOUT_FORWARD_GROUP -> _rollout_group, BG_DEFER_FINISH -> _defer_finish / _defer_serial (own test below),
-    #  BG_CHAIN_SPLIT / BG_CHAIN_SPLIT_BWD / BG_CHAIN_ALTERNATE -> MLPTrainer.CHAIN_SPLIT / CHAIN_SPLIT_BWD / CHAIN_ALTERNATE; BG_OWN_RCCL = 0 and 1: tests/test_gpu_rccl.py; BG_FWD_CHAIN_CUS / BG_BWD_CHAIN_CUS: test_cu_shares_of_the_chains_change_no_bit below)
+    #  BG_CHAIN_SPLIT / BG_CHAIN_SPLIT_BWD / BG_CHAIN_ALTERNATE / BG_WGRAD_SPLIT -> MLPTrainer.CHAIN_SPLIT / CHAIN_SPLIT_BWD / CHAIN_ALTERNATE / WGRAD_SPLIT; BG_OWN_RCCL = 0 and 1: tests/test_gpu_rccl.py; BG_FWD_CHAIN_CUS / BG_BWD_CHAIN_CUS: test_cu_shares_of_the_chains_change_no_bit below)
     "tail_as_three_launches": ({"_one_launch_tail": False}, {}),                  # reduce_group, weight gradients + finish, optimizer_step (what ranks of a job run)
     "separate_optimizer_tail": ({"_fused_opt": False}, {}),                      # bg_adam_step + bg_adapt_lr + torch adds (first step after a restore)
     "gae_as_three_launches": ({"_fused_gae": False}, {}),                        # bg_critic_head_forward + fill + bg_gae (horizons beyond 32 steps)
@@ -361,6 +361,7 @@ SWITCHES = {
     "weight_gradients_as_library_gemms": ({}, {"FUSED_WGRAD": False}),           # split-K bmm + sum
     "fp32_mfma_chains": ({}, {"CHAIN_SPLIT": False}),                            # BG_CHAIN_SPLIT=0: forward chain and backward layers on the fp32 matrix pipe (round 5's default)
     "split_forward_fp32_mfma_backward": ({}, {"CHAIN_SPLIT_BWD": False}),        # BG_CHAIN_SPLIT_BWD=0: the chained split forward, one fp32-MFMA launch per backward layer
+    "fp32_mfma_weight_gradients": ({}, {"WGRAD_SPLIT": 0}),                      # BG_WGRAD_SPLIT=0: the grouped weight gradients on the fp32 matrix pipe (bg_wgrad.hip; the default until late round 6)
     "plain_accumulation": ({}, {"CHAIN_ALTERNATE": False}),                      # BG_CHAIN_ALTERNATE=0: no slab accumulates the negated sums
     "chain_one_workgroup_per_slab": ({"_split_chain_cus": False}, {}),            # BG_SPLIT_CHAIN_CUS=0: the two forward launches share the chip by slabs instead of by CUs
     "backward_chain_one_workgroup_per_slab": ({"_split_bwd_chain_cus": False}, {}),  # BG_SPLIT_BWD_CHAIN_CUS=0: ... and the two backward launches
