@@ -92,12 +92,19 @@ __device__ __forceinline__ void tile_mfmas(f32x16& acc, const u32x4 (&g)[3], con
     constexpr int GP[9] = {2, 1, 2, 0, 1, 2, 0, 1, 0}, AP[9] = {2, 2, 1, 2, 1, 0, 1, 0, 0};
     constexpr int NOPS = 11 * NU;
     SplitUnit s[4];
+#ifdef WS_ABL_NOSPLIT
+    for (int k = 0; k < NU; k++) { o[k].h = __float_as_uint(x[k]); o[k].m = __float_as_uint(y[k]); o[k].l = 0u; }
+#endif
 #pragma unroll
     for (int m = 0; m < TERMS; m++) {
         const int term = 9 - TERMS + m;
         BG_MFMA(acc, g[GP[term]], a[AP[term]]);
 #pragma unroll
-        for (int op = (m * NOPS) / TERMS; op < ((m + 1) * NOPS) / TERMS; op++) split_op<NU == 0 ? 1 : NU>(op, s, x, y, o, NU - 1, sgn);  // (units 0 .. NU - 2: G's; the last: A's)
+        for (int op = (m * NOPS) / TERMS; op < ((m + 1) * NOPS) / TERMS; op++) {
+#ifndef WS_ABL_NOSPLIT  // (tools/probe builds: the loop without the split's VALU work -- never defined in the product build)
+            split_op<NU == 0 ? 1 : NU>(op, s, x, y, o, NU - 1, sgn);  // (units 0 .. NU - 2: G's; the last: A's)
+#endif
+        }
         BG_PIN();
     }
 }
@@ -182,6 +189,9 @@ __device__ __forceinline__ void wgrad_split_tile(float* lds, int M, const float*
         // the kernel spilled; it fits since the split's first step carries its values in the unit's own registers: 232 of 256): 320 -> 308 us
         f32x4 gq[2][2]; avec aq[2][2];
         auto rd = [&](int t, int w) {
+#ifdef WS_ABL_NOLDSREAD
+            gq[w][0] = gq[w][1] = f32x4{1.f, 2.f, 3.f, 4.f}; aq[w][0] = aq[w][1] = avec(1.5f); return;
+#endif
             gq[w][0] = *reinterpret_cast<const f32x4*>(src + gofs + (2 * t) * Cout); gq[w][1] = *reinterpret_cast<const f32x4*>(src + gofs + (2 * t + 1) * Cout);
             aq[w][0] = *reinterpret_cast<const avec*>(src + aofs + (2 * t) * Cin); aq[w][1] = *reinterpret_cast<const avec*>(src + aofs + (2 * t + 1) * Cin);
         };
@@ -217,7 +227,9 @@ __device__ __forceinline__ void wgrad_split_tile(float* lds, int M, const float*
     // (raw s_barrier: __syncthreads() would drain them) -- then everybody is done with buffer c % NBUF and the copy of block c + NBUF goes there
     auto top = [&](int c) {
         __builtin_amdgcn_s_waitcnt(0x0F70 | ((NBUF - 2) * N_MINE & 15) | (((NBUF - 2) * N_MINE >> 4) << 14));
+#ifndef WS_ABL_NOBARRIER
         __builtin_amdgcn_s_barrier();
+#endif
 #ifndef BG_PROBE_NO_STAGE  // tools/archive/wgrad_split_parts_probe.py: the loop without its copies (never defined in the product build)
         stage(c + NBUF);
 #endif
