@@ -18,7 +18,8 @@ Same surface: `Runner(test=False)` parses the reference's 8 CLI flags (runner.py
               heads + loss   output layers fused with the PPO loss and its backward (bg_critic_head_backward, bg_actor_head);
               backward-data  the hidden layers of both networks as ONE launch (bg_mlp_chain_backward_split: same arithmetic, ELU' and bias-gradient
                              sums in its epilogues; BG_CHAIN_SPLIT_BWD=0: one fp32-MFMA launch per layer);
-              weight grads   all six hidden layers of both networks in one grouped fp32-MFMA launch (bg_mlp_weight_grad_group_partial);
+              weight grads   all six hidden layers of both networks in one grouped launch, the same bf16-pipe arithmetic
+                             (bg_mlp_weight_grad_group_split_partial; BG_WGRAD_SPLIT=0: the fp32-MFMA launch bg_mlp_weight_grad_group_partial);
               tail           two launches (bg_update_tail): the deferred fixed-order sums + the squared-norm pieces, then clip + Adam + KL learning-rate
                              rule + statistics bookkeeping + the copies of the weights the layer kernels read (bf16 planes of W, -W, W^T, -W^T).
   multi-GPU one process per GPU (torchrun), environments sharded; per mini-epoch one float64 moments all-reduce on the side stream and ONE grouped RCCL
