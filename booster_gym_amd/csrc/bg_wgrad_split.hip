@@ -98,7 +98,9 @@ __device__ __forceinline__ void tile_mfmas(f32x16& acc, const u32x4 (&g)[3], con
 #pragma unroll
     for (int m = 0; m < TERMS; m++) {
         const int term = 9 - TERMS + m;
+#ifndef WS_ABL_NOMFMA  // (probe builds: the loop's copies, reads and split without the matrix work)
         BG_MFMA(acc, g[GP[term]], a[AP[term]]);
+#endif
 #pragma unroll
         for (int op = (m * NOPS) / TERMS; op < ((m + 1) * NOPS) / TERMS; op++) {
 #ifndef WS_ABL_NOSPLIT  // (tools/probe builds: the loop without the split's VALU work -- never defined in the product build)
